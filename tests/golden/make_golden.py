@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE's own hot-path modules (build container only).
+
+The reference (/root/reference, Python) imports here once its absent *third-party* packages are given in-memory
+stand-ins: pedestrians_scenarios (Skeleton/CARLA_SKELETON enums, deepcopy helpers), pytorch3d 0.6.0
+(rotation conversions, look_at_view_transform, screen-space PerspectiveCameras), cameratransform, pytorch_lightning's
+rank_zero_warn. The stand-ins re-state those packages' public definitions -- they are this build's code, not the
+reference's. Every module of the reference itself (ProjectionModule, P3dPose, P3dPoseProjection, ControlledPedestrian,
+Normalizer + extractors, ReferenceSkeletonsDeNormalizer, LossModes / Loc2DPoseLoss / loc_3d / loc_2d_3d,
+calculate_world_from_changes, get_common_indices, LinearAE, Seq2SeqEmbeddings) is imported and executed unmodified.
+
+Outputs are data only (inputs + expected outputs), small (B=4, T=16). /root/reference never travels to the GPU box;
+tests read the committed .npz files.
+"""
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF_SRC = '/root/reference/src'
+
+warnings.filterwarnings('ignore')
+
+
+# ------------------------------------------------------------------------------------------------------------
+# stand-ins for third-party packages (NOT for any reference module)
+# ------------------------------------------------------------------------------------------------------------
+def _module(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    parent, _, child = name.rpartition('.')
+    if parent:
+        if parent not in sys.modules:
+            _module(parent)
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+def install_standins():
+    from pedestrians_video_2_carla_amd.data.base.skeleton import Skeleton
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from oracle import pose_head as O
+
+    # --- pedestrians_scenarios 0.0.1 -------------------------------------------------------------------------
+    _module('pedestrians_scenarios')
+    _module('pedestrians_scenarios.karma')
+    _module('pedestrians_scenarios.karma.pose')
+    _module('pedestrians_scenarios.karma.pose.skeleton', Skeleton=Skeleton, CARLA_SKELETON=CARLA_SKELETON)
+    _module('pedestrians_scenarios.karma.pose.types', PoseDict=dict)
+    _module('pedestrians_scenarios.karma.utils')
+
+    def deepcopy_location(l):
+        return type(l)(x=l.x, y=l.y, z=l.z)
+
+    def deepcopy_rotation(r):
+        return type(r)(pitch=r.pitch, yaw=r.yaw, roll=r.roll)
+
+    def deepcopy_transform(t):
+        return type(t)(location=deepcopy_location(t.location), rotation=deepcopy_rotation(t.rotation))
+
+    _module('pedestrians_scenarios.karma.utils.deepcopy', deepcopy_location=deepcopy_location,
+            deepcopy_rotation=deepcopy_rotation, deepcopy_transform=deepcopy_transform)
+    _module('pedestrians_scenarios.karma.utils.rotations', mul_carla_rotations=None)
+
+    # --- pytorch3d 0.6.0 --------------------------------------------------------------------------------------
+    def euler_angles_to_matrix(euler_angles, convention):
+        assert convention == 'XYZ'
+        return O.euler_angles_to_matrix_xyz(euler_angles)
+
+    def matrix_to_euler_angles(*a, **k):
+        raise NotImplementedError('not on the hot path')
+
+    def look_at_view_transform(eye, at, up):
+        eye, at, up = (torch.tensor(v, dtype=torch.float32) for v in (eye, at, up))
+        nrm = torch.nn.functional.normalize
+        z = nrm(at - eye, dim=-1)
+        x = nrm(torch.cross(up, z, dim=-1), dim=-1)
+        y = nrm(torch.cross(z, x, dim=-1), dim=-1)
+        R = torch.stack((x, y, z), dim=-1)                  # columns x, y, z
+        T = -(R.transpose(1, 2) @ eye[..., None])[..., 0]
+        return R, T
+
+    class PerspectiveCameras:
+        def __init__(self, device, in_ndc, focal_length, principal_point, image_size, R, T):
+            assert in_ndc is False
+            self.device = device
+            self.f = float(np.asarray(focal_length).reshape(-1)[0])
+            self.pp = torch.tensor(principal_point, dtype=torch.float32, device=device).reshape(-1, 2)
+            self.R = R.to(device)
+            self.T = T.to(device)
+
+        def transform_points_screen(self, points):
+            view = points @ self.R + self.T[:, None, :]
+            X, Y, Z = view[..., 0], view[..., 1], view[..., 2]
+            return torch.stack((self.pp[:, 0:1] - self.f * X / Z, self.pp[:, 1:2] - self.f * Y / Z, 1.0 / Z), -1)
+
+    _module('pytorch3d')
+    _module('pytorch3d.transforms', euler_angles_to_matrix=euler_angles_to_matrix,
+            rotation_6d_to_matrix=O.rotation_6d_to_matrix, matrix_to_rotation_6d=O.matrix_to_rotation_6d)
+    _module('pytorch3d.transforms.rotation_conversions', euler_angles_to_matrix=euler_angles_to_matrix,
+            matrix_to_euler_angles=matrix_to_euler_angles, rotation_6d_to_matrix=O.rotation_6d_to_matrix,
+            matrix_to_rotation_6d=O.matrix_to_rotation_6d)
+    _module('pytorch3d.transforms.transform3d', Rotate=None, Translate=None)
+    _module('pytorch3d.renderer')
+    _module('pytorch3d.renderer.cameras', PerspectiveCameras=PerspectiveCameras,
+            look_at_view_transform=look_at_view_transform)
+
+    # --- misc ---------------------------------------------------------------------------------------------------
+    _module('cameratransform')
+    _module('pytorch_lightning')
+    _module('pytorch_lightning.utilities')
+    _module('pytorch_lightning.utilities.warnings', rank_zero_warn=lambda *a, **k: None)
+
+
+def npz(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, len(out), 'arrays')
+
+
+def main():
+    if not os.path.isdir(REF_SRC):
+        sys.exit('reference tree not present: the committed .npz files are the artefact to use')
+    install_standins()
+    sys.path.insert(0, REF_SRC)
+    torch.manual_seed(22742)
+
+    import pedestrians_video_2_carla as pkg  # noqa: F401
+    from pedestrians_video_2_carla.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla.data.openpose.skeleton import BODY_25_SKELETON, COCO_SKELETON
+    from pedestrians_video_2_carla.data.base.skeleton import get_common_indices
+    from pedestrians_video_2_carla.data.carla import reference as ref_tables
+    from pedestrians_video_2_carla.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla.modules.layers.projection import ProjectionModule
+    from pedestrians_video_2_carla.transforms.pose.normalization import Normalizer
+    from pedestrians_video_2_carla.transforms.pose.normalization.hips_neck_extractor import HipsNeckExtractor
+    from pedestrians_video_2_carla.transforms.pose.normalization.bbox_extractor import BBoxExtractor
+    from pedestrians_video_2_carla.transforms.pose.normalization.hips_neck_bbox_fallback_extractor import \
+        HipsNeckBBoxFallbackExtractor
+    from pedestrians_video_2_carla.transforms.pose.normalization.reference_skeletons_denormalizer import \
+        ReferenceSkeletonsDeNormalizer
+    from pedestrians_video_2_carla.loss import LossModes
+    from pedestrians_video_2_carla.utils.world import calculate_world_from_changes
+    from pedestrians_video_2_carla.utils.tensors import get_bboxes
+    from pytorch3d.transforms import rotation_6d_to_matrix, euler_angles_to_matrix
+
+    types_ = ref_tables.CARLA_REFERENCE_SKELETON_TYPES
+    B, T, J = 4, 16, 26
+    meta = {'age': [a for a, _ in types_], 'gender': [g for _, g in types_]}
+
+    # ---- 0. reference tables ------------------------------------------------------------------------------------
+    rel_loc, rel_rot = ref_tables.get_relative_tensors()
+    abs_loc, abs_rot = ref_tables.get_absolute_tensors()
+    projections = ref_tables.get_projections()
+    npz('reference_tables', rel_loc=rel_loc, rel_rot=rel_rot, abs_loc=abs_loc, abs_rot=abs_rot,
+        projections=projections)
+
+    def run_losses(sliced, targets, in_nodes=CARLA_SKELETON, out_nodes=CARLA_SKELETON, mask=True):
+        res = {}
+        l2d = LossModes.loc_2d.value[0](criterion=LossModes.loc_2d.value[1], input_nodes=in_nodes,
+                                        output_nodes=out_nodes, mask_missing_joints=mask)
+        res['loc_2d'] = l2d(targets=targets, **sliced)
+        res['loc_3d'] = LossModes.loc_3d.value[0](criterion=LossModes.loc_3d.value[1], input_nodes=in_nodes,
+                                                  output_nodes=out_nodes, targets=targets, **sliced)
+        res['loc_2d_3d'] = LossModes.loc_2d_3d.value[0](requirements=res)
+        return res
+
+    def make_targets(seed, missing=0.0):
+        g = torch.Generator().manual_seed(seed)
+        ang = (torch.rand(B, T, J, 3, generator=g) * 2 - 1) * np.deg2rad(8.0)
+        pm = ProjectionModule(movements_output_type=MT.pose_changes)
+        pm.on_batch_start((torch.zeros(B, T, J, 2), None, meta), 0)
+        proj, d = pm(euler_angles_to_matrix(ang, 'XYZ'), None, None)
+        norm = Normalizer(HipsNeckBBoxFallbackExtractor(CARLA_SKELETON))
+        p2t = norm(proj[..., :2].clone())
+        if missing > 0:
+            miss = torch.rand(B, T, J, generator=g) < missing
+            p2t[miss] = 0.0
+        return {'projection_2d': proj[..., :2].clone(), 'projection_2d_transformed': p2t,
+                'absolute_pose_loc': d['absolute_pose_loc'].clone()}
+
+    # ---- 1. pose_changes variant (6D model output), with and without missing gt joints, with world motion ------
+    for tag, missing, world in (('pose_changes', 0.0, False), ('pose_changes_missing', 0.15, False),
+                                ('pose_changes_world', 0.0, True)):
+        g = torch.Generator().manual_seed(1 if not world else 2)
+        y6d = torch.randn(B, T, J, 6, generator=g)
+        y6d[..., 0] += 2.0
+        y6d[..., 4] += 2.0            # near-identity-ish but far from degenerate
+        y6d.requires_grad_(True)
+        targets = make_targets(11, missing)
+        dloc = drot = None
+        if world:
+            dloc = torch.randn(B, T, 3, generator=g) * 0.05
+            drot = euler_angles_to_matrix((torch.rand(B, T, 3, generator=g) * 2 - 1) * 0.1, 'XYZ')
+        pm = ProjectionModule(movements_output_type=MT.pose_changes)
+        pm.on_batch_start((torch.zeros(B, T, J, 2), None, meta), 0)
+        changes = rotation_6d_to_matrix(y6d)
+        proj, d = pm(changes, dloc, drot)
+        norm = Normalizer(HipsNeckBBoxFallbackExtractor(CARLA_SKELETON))
+        proj_t = norm(proj)
+        sliced = {'projection_2d': proj, 'projection_2d_transformed': proj_t, **d}
+        res = run_losses(sliced, targets)
+        res['loc_2d_3d'].backward()
+        npz(tag, y6d=y6d, pose_changes=changes, skel_type=np.arange(4),
+            dloc=dloc if world else np.zeros(0), drot=drot if world else np.zeros(0),
+            projection_2d=proj, projection_2d_transformed=proj_t, shift=norm.shift, scale=norm.scale,
+            relative_pose_loc=d['relative_pose_loc'], relative_pose_rot=d['relative_pose_rot'],
+            absolute_pose_loc=d['absolute_pose_loc'], absolute_pose_rot=d['absolute_pose_rot'],
+            world_loc=d['world_loc'], world_rot=d['world_rot'],
+            gt_projection_2d_transformed=targets['projection_2d_transformed'],
+            gt_absolute_pose_loc=targets['absolute_pose_loc'],
+            loc_2d=res['loc_2d'], loc_3d=res['loc_3d'], loc_2d_3d=res['loc_2d_3d'], grad_y=y6d.grad)
+
+    # ---- 2. absolute_loc variant -----------------------------------------------------------------------------------
+    g = torch.Generator().manual_seed(3)
+    targets = make_targets(12)
+    y = (targets['absolute_pose_loc'] * 0.7 + 0.1 * torch.randn(B, T, J, 3, generator=g) + 0.3).requires_grad_(True)
+    pm = ProjectionModule(movements_output_type=MT.absolute_loc)
+    pm.on_batch_start((torch.zeros(B, T, J, 2), None, meta), 0)
+    proj, d = pm(y, None, None)
+    norm = Normalizer(HipsNeckBBoxFallbackExtractor(CARLA_SKELETON))
+    proj_t = norm(proj)
+    res = run_losses({'projection_2d': proj, 'projection_2d_transformed': proj_t, **d}, targets)
+    res['loc_2d_3d'].backward()
+    npz('absolute_loc', y=y, skel_type=np.arange(4), projection_2d=proj, projection_2d_transformed=proj_t,
+        absolute_pose_loc=d['absolute_pose_loc'], world_loc=d['world_loc'], world_rot=d['world_rot'],
+        gt_projection_2d_transformed=targets['projection_2d_transformed'],
+        gt_absolute_pose_loc=targets['absolute_pose_loc'],
+        loc_2d=res['loc_2d'], loc_3d=res['loc_3d'], loc_2d_3d=res['loc_2d_3d'], grad_y=y.grad)
+
+    # ---- 3. relative_rot variant -----------------------------------------------------------------------------------
+    g = torch.Generator().manual_seed(4)
+    y6d = torch.randn(B, T, J, 6, generator=g)
+    pm = ProjectionModule(movements_output_type=MT.relative_rot)
+    pm.on_batch_start((torch.zeros(B, T, J, 2), None, meta), 0)
+    proj, d = pm(rotation_6d_to_matrix(y6d), None, None)
+    npz('relative_rot', y6d=y6d, skel_type=np.arange(4), projection_2d=proj,
+        absolute_pose_loc=d['absolute_pose_loc'], absolute_pose_rot=d['absolute_pose_rot'],
+        relative_pose_loc=d['relative_pose_loc'])
+
+    # ---- 4. normalisers incl. fallback paths --------------------------------------------------------------------------
+    g = torch.Generator().manual_seed(5)
+    base = make_targets(13)['projection_2d']                       # pixels
+    cases = base.clone()                                           # (4,16,26,2)
+    cases[0, 0:4, 1] = 0.0                                         # hips missing
+    cases[0, 4:8, 8] = 0.0                                         # neck missing
+    cases[1, 0:4, [1, 8]] = 0.0                                    # both
+    cases[1, 4:8] = 0.0                                            # all joints missing
+    cases[2, 0:4, 3:20] = 0.0                                      # many missing, hips present
+    cases[2, 4:8, 1] = -5.0                                        # negative hips == "missing" for < near_zero test
+    cases[3, 0:4] = cases[3, 0:4] - 450.0                          # partially negative coordinates
+    conf = torch.rand(B, T, J, 1, generator=g)
+    conf[3, 8:12, 5:9] = 0.0                                       # zero-confidence joints -> xy zeroed
+    cases3 = torch.cat((cases, conf), -1)
+    outs = {}
+    for name, ext in (('hips_neck', HipsNeckExtractor), ('bbox', BBoxExtractor),
+                      ('hips_neck_bbox', HipsNeckBBoxFallbackExtractor)):
+        n = Normalizer(ext(CARLA_SKELETON))
+        outs[f'{name}_out2'] = n(cases.clone())
+        outs[f'{name}_shift2'] = n.shift
+        outs[f'{name}_scale2'] = n.scale
+        outs[f'{name}_out3'] = n(cases3.clone())
+    outs['bboxes'] = get_bboxes(cases)
+    npz('normalizers', cases=cases, cases3=cases3, **outs)
+
+    # normaliser gradients through the fallback path (bbox scale) and the regular path
+    x = cases.clone()
+    x[1, 4:8] = base[1, 4:8]                                        # drop the all-missing rows (nan grads in reference)
+    x.requires_grad_(True)
+    n = Normalizer(HipsNeckBBoxFallbackExtractor(CARLA_SKELETON))
+    w = torch.randn(B, T, J, 2, generator=g)
+    (n(x) * w).sum().backward()
+    npz('normalizer_grad', x=x, w=w, grad=x.grad)
+
+    # ---- 5. reference-skeleton de-normaliser ---------------------------------------------------------------------------
+    dn = ReferenceSkeletonsDeNormalizer()
+    xin = abs_loc[:, None].repeat(1, 3, 1, 1) * torch.tensor([0.5, 1.0, 2.5]).reshape(1, 3, 1, 1) + 0.25
+    npz('denormalizer', x=xin, out=dn.from_abs(xin, meta, autonormalize=True))
+
+    # ---- 6. joint index maps ---------------------------------------------------------------------------------------------
+    def as_arr(v):
+        return np.arange(26) if isinstance(v, slice) else np.asarray(v)
+    pairs = {}
+    for a_name, a in (('body25', BODY_25_SKELETON), ('coco', COCO_SKELETON), ('carla', CARLA_SKELETON)):
+        for b_name, b in (('body25', BODY_25_SKELETON), ('coco', COCO_SKELETON), ('carla', CARLA_SKELETON)):
+            if a is b:
+                continue
+            o, i = get_common_indices(input_nodes=a, output_nodes=b)
+            pairs[f'in_{a_name}__out_{b_name}__out_idx'] = as_arr(o)
+            pairs[f'in_{a_name}__out_{b_name}__in_idx'] = as_arr(i)
+    npz('common_indices', **pairs)
+
+    # ---- 7. world transform with real rotations -----------------------------------------------------------------------------
+    g = torch.Generator().manual_seed(6)
+    dloc = torch.randn(3, 10, 3, generator=g)
+    drot = euler_angles_to_matrix(torch.rand(3, 10, 3, generator=g), 'XYZ')
+    il = torch.randn(3, 3, generator=g)
+    ir = euler_angles_to_matrix(torch.rand(3, 3, generator=g), 'XYZ')
+    wl, wr = calculate_world_from_changes((3, 10, 26, 3), torch.device('cpu'), dloc, drot, il, ir)
+    npz('world', dloc=dloc, drot=drot, init_loc=il, init_rot=ir, world_loc=wl, world_rot=wr)
+
+    # ---- 8. model plugins under a fixed state_dict ------------------------------------------------------------------------------
+    from pedestrians_video_2_carla.modules.movements.linear_ae.linear_ae import LinearAE
+    from pedestrians_video_2_carla.modules.movements.seq2seq.seq2seq_embeddings import Seq2SeqEmbeddings
+    frames = make_targets(14)['projection_2d_transformed']
+    for name, cls, kw in (
+            ('linear_ae_pose_changes', LinearAE, dict(movements_output_type=MT.pose_changes)),
+            ('linear_ae_absolute_loc', LinearAE, dict(movements_output_type=MT.absolute_loc)),
+            ('linear_ae_pose_2d', LinearAE, dict(movements_output_type=MT.pose_2d)),
+            ('seq2seq_embeddings_pose_2d', Seq2SeqEmbeddings, dict(movements_output_type=MT.pose_2d)),
+    ):
+        torch.manual_seed(22742)
+        model = cls(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, **kw).eval()
+        with torch.no_grad():
+            out = model(frames)
+        sd = {('sd__' + k): v for k, v in model.state_dict().items()}
+        npz('model_' + name, frames=frames, out=out, n_params=sum(p.numel() for p in model.parameters()), **sd)
+
+
+if __name__ == '__main__':
+    main()
