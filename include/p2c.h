@@ -1,0 +1,149 @@
+/*
+ * p2c.h -- C ABI of libp2c_hip.so: the MI355X (gfx950) pose-sequence hot path of pedestrians-video-2-carla.
+ *
+ * The reference (wielgosz-info/pedestrians-video-2-carla) is pure Python: there is no FFI to match. These entry
+ * points are what a ctypes / cffi binding on the reference side would bind to replace the chains of small PyTorch ops
+ * listed below (INTEGRATION.md shows the binding). Paths are relative to src/pedestrians_video_2_carla/ of the reference.
+ *
+ *   p2c_pose_head_fwd / _bwd   replaces, fused in one launch each:
+ *        modules/movements/movements.py:105-118          rotation_6d_to_matrix on the model output
+ *        modules/layers/projection.py:52-71              per-clip reference skeleton (O(B) python) -> skel_type index
+ *        modules/layers/projection.py:170-195 + walker_control/p3d_pose.py:98-213    cumulative rotations + FK
+ *        modules/layers/projection.py:125-136 + transforms/pose/normalization/reference_skeletons_denormalizer.py:67-91
+ *        utils/world.py:16-63                            world transform from changes
+ *        walker_control/p3d_pose_projection.py:115-152   pinhole projection
+ *        transforms/pose/normalization/normalizer.py:20-41 (+ extractors)   dm.transform_callable on the projection
+ *        loss/loc_2d.py:69-89, loss/loc_3d.py:12-40, loss/loc_2d_3d.py:6-17
+ *   p2c_normalize_fwd / _bwd   transforms/pose/normalization/normalizer.py:20-41 stand-alone (any skeleton)
+ *   p2c_loss2d_fwd / _bwd      loss/base_pose_loss.py:36-66 + loss/loc_2d.py:69-89 (autoencoder flow)
+ *   p2c_remap_nodes            data/base/base_dataset.py:156-167 (_get_common_tensor, zero-filled joint scatter)
+ *
+ * Conventions: every pointer is a DEVICE pointer unless named host_*; tensors are dense row-major fp32; `stream` is a
+ * hipStream_t passed as void*; nothing is allocated, freed or synchronised inside; no exception crosses the ABI.
+ * Return value: 0 = launched, negative = argument error (P2C_E_*), positive = hipError_t of the failed launch.
+ */
+#ifndef P2C_H
+#define P2C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(P2C_BUILD)
+#define P2C_API __attribute__((visibility("default")))
+#else
+#define P2C_API
+#endif
+
+#define P2C_JOINTS 26            /* CARLA_SKELETON bones; pose-head tensors are (B, T, 26, k) */
+#define P2C_SKELETON_TYPES 4     /* (adult,female) (adult,male) (child,female) (child,male) */
+
+/* kind of the movements-model output handed to the pose head (modules/flow/output_types.py:4-20) */
+enum {
+  P2C_KIND_POSE_CHANGES_6D = 0,  /* y (B,T,26,6)   6-D rotation *changes*, orthonormalised in-kernel          */
+  P2C_KIND_POSE_CHANGES_MAT = 1, /* y (B,T,26,3,3) rotation-matrix changes (the reference's API tensor)        */
+  P2C_KIND_RELATIVE_ROT_6D = 2,  /* y (B,T,26,6)   relative rotations (no cumulative product)                  */
+  P2C_KIND_RELATIVE_ROT_MAT = 3, /* y (B,T,26,3,3)                                                             */
+  P2C_KIND_ABSOLUTE_LOC = 4      /* y (B,T,26,3)   absolute locations, hips-neck re-normalised to the skeleton */
+};
+
+/* data-module transform applied to the projection (data/base/base_transforms.py) */
+enum { P2C_TRANSFORM_NONE = 0, P2C_TRANSFORM_HIPS_NECK = 1, P2C_TRANSFORM_BBOX = 2, P2C_TRANSFORM_HIPS_NECK_BBOX = 3 };
+
+enum { P2C_E_NULL = -1, P2C_E_SHAPE = -2, P2C_E_ENUM = -3, P2C_E_INDEX = -4 };
+
+typedef struct p2c_pose_head_desc {
+  /* ---- shapes / modes ---- */
+  int32_t B, T;                 /* clips, frames per clip */
+  int32_t kind;                 /* P2C_KIND_* */
+  int32_t transform;            /* P2C_TRANSFORM_* */
+  int32_t t0, t1;               /* eval_slice [t0, t1) over frames: losses / transformed outputs only there */
+  int32_t mask_missing_joints;  /* loc_2d: ignore joints whose gt is exactly (0,0) */
+  int32_t hips_lane;            /* predicted joint never masked (tensors.py:33-38), -1 = none */
+  int32_t n_hips, n_neck;       /* 1 or 2 joints averaged for the shift / scale points */
+  int32_t hips_idx[2], neck_idx[2];
+  int32_t gt2d_joints, gt2d_channels;   /* gt2d is (B,T,gt2d_joints,gt2d_channels), channels >= 2 */
+  int32_t gt3d_joints;                  /* gt3d is (B,T,gt3d_joints,3) */
+  int32_t gmap2d[P2C_JOINTS];   /* per predicted joint: index of its gt joint, -1 = not a common joint */
+  int32_t gmap3d[P2C_JOINTS];
+  int32_t n_common2d, n_common3d;       /* number of gmap entries >= 0 (loss denominators) */
+  float cam_f, cam_cx, cam_cy, cam_dist, cam_elev;
+  float near_zero;              /* 1e-5 */
+  /* ---- inputs ---- */
+  const float *y;               /* model output, layout by kind */
+  const int32_t *skel_type;     /* (B) in [0,4) */
+  const float *ref_rel_loc;     /* (4,26,3)   reference skeleton tables (data/carla/reference.py) */
+  const float *ref_rel_rot;     /* (4,26,3,3) */
+  const float *ref_hn_shift;    /* (4,3) hips of the reference absolute pose  (absolute_loc kind) */
+  const float *ref_hn_scale;    /* (4)   |neck-hips| of the reference absolute pose */
+  const float *dloc;            /* (B,T,3)   world location changes or NULL (= ZeroTrajectory) */
+  const float *drot;            /* (B,T,3,3) world rotation changes or NULL */
+  const float *gt2d;            /* targets['projection_2d_transformed'] (or 'projection_2d'); NULL = no loc_2d */
+  const float *gt3d;            /* targets['absolute_pose_loc']; NULL = loc_3d unavailable */
+  /* ---- outputs ---- */
+  float *partials;              /* workspace, p2c_pose_head_workspace_floats(B) floats */
+  float *loss_sums;             /* (4): sum_sq_2d, n_unmasked_2d, sum_sq_3d, n_elems_3d */
+  float *losses;                /* (3): loc_2d, loc_3d, loc_2d_3d   (NaN when the gt is absent) */
+  float *final_rel_rot;         /* (B,26,3,3) last relative rotation, consumed by the backward; pose_changes kinds */
+  /* optional materialised tensors (eval / predict); NULL = not written */
+  float *out_pose_changes;      /* (B,T,26,3,3) */
+  float *out_projection_2d;     /* (B,T,26,3) */
+  float *out_projection_2d_transformed; /* (B,T,26,3) frames outside [t0,t1) untouched */
+  float *out_shift;             /* (B,T,2) */
+  float *out_scale;             /* (B,T) */
+  float *out_relative_pose_loc; /* (B,T,26,3) */
+  float *out_relative_pose_rot; /* (B,T,26,3,3) */
+  float *out_absolute_pose_loc; /* (B,T,26,3) */
+  float *out_absolute_pose_rot; /* (B,T,26,3,3) */
+  float *out_world_loc;         /* (B,T,3) */
+  float *out_world_rot;         /* (B,T,3,3) */
+} p2c_pose_head_desc;
+
+/* library / build identification: "p2c-hip <version> gfx950" */
+P2C_API const char *p2c_version(void);
+
+/* number of floats `partials` must hold for a batch of B clips */
+P2C_API int64_t p2c_pose_head_workspace_floats(int32_t B);
+
+/* Forward: fills loss_sums, losses, final_rel_rot and any non-NULL out_* tensor. Two launches on `stream`
+ * (pose head + deterministic reduction of the per-wave partial sums). */
+P2C_API int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream);
+
+/* Backward (recompute): grad_y has the layout of desc->y. `grad_losses` (3 floats, device) = upstream gradients
+ * of (loc_2d, loc_3d, loc_2d_3d); desc->loss_sums and desc->final_rel_rot must hold the values written by the forward.
+ * Optional upstream gradients of materialised outputs (NULL = none): grad_absolute_pose_loc (B,T,26,3),
+ * grad_projection_2d_transformed (B,T,26,3) [channel 2 ignored]. One launch. */
+P2C_API int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *grad_losses,
+                      const float *grad_absolute_pose_loc, const float *grad_projection_2d_transformed,
+                      float *grad_y, void *stream);
+
+/* Stand-alone normaliser (Normalizer.__call__, dim = 2 or 3) over N frames of J joints with C channels (C >= dim).
+ * out (N,J,C), shift (N,dim), scale (N); shift/scale may be NULL. */
+P2C_API int p2c_normalize_fwd(const float *x, float *out, float *shift, float *scale, int64_t N, int32_t J, int32_t C,
+                      int32_t dim, int32_t transform, int32_t n_hips, const int32_t *host_hips_idx, int32_t n_neck,
+                      const int32_t *host_neck_idx, float near_zero, void *stream);
+P2C_API int p2c_normalize_bwd(const float *x, const float *grad_out, float *grad_x, int64_t N, int32_t J, int32_t C,
+                      int32_t dim, int32_t transform, int32_t n_hips, const int32_t *host_hips_idx, int32_t n_neck,
+                      const int32_t *host_neck_idx, float near_zero, void *stream);
+
+/* Masked 2-D MSE (Loc2DPoseLoss): pred (N,Jp,Cp), gt (N,Jg,Cg); K common joints, host index lists; hips_col = position
+ * in the common list that is never masked or -1. loss_sums (2) = sum_sq, n_unmasked; loss (1). */
+P2C_API int64_t p2c_loss2d_workspace_floats(int64_t N);
+P2C_API int p2c_loss2d_fwd(const float *pred, const float *gt, int64_t N, int32_t Jp, int32_t Cp, int32_t Jg, int32_t Cg,
+                   int32_t K, const int32_t *host_pred_idx, const int32_t *host_gt_idx, int32_t hips_col,
+                   int32_t mask_missing_joints, float *partials, float *loss_sums, float *loss, void *stream);
+P2C_API int p2c_loss2d_bwd(const float *pred, const float *gt, int64_t N, int32_t Jp, int32_t Cp, int32_t Jg, int32_t Cg,
+                   int32_t K, const int32_t *host_pred_idx, const int32_t *host_gt_idx, int32_t hips_col,
+                   int32_t mask_missing_joints, const float *loss_sums, const float *grad_loss, float *grad_pred,
+                   void *stream);
+
+/* Zero-filled joint remap: dst[n, dst_idx[k], :] = src[n, src_idx[k], :], every other dst joint = 0. */
+P2C_API int p2c_remap_nodes(const float *src, float *dst, int64_t N, int32_t Jsrc, int32_t Jdst, int32_t C, int32_t K,
+                    const int32_t *host_src_idx, const int32_t *host_dst_idx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2C_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libp2c_hip.so (C ABI in include/p2c.h).
+
+There is no CPU fallback: if the shared library is missing or an op is given host tensors, the call raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libp2c_hip.so')
+P2C_JOINTS = 26
+
+KIND = {'pose_changes_6d': 0, 'pose_changes': 1, 'relative_rot_6d': 2, 'relative_rot': 3, 'absolute_loc': 4}
+TRANSFORM = {'none': 0, 'hips_neck': 1, 'bbox': 2, 'hips_neck_bbox': 3}
+
+_f32p = ctypes.c_void_p  # device pointers travel as plain addresses
+_i32 = ctypes.c_int32
+
+
+class PoseHeadDesc(ctypes.Structure):
+    """Mirror of ``p2c_pose_head_desc`` (include/p2c.h) -- keep field order in sync."""
+    _fields_ = [
+        ('B', _i32), ('T', _i32), ('kind', _i32), ('transform', _i32), ('t0', _i32), ('t1', _i32),
+        ('mask_missing_joints', _i32), ('hips_lane', _i32), ('n_hips', _i32), ('n_neck', _i32),
+        ('hips_idx', _i32 * 2), ('neck_idx', _i32 * 2),
+        ('gt2d_joints', _i32), ('gt2d_channels', _i32), ('gt3d_joints', _i32),
+        ('gmap2d', _i32 * P2C_JOINTS), ('gmap3d', _i32 * P2C_JOINTS), ('n_common2d', _i32), ('n_common3d', _i32),
+        ('cam_f', ctypes.c_float), ('cam_cx', ctypes.c_float), ('cam_cy', ctypes.c_float),
+        ('cam_dist', ctypes.c_float), ('cam_elev', ctypes.c_float), ('near_zero', ctypes.c_float),
+        ('y', _f32p), ('skel_type', _f32p), ('ref_rel_loc', _f32p), ('ref_rel_rot', _f32p),
+        ('ref_hn_shift', _f32p), ('ref_hn_scale', _f32p), ('dloc', _f32p), ('drot', _f32p),
+        ('gt2d', _f32p), ('gt3d', _f32p),
+        ('partials', _f32p), ('loss_sums', _f32p), ('losses', _f32p), ('final_rel_rot', _f32p),
+        ('out_pose_changes', _f32p), ('out_projection_2d', _f32p), ('out_projection_2d_transformed', _f32p),
+        ('out_shift', _f32p), ('out_scale', _f32p), ('out_relative_pose_loc', _f32p),
+        ('out_relative_pose_rot', _f32p), ('out_absolute_pose_loc', _f32p), ('out_absolute_pose_rot', _f32p),
+        ('out_world_loc', _f32p), ('out_world_rot', _f32p),
+    ]
+
+
+# every symbol include/p2c.h declares: (restype, argtypes)
+_vp, _i64, _ip = ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)
+SYMBOLS = {
+    'p2c_version': (ctypes.c_char_p, []),
+    'p2c_pose_head_workspace_floats': (_i64, [_i32]),
+    'p2c_pose_head_fwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp]),
+    'p2c_pose_head_bwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp, _vp, _vp, _vp, _vp]),
+    'p2c_normalize_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _i32, _ip,
+                                         ctypes.c_float, _vp]),
+    'p2c_normalize_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _i32, _ip,
+                                         ctypes.c_float, _vp]),
+    'p2c_loss2d_workspace_floats': (_i64, [_i64]),
+    'p2c_loss2d_fwd': (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _i32, _vp, _vp,
+                                      _vp, _vp]),
+    'p2c_loss2d_bwd': (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _i32, _vp, _vp,
+                                      _vp, _vp]),
+    'p2c_remap_nodes': (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _ip, _ip, _vp]),
+}
+
+_lib = None
+
+
+class P2CError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into csrc/libp2c_hip.so (hipcc cross-compiles without a GPU)."""
+    res = subprocess.run(['make', '-C', os.path.join(_HERE, 'csrc')], capture_output=True, text=True)
+    if verbose or res.returncode:
+        print(res.stdout, res.stderr)
+    if res.returncode:
+        raise P2CError('building libp2c_hip.so failed:\n' + res.stderr)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load the library once (torch first, so its bundled libamdhip64.so.7 is the HIP runtime both sides use)."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (side effect: HIP runtime already mapped)
+        if not os.path.exists(LIB_PATH):
+            raise P2CError(f'{LIB_PATH} is missing: run `python __graft_entry__.py` (build()) or `make -C '
+                           f'{os.path.join(_HERE, "csrc")}`. There is no CPU fallback for the HIP hot path.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the export is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        kind = {-1: 'null pointer', -2: 'bad shape', -3: 'bad enum', -4: 'bad index'}.get(rc, f'hipError_t {rc}')
+        raise P2CError(f'{what} failed: {kind} (rc={rc})')

@@ -1,0 +1,913 @@
+// p2c_pose_head.hip -- fused pose head (forward + recompute-backward) for gfx950 / CDNA4.
+//
+// Work decomposition ("joint-lane" mapping):
+//   * one 64-lane wavefront owns TWO clips; each clip gets a 32-lane group, lanes 0..25 = the 26 CARLA bones in
+//     DFS order, lanes 26..31 carry the identity transform (they are the "no ancestor" target of the tree walks).
+//   * every lane walks its joint through the T frames of the clip sequentially, so the cumulative rotation
+//     rel_rot[t] = change[t] @ rel_rot[t-1] (reference projection.py:190-193) lives in 9 registers and costs one 3x3
+//     product per frame; the global loads of y[b,t,:,:] are 26 lanes x 24 B = 624 contiguous bytes per clip-frame.
+//   * forward kinematics over the bone tree is a parallel tree-prefix "product" of affine maps (R, l) with
+//     (R1,l1)o(R2,l2) = (R1 R2, l1 R2 + l2): three pointer-doubling rounds (depth of the skeleton <= 8) of
+//     ds_bpermute exchanges -- no LDS storage, no barrier, any T.
+//   * hips / neck (and bbox) statistics of the normaliser and the loss sums are wave-level reductions.
+//   * backward recomputes the forward per frame while running the frames in REVERSE; rel_rot[t-1] = change[t]^T
+//     rel_rot[t] (changes are rotations), children->parent accumulation of FK gradients becomes two prefix sums over
+//     the DFS-ordered lanes (subtree(j) is the contiguous lane range [j, end(j)]).
+//
+// Reference semantics restated here are cited per function (paths relative to src/pedestrians_video_2_carla/).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#include "../../include/p2c.h"
+
+namespace p2c {
+
+constexpr int J = P2C_JOINTS;
+constexpr int GROUP = 32;
+constexpr int IDL = 26;  // identity lane inside a group
+
+// parent lane inside the group (data/carla/files/structure.yaml DFS order); root and idle lanes -> identity lane
+__constant__ int c_parent[GROUP] = {IDL, 0, 1, 2, 3, 4, 5, 6, 3, 8, 9, 9, 3, 12, 13, 14, 1, 16, 17, 18, 19, 1, 21, 22, 23, 24,
+                                    26, 27, 28, 29, 30, 31};
+// last lane of the subtree rooted at each joint
+__constant__ int c_subtree_end[GROUP] = {25, 25, 15, 15, 7, 7, 7, 7, 11, 11, 10, 11, 15, 15, 15, 15, 20, 20, 20, 20, 20,
+                                         25, 25, 25, 25, 25, 26, 27, 28, 29, 30, 31};
+
+struct V3 {
+  float x, y, z;
+};
+struct M3 {
+  float m[9];  // row-major
+};
+
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ M3 identity() { return M3{{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f}}; }
+__device__ __forceinline__ M3 zero3() { return M3{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}}; }
+// C = A @ B
+__device__ __forceinline__ M3 mul(const M3 &a, const M3 &b) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      c.m[i * 3 + k] = fmaf(a.m[i * 3 + 0], b.m[0 + k], fmaf(a.m[i * 3 + 1], b.m[3 + k], a.m[i * 3 + 2] * b.m[6 + k]));
+  return c;
+}
+// C = A^T @ B
+__device__ __forceinline__ M3 mulTN(const M3 &a, const M3 &b) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      c.m[i * 3 + k] = fmaf(a.m[0 + i], b.m[0 + k], fmaf(a.m[3 + i], b.m[3 + k], a.m[6 + i] * b.m[6 + k]));
+  return c;
+}
+// C = A @ B^T
+__device__ __forceinline__ M3 mulNT(const M3 &a, const M3 &b) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      c.m[i * 3 + k] = fmaf(a.m[i * 3 + 0], b.m[k * 3 + 0], fmaf(a.m[i * 3 + 1], b.m[k * 3 + 1], a.m[i * 3 + 2] * b.m[k * 3 + 2]));
+  return c;
+}
+// row vector times matrix
+__device__ __forceinline__ V3 vmul(V3 v, const M3 &a) {
+  return v3(fmaf(v.x, a.m[0], fmaf(v.y, a.m[3], v.z * a.m[6])), fmaf(v.x, a.m[1], fmaf(v.y, a.m[4], v.z * a.m[7])),
+            fmaf(v.x, a.m[2], fmaf(v.y, a.m[5], v.z * a.m[8])));
+}
+// row vector times matrix transposed
+__device__ __forceinline__ V3 vmulT(V3 v, const M3 &a) {
+  return v3(fmaf(v.x, a.m[0], fmaf(v.y, a.m[1], v.z * a.m[2])), fmaf(v.x, a.m[3], fmaf(v.y, a.m[4], v.z * a.m[5])),
+            fmaf(v.x, a.m[6], fmaf(v.y, a.m[7], v.z * a.m[8])));
+}
+__device__ __forceinline__ M3 add(const M3 &a, const M3 &b) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.m[i] = a.m[i] + b.m[i];
+  return c;
+}
+
+// ---- cross-lane helpers (64-wide wavefront, two 32-lane groups) ----------------------------------------------------
+__device__ __forceinline__ float shfl(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+__device__ __forceinline__ V3 shfl(V3 v, int s) { return v3(shfl(v.x, s), shfl(v.y, s), shfl(v.z, s)); }
+__device__ __forceinline__ M3 shfl(const M3 &a, int s) {
+  M3 c;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c.m[i] = shfl(a.m[i], s);
+  return c;
+}
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+__device__ __forceinline__ float group_min(float v) {
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+// inclusive prefix sum over the lanes of a group (lane order = DFS order of the joints)
+__device__ __forceinline__ float group_prefix(float v, int j) {
+#pragma unroll
+  for (int d = 1; d < GROUP; d <<= 1) {
+    float n = __shfl_up(v, d, GROUP);
+    if (j >= d) v += n;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+__device__ __forceinline__ float nan_to_zero(float v) { return (isfinite(v)) ? v : 0.f; }  // utils/tensors.py:43-53
+
+// ---- 6-D rotation -> matrix (pytorch3d 0.6.0 rotation_6d_to_matrix; movements/movements.py:105-118) -------------
+struct SixD {
+  V3 a1, a2, b1, b2;
+  float n1, n2, d;  // clamped norms, b1.a2
+  bool c1, c2;      // norm above the 1e-12 clamp (gradient flows through the norm)
+};
+__device__ __forceinline__ M3 rot6d_fwd(const float *y6, SixD &s) {
+  s.a1 = v3(y6[0], y6[1], y6[2]);
+  s.a2 = v3(y6[3], y6[4], y6[5]);
+  float n1 = sqrtf(dot(s.a1, s.a1));
+  s.c1 = n1 > 1e-12f;
+  s.n1 = fmaxf(n1, 1e-12f);
+  s.b1 = s.a1 * (1.f / s.n1);
+  s.d = dot(s.b1, s.a2);
+  V3 u2 = s.a2 - s.b1 * s.d;
+  float n2 = sqrtf(dot(u2, u2));
+  s.c2 = n2 > 1e-12f;
+  s.n2 = fmaxf(n2, 1e-12f);
+  s.b2 = u2 * (1.f / s.n2);
+  V3 b3 = cross(s.b1, s.b2);
+  return M3{{s.b1.x, s.b1.y, s.b1.z, s.b2.x, s.b2.y, s.b2.z, b3.x, b3.y, b3.z}};
+}
+// gradient wrt the 6 inputs given the gradient wrt the matrix rows
+__device__ __forceinline__ void rot6d_bwd(const SixD &s, const M3 &g, float *gy6) {
+  V3 g1 = v3(g.m[0], g.m[1], g.m[2]), g2 = v3(g.m[3], g.m[4], g.m[5]), g3 = v3(g.m[6], g.m[7], g.m[8]);
+  V3 gb1 = g1 + cross(s.b2, g3);
+  V3 gb2 = g2 + cross(g3, s.b1);
+  float r2 = 1.f / s.n2;
+  V3 gu2 = s.c2 ? (gb2 - s.b2 * dot(s.b2, gb2)) * r2 : gb2 * r2;
+  float k = dot(gu2, s.b1);
+  V3 ga2 = gu2 - s.b1 * k;
+  gb1 = gb1 - gu2 * s.d - s.a2 * k;
+  float r1 = 1.f / s.n1;
+  V3 ga1 = s.c1 ? (gb1 - s.b1 * dot(s.b1, gb1)) * r1 : gb1 * r1;
+  gy6[0] = ga1.x, gy6[1] = ga1.y, gy6[2] = ga1.z, gy6[3] = ga2.x, gy6[4] = ga2.y, gy6[5] = ga2.z;
+}
+
+// ---- per-lane constants ------------------------------------------------------------------------------------------------
+struct LaneCtx {
+  int lane, j, base, clip;
+  bool active;  // real joint of a real clip
+  int anc0, anc1, anc2, sub_end;
+  int gm2, gm3;
+  bool never_masked;
+};
+
+__device__ __forceinline__ LaneCtx make_lane(const p2c_pose_head_desc &d) {
+  LaneCtx L;
+  L.lane = threadIdx.x & 63;
+  L.j = L.lane & 31;
+  L.base = L.lane & 32;
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  L.clip = wave * 2 + (L.lane >> 5);
+  L.active = (L.j < J) && (L.clip < d.B);
+  int p = c_parent[L.j];
+  L.anc0 = p;
+  L.anc1 = c_parent[p];
+  L.anc2 = c_parent[c_parent[L.anc1]];
+  L.sub_end = c_subtree_end[L.j];
+  L.gm2 = (L.j < J) ? d.gmap2d[L.j] : -1;
+  L.gm3 = (L.j < J) ? d.gmap3d[L.j] : -1;
+  L.never_masked = (L.j == d.hips_lane);
+  return L;
+}
+
+// Forward kinematics by pointer doubling over the group (walker_control/p3d_pose.py:116-184):
+//   abs_rot[j] = rel_rot[j] @ abs_rot[parent], abs_loc[j] = rel_loc[j] @ abs_rot[parent] + abs_loc[parent].
+__device__ __forceinline__ void fk_doubling(const LaneCtx &L, M3 &R, V3 &l) {
+  {
+    M3 Ra = shfl(R, L.base + L.anc0);
+    V3 la = shfl(l, L.base + L.anc0);
+    l = vmul(l, Ra) + la;
+    R = mul(R, Ra);
+  }
+  {
+    M3 Ra = shfl(R, L.base + L.anc1);
+    V3 la = shfl(l, L.base + L.anc1);
+    l = vmul(l, Ra) + la;
+    R = mul(R, Ra);
+  }
+  {
+    // after two rounds a node has absorbed 4 path nodes; its next unabsorbed ancestor is 4 levels up
+    M3 Ra = shfl(R, L.base + L.anc2);
+    V3 la = shfl(l, L.base + L.anc2);
+    l = vmul(l, Ra) + la;
+    R = mul(R, Ra);
+  }
+}
+
+// ---- projection + normaliser + losses for one frame -----------------------------------------------------------------
+// Forward restates walker_control/p3d_pose_projection.py:115-152 (camera :37-69), normalizer.py:20-41 with the
+// extractors of transforms/pose/normalization/, loss/loc_2d.py:69-89 + base_pose_loss.py:36-66, loss/loc_3d.py:12-40.
+// With BWD it also returns d(total)/d(abs_loc) of this lane's joint.
+struct World {
+  M3 rot;
+  V3 loc;
+  bool on;
+};
+
+struct HeadAcc {
+  float sum2, cnt2, sum3;
+};
+
+template <bool BWD>
+__device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const LaneCtx &L, int t, V3 x, const World &W,
+                                         HeadAcc &acc, float coef2, float coef3, const float *g_abs_ext,
+                                         const float *g_projt_ext) {
+  const bool in_slice = (t >= d.t0) && (t < d.t1);
+  const size_t frame = (size_t)L.clip * d.T + t;
+
+  // ---- projection --------------------------------------------------------------------------------------------------
+  V3 w = v3(x.y, -x.x, x.z);  // x @ p3d_2_world
+  V3 p = W.on ? vmul(w, W.rot) + W.loc : w;
+  float Z = d.cam_dist - p.x;
+  float invZ = 1.f / Z;
+  float u = d.cam_cx - d.cam_f * p.y * invZ;
+  float v = d.cam_cy + d.cam_f * (p.z + d.cam_elev) * invZ;
+  if (!L.active) { u = 0.f; v = 0.f; invZ = 0.f; }
+
+  if (!BWD) {
+    if (L.active && d.out_projection_2d) {
+      float *o = d.out_projection_2d + (frame * J + L.j) * 3;
+      o[0] = u, o[1] = v, o[2] = invZ;
+    }
+    if (L.active && d.out_absolute_pose_loc) {
+      float *o = d.out_absolute_pose_loc + (frame * J + L.j) * 3;
+      o[0] = x.x, o[1] = x.y, o[2] = x.z;
+    }
+  }
+
+  // ---- normaliser ---------------------------------------------------------------------------------------------------
+  const int tr = d.transform;
+  float su = 0.f, sv = 0.f, scale = 1.f;         // shift, scale
+  float hu = 0.f, hv = 0.f, ku = 0.f, kv = 0.f;  // hips / neck points
+  float hn_scale = 1.f, bb_scale = 1.f;
+  bool use_bb_scale = false;
+  float minu = 0.f, maxu = 0.f, minv = 0.f, maxv = 0.f;
+  bool missing = false;
+  if (tr != P2C_TRANSFORM_NONE) {
+    if (tr != P2C_TRANSFORM_BBOX) {  // hips_neck_extractor.py:6-13 (mean over the point tuple)
+      hu = shfl(u, L.base + d.hips_idx[0]);
+      hv = shfl(v, L.base + d.hips_idx[0]);
+      if (d.n_hips == 2) {
+        hu = 0.5f * (hu + shfl(u, L.base + d.hips_idx[1]));
+        hv = 0.5f * (hv + shfl(v, L.base + d.hips_idx[1]));
+      }
+      ku = shfl(u, L.base + d.neck_idx[0]);
+      kv = shfl(v, L.base + d.neck_idx[0]);
+      if (d.n_neck == 2) {
+        ku = 0.5f * (ku + shfl(u, L.base + d.neck_idx[1]));
+        kv = 0.5f * (kv + shfl(v, L.base + d.neck_idx[1]));
+      }
+      float du = ku - hu, dv = kv - hv;
+      hn_scale = sqrtf(fmaf(du, du, dv * dv));  // extractor.py:27-28
+      su = hu, sv = hv, scale = hn_scale;
+    }
+    bool need_bb = (tr == P2C_TRANSFORM_BBOX);
+    if (tr == P2C_TRANSFORM_HIPS_NECK_BBOX) {  // hips_neck_bbox_fallback_extractor.py:25,33
+      bool mh = (hu < d.near_zero) && (hv < d.near_zero);
+      bool mk = (ku < d.near_zero) && (kv < d.near_zero);
+      use_bb_scale = mh || mk;
+      need_bb = use_bb_scale;
+    }
+    if (__any(need_bb)) {  // utils/tensors.py:12-26, bbox_extractor.py:6-18
+      missing = !L.active || ((u < d.near_zero) && (v < d.near_zero)) || (L.j >= J);
+      const float inf = __builtin_inff();
+      minu = group_min(missing ? inf : u);
+      minv = group_min(missing ? inf : v);
+      maxu = group_max(missing ? -inf : u);
+      maxv = group_max(missing ? -inf : v);
+      float cu = 0.5f * (minu + maxu), cv = 0.5f * (minv + maxv);
+      float top_v = fminf(minv, maxv);
+      float dx = cu - cu, dy = top_v - cv;  // literal: inf - inf = nan when every joint is missing
+      bb_scale = sqrtf(fmaf(dx, dx, dy * dy));
+      if (tr == P2C_TRANSFORM_BBOX) {
+        su = cu, sv = cv, scale = bb_scale;
+      } else if (use_bb_scale) {
+        scale = bb_scale * 0.5748f;  // :18,:34-38 ; the shift fallback (:26-31) is a no-op in the reference
+      }
+    }
+  }
+  float nu = u, nv = v, wch = invZ;
+  bool fin_u = true, fin_v = true, keep = true;
+  float inv_scale = 1.f;
+  if (tr != P2C_TRANSFORM_NONE) {
+    inv_scale = 1.f / scale;
+    nu = (u - su) / scale;  // normalizer.py:24-25
+    nv = (v - sv) / scale;
+    fin_u = isfinite(nu), fin_v = isfinite(nv);
+    nu = fin_u ? nu : 0.f;  // :30
+    nv = fin_v ? nv : 0.f;
+    wch = nan_to_zero(invZ);
+    keep = wch >= d.near_zero;  // :35-37 third channel (1/depth) acts as the confidence
+    if (!keep) { nu = 0.f; nv = 0.f; }
+  }
+  if (!BWD && tr != P2C_TRANSFORM_NONE && in_slice && L.clip < d.B) {
+    if (L.active && d.out_projection_2d_transformed) {
+      float *o = d.out_projection_2d_transformed + (frame * J + L.j) * 3;
+      o[0] = nu, o[1] = nv, o[2] = wch;
+    }
+    if (L.j == 0) {
+      if (d.out_shift) d.out_shift[frame * 2 + 0] = su, d.out_shift[frame * 2 + 1] = sv;
+      if (d.out_scale) d.out_scale[frame] = scale;
+    }
+  }
+
+  // ---- losses -------------------------------------------------------------------------------------------------------
+  V3 gx = v3(0.f, 0.f, 0.f);
+  float dnu = 0.f, dnv = 0.f;  // d total / d normalised (u, v)
+  if (in_slice) {
+    if (d.gt2d && L.active && L.gm2 >= 0) {
+      const float *g = d.gt2d + (frame * d.gt2d_joints + L.gm2) * d.gt2d_channels;
+      float g0 = g[0], g1 = g[1];
+      bool m = !d.mask_missing_joints || L.never_masked || ((g0 != 0.f) && (g1 != 0.f));  // tensors.py:29-40
+      if (m) {
+        float e0 = nu - g0, e1 = nv - g1;
+        if (!BWD) {
+          acc.sum2 += fmaf(e0, e0, e1 * e1);
+          acc.cnt2 += 1.f;
+        } else {
+          dnu = coef2 * e0;
+          dnv = coef2 * e1;
+        }
+      }
+    }
+    if (d.gt3d && L.active && L.gm3 >= 0) {
+      const float *g = d.gt3d + (frame * d.gt3d_joints + L.gm3) * 3;
+      float e0 = x.x - g[0], e1 = x.y - g[1], e2 = x.z - g[2];
+      if (!BWD)
+        acc.sum3 += fmaf(e0, e0, fmaf(e1, e1, e2 * e2));
+      else
+        gx = v3(coef3 * e0, coef3 * e1, coef3 * e2);
+    }
+  }
+  if (!BWD) return gx;
+
+  // ================================================ backward ==========================================================
+  if (L.active && g_abs_ext) {
+    const float *g = g_abs_ext + (frame * J + L.j) * 3;
+    gx = gx + v3(g[0], g[1], g[2]);
+  }
+  if (L.active && g_projt_ext && in_slice) {
+    const float *g = g_projt_ext + (frame * J + L.j) * 3;
+    dnu += g[0], dnv += g[1];
+  }
+  float gu, gv;
+  if (tr == P2C_TRANSFORM_NONE) {
+    gu = dnu, gv = dnv;
+  } else {
+    // where(keep) and nan_to_num pass the gradient only through kept, finite entries
+    if (!keep || !fin_u) dnu = 0.f;
+    if (!keep || !fin_v) dnv = 0.f;
+    bool ok = isfinite(inv_scale) && (scale != 0.f);
+    gu = ok ? dnu * inv_scale : 0.f;
+    gv = ok ? dnv * inv_scale : 0.f;
+    float Au = group_sum(gu), Av = group_sum(gv);                 // -d/d shift
+    float Cs = group_sum(fmaf(gu, nu, gv * nv));                  // -d/d scale  (n = (p - shift)/scale)
+    float g_scale = -Cs;
+    float gsu = -Au, gsv = -Av;                                   // gradient wrt the shift point
+    float g_bbs = 0.f;
+    if (tr == P2C_TRANSFORM_BBOX) {
+      g_bbs = g_scale;
+    } else if (use_bb_scale) {
+      g_bbs = g_scale * 0.5748f;
+    } else {
+      // scale = |neck - hips| (torch.linalg.norm backward; zero norm -> zero gradient)
+      float r = (hn_scale > 0.f) ? g_scale / hn_scale : 0.f;
+      float gku = r * (ku - hu), gkv = r * (kv - hv);
+      gsu -= gku, gsv -= gkv;
+      float kn = 1.f / (float)d.n_neck;
+      if (L.j == d.neck_idx[0] || (d.n_neck == 2 && L.j == d.neck_idx[1])) gu += gku * kn, gv += gkv * kn;
+    }
+    if (tr != P2C_TRANSFORM_BBOX) {
+      float hn = 1.f / (float)d.n_hips;
+      if (L.j == d.hips_idx[0] || (d.n_hips == 2 && L.j == d.hips_idx[1])) gu += gsu * hn, gv += gsv * hn;
+    }
+    if (tr == P2C_TRANSFORM_BBOX || __any(use_bb_scale)) {
+      // min / max pick the first joint holding the extreme value (torch.min/max(dim) backward)
+      float g_minu = 0.f, g_maxu = 0.f, g_minv = 0.f, g_maxv = 0.f;
+      if (tr == P2C_TRANSFORM_BBOX) {  // shift = centre of the box
+        g_minu += 0.5f * gsu, g_maxu += 0.5f * gsu, g_minv += 0.5f * gsv, g_maxv += 0.5f * gsv;
+      }
+      if (tr == P2C_TRANSFORM_BBOX || use_bb_scale) {
+        float dy = fminf(minv, maxv) - 0.5f * (minv + maxv);
+        float g_dy = (bb_scale > 0.f) ? g_bbs * dy / bb_scale : 0.f;
+        g_minv += 0.5f * g_dy;   // top_v = minv (+g_dy), centre (-g_dy/2 each)
+        g_maxv -= 0.5f * g_dy;
+      }
+      unsigned long long grp = 0xffffffffull << L.base;
+      unsigned long long b;
+      b = __ballot(!missing && u == minu) & grp;
+      if (b && L.lane == __ffsll((long long)b) - 1) gu += g_minu;
+      b = __ballot(!missing && u == maxu) & grp;
+      if (b && L.lane == __ffsll((long long)b) - 1) gu += g_maxu;
+      b = __ballot(!missing && v == minv) & grp;
+      if (b && L.lane == __ffsll((long long)b) - 1) gv += g_minv;
+      b = __ballot(!missing && v == maxv) & grp;
+      if (b && L.lane == __ffsll((long long)b) - 1) gv += g_maxv;
+    }
+  }
+  // projection backward
+  float fz = d.cam_f * invZ;
+  float gb = -fz * gu;
+  float gc = fz * gv;
+  float gZ = (d.cam_f * p.y * gu - d.cam_f * (p.z + d.cam_elev) * gv) * invZ * invZ;
+  V3 gp = v3(-gZ, gb, gc);
+  V3 gw = W.on ? vmulT(gp, W.rot) : gp;
+  if (L.active) gx = gx + v3(-gw.y, gw.x, gw.z);
+  return gx;
+}
+
+// world transform scan step (utils/world.py:16-63): rot[t] = rot[t-1] @ drot[t], loc[t] = loc[t-1] + dloc[t]
+__device__ __forceinline__ void world_step(const p2c_pose_head_desc &d, const LaneCtx &L, int t, World &W) {
+  if (!W.on || L.clip >= d.B) return;
+  size_t frame = (size_t)L.clip * d.T + t;
+  if (d.drot) {
+    M3 dr;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dr.m[i] = d.drot[frame * 9 + i];
+    W.rot = mul(W.rot, dr);
+  }
+  if (d.dloc) W.loc = W.loc + v3(d.dloc[frame * 3 + 0], d.dloc[frame * 3 + 1], d.dloc[frame * 3 + 2]);
+}
+__device__ __forceinline__ void world_store(const p2c_pose_head_desc &d, const LaneCtx &L, int t, const World &W) {
+  if (L.j != 0 || L.clip >= d.B) return;
+  size_t frame = (size_t)L.clip * d.T + t;
+  if (d.out_world_loc) {
+    d.out_world_loc[frame * 3 + 0] = W.loc.x, d.out_world_loc[frame * 3 + 1] = W.loc.y, d.out_world_loc[frame * 3 + 2] = W.loc.z;
+  }
+  if (d.out_world_rot) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d.out_world_rot[frame * 9 + i] = W.rot.m[i];
+  }
+}
+
+// loss scaling: loc_2d = S2 / (2 N2) -> d/dn = (n - g) / N2 ;  loc_3d = S3 / N3 -> d/dx = 2 (x - g) / N3.
+// grad_losses = upstream gradients of (loc_2d, loc_3d, loc_2d_3d); loc_2d_3d = loc_2d + loc_3d (loss/loc_2d_3d.py:15).
+__device__ __forceinline__ void loss_coefs(const p2c_pose_head_desc &d, const float *grad_losses, float &coef2,
+                                           float &coef3) {
+  if (!grad_losses) return;
+  float n2 = d.loss_sums[1], n3 = d.loss_sums[3];
+  float g2 = grad_losses[0] + grad_losses[2], g3 = grad_losses[1] + grad_losses[2];
+  coef2 = (d.gt2d && n2 > 0.f) ? g2 / n2 : 0.f;
+  coef3 = (d.gt3d && n3 > 0.f) ? 2.f * g3 / n3 : 0.f;
+}
+
+template <int KIND>
+struct KindTraits {
+  static constexpr bool SIXD = (KIND == P2C_KIND_POSE_CHANGES_6D || KIND == P2C_KIND_RELATIVE_ROT_6D);
+  static constexpr bool SCAN = (KIND == P2C_KIND_POSE_CHANGES_6D || KIND == P2C_KIND_POSE_CHANGES_MAT);
+  static constexpr int NY = SIXD ? 6 : 9;
+};
+
+template <int NY>
+__device__ __forceinline__ void load_y(const float *y, size_t idx, float *dst) {
+  const float *p = y + idx * NY;
+  if (NY == 6) {
+    const float2 *q = reinterpret_cast<const float2 *>(p);
+    float2 a = q[0], b = q[1], c = q[2];
+    dst[0] = a.x, dst[1] = a.y, dst[2] = b.x, dst[3] = b.y, dst[4] = c.x, dst[5] = c.y;
+  } else {
+#pragma unroll
+    for (int i = 0; i < NY; ++i) dst[i] = p[i];
+  }
+}
+__device__ __forceinline__ void store_m3(float *base, size_t idx, const M3 &a) {
+  float *p = base + idx * 9;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) p[i] = a.m[i];
+}
+
+// =====================================================================================================================
+// forward, rotation kinds (pose_changes / relative_rot; projection.py:144-195)
+// =====================================================================================================================
+template <int KIND>
+__global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_desc d) {
+  using K = KindTraits<KIND>;
+  const LaneCtx L = make_lane(d);
+  const int T = d.T;
+
+  V3 l = v3(0.f, 0.f, 0.f);  // reference relative location of this joint
+  M3 R = identity();         // running relative rotation
+  if (L.active) {
+    int st = d.skel_type[L.clip];
+    const float *pl = d.ref_rel_loc + ((size_t)st * J + L.j) * 3;
+    l = v3(pl[0], pl[1], pl[2]);
+    if (K::SCAN) {
+      const float *pr = d.ref_rel_rot + ((size_t)st * J + L.j) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) R.m[i] = pr[i];
+    }
+  }
+  World W;
+  W.on = (d.dloc != nullptr) || (d.drot != nullptr);
+  W.rot = identity();
+  W.loc = v3(0.f, 0.f, 0.f);
+  HeadAcc acc{0.f, 0.f, 0.f};
+
+  for (int t = 0; t < T; ++t) {
+    const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
+    M3 c = identity();
+    if (L.active) {
+      float yv[K::NY];
+      load_y<K::NY>(d.y, jf, yv);
+      if (K::SIXD) {
+        SixD s;
+        c = rot6d_fwd(yv, s);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c.m[i] = yv[i];
+      }
+    }
+    R = K::SCAN ? mul(c, R) : c;  // p3d_pose.py:98-114
+    if (L.active) {
+      if (d.out_pose_changes && K::SCAN) store_m3(d.out_pose_changes, jf, c);
+      if (d.out_relative_pose_rot) store_m3(d.out_relative_pose_rot, jf, R);
+      if (d.out_relative_pose_loc) {
+        float *o = d.out_relative_pose_loc + jf * 3;
+        o[0] = l.x, o[1] = l.y, o[2] = l.z;
+      }
+    }
+    M3 A = R;
+    V3 x = l;
+    fk_doubling(L, A, x);
+    if (L.active && d.out_absolute_pose_rot) store_m3(d.out_absolute_pose_rot, jf, A);
+    world_step(d, L, t, W);
+    if (W.on) world_store(d, L, t, W);
+    frame_head<false>(d, L, t, x, W, acc, 0.f, 0.f, nullptr, nullptr);
+  }
+  if (L.active && K::SCAN && d.final_rel_rot) store_m3(d.final_rel_rot, (size_t)L.clip * J + L.j, R);
+
+  float s2 = wave_sum(acc.sum2), c2 = wave_sum(acc.cnt2), s3 = wave_sum(acc.sum3);
+  if (L.lane == 0) {
+    size_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    float *p = d.partials + wave * 4;
+    p[0] = s2, p[1] = c2, p[2] = s3, p[3] = 0.f;
+  }
+}
+
+// =====================================================================================================================
+// backward, rotation kinds: frames in reverse, forward recomputed per frame
+// =====================================================================================================================
+template <int KIND>
+__global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_desc d, const float *grad_losses,
+                                                         const float *g_abs_ext, const float *g_projt_ext,
+                                                         float *grad_y) {
+  using K = KindTraits<KIND>;
+  const LaneCtx L = make_lane(d);
+  const int T = d.T;
+
+  V3 l = v3(0.f, 0.f, 0.f);
+  M3 Rref = identity(), R = identity();
+  if (L.active) {
+    int st = d.skel_type[L.clip];
+    const float *pl = d.ref_rel_loc + ((size_t)st * J + L.j) * 3;
+    l = v3(pl[0], pl[1], pl[2]);
+    if (K::SCAN) {
+      const float *pr = d.ref_rel_rot + ((size_t)st * J + L.j) * 9;
+      const float *pf = d.final_rel_rot + ((size_t)L.clip * J + L.j) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rref.m[i] = pr[i], R.m[i] = pf[i];
+    }
+  }
+  float coef2 = 0.f, coef3 = 0.f;
+  loss_coefs(d, grad_losses, coef2, coef3);
+
+  World W;
+  W.on = (d.dloc != nullptr) || (d.drot != nullptr);
+  W.rot = identity();
+  W.loc = v3(0.f, 0.f, 0.f);
+  if (W.on)
+    for (int t = 0; t < T; ++t) world_step(d, L, t, W);  // world state at the last frame
+
+  HeadAcc acc{0.f, 0.f, 0.f};
+  M3 carry = zero3();  // change[t+1]^T @ dL/d rel_rot[t+1]
+
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
+    M3 c = identity();
+    SixD s;
+    if (L.active) {
+      float yv[K::NY];
+      load_y<K::NY>(d.y, jf, yv);
+      if (K::SIXD) {
+        c = rot6d_fwd(yv, s);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) c.m[i] = yv[i];
+      }
+    }
+    if (!K::SCAN) R = c;
+    // ---- forward of this frame ----
+    M3 A = R;
+    V3 x = l;
+    fk_doubling(L, A, x);
+    V3 F = frame_head<true>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext);
+    // ---- FK backward: subtree sums via prefix sums over the DFS-ordered lanes ----
+    // SubF[j] = sum of F over subtree(j);  Z[j] = sum over strict descendants m of r_m^T (x) SubF[m],
+    // r_m = x_m - x_parent(m);  dL/dA_j = A_j Z_j ;  dL/d rel_rot_j = dL/dA_j @ A_parent^T
+    V3 P = v3(group_prefix(F.x, L.j), group_prefix(F.y, L.j), group_prefix(F.z, L.j));
+    V3 Pe = shfl(P, L.base + L.sub_end);
+    V3 SubF = Pe - (P - F);
+    V3 xp = shfl(x, L.base + L.anc0);
+    M3 Ap = shfl(A, L.base + L.anc0);
+    V3 r = x - xp;
+    M3 Y = M3{{r.x * SubF.x, r.x * SubF.y, r.x * SubF.z, r.y * SubF.x, r.y * SubF.y, r.y * SubF.z, r.z * SubF.x,
+               r.z * SubF.y, r.z * SubF.z}};
+    M3 Zm;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      float py = group_prefix(Y.m[i], L.j);
+      Zm.m[i] = shfl(py, L.base + L.sub_end) - py;
+    }
+    M3 GR = mulNT(mul(A, Zm), Ap);
+    // ---- reverse scan over time ----
+    M3 gc;
+    if (K::SCAN) {
+      GR = add(GR, carry);
+      M3 Rprev = (t > 0) ? mulTN(c, R) : Rref;  // change is a rotation: rel_rot[t-1] = change^T rel_rot[t]
+      gc = mulNT(GR, Rprev);
+      carry = mulTN(c, GR);
+      R = Rprev;
+    } else {
+      gc = GR;
+    }
+    if (L.active) {
+      float *g = grad_y + jf * K::NY;
+      if (K::SIXD) {
+        float gy6[6];
+        rot6d_bwd(s, gc, gy6);
+        float2 *q = reinterpret_cast<float2 *>(g);
+        q[0] = make_float2(gy6[0], gy6[1]), q[1] = make_float2(gy6[2], gy6[3]), q[2] = make_float2(gy6[4], gy6[5]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) g[i] = gc.m[i];
+      }
+    }
+    // ---- world state of the previous frame (inverse step; drot is a rotation) ----
+    if (W.on && t > 0 && L.clip < d.B) {
+      size_t frame = (size_t)L.clip * T + t;
+      if (d.drot) {
+        M3 dr;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dr.m[i] = d.drot[frame * 9 + i];
+        W.rot = mulNT(W.rot, dr);
+      }
+      if (d.dloc) W.loc = W.loc - v3(d.dloc[frame * 3 + 0], d.dloc[frame * 3 + 1], d.dloc[frame * 3 + 2]);
+    }
+  }
+}
+
+// =====================================================================================================================
+// absolute_loc kind (projection.py:125-136 + reference_skeletons_denormalizer.py:67-91)
+//   x^ = nan_to_zero((y - y[hips]) / |y[neck] - y[hips]|) ;  abs_loc = x^ * s_ref + h_ref
+// =====================================================================================================================
+template <bool BWD>
+__global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc d, const float *grad_losses,
+                                                        const float *g_abs_ext, const float *g_projt_ext,
+                                                        float *grad_y) {
+  const LaneCtx L = make_lane(d);
+  const int T = d.T;
+  constexpr int HIPS = 1, NECK = 8;  // HipsNeckExtractor(CARLA_SKELETON), reference_skeletons_denormalizer.py:37
+  V3 href = v3(0.f, 0.f, 0.f);
+  float sref = 1.f;
+  if (L.clip < d.B) {
+    int st = d.skel_type[L.clip];
+    href = v3(d.ref_hn_shift[st * 3 + 0], d.ref_hn_shift[st * 3 + 1], d.ref_hn_shift[st * 3 + 2]);
+    sref = d.ref_hn_scale[st];
+  }
+  float coef2 = 0.f, coef3 = 0.f;
+  if (BWD) loss_coefs(d, grad_losses, coef2, coef3);
+  World W;
+  W.on = (d.dloc != nullptr) || (d.drot != nullptr);
+  W.rot = identity();
+  W.loc = v3(0.f, 0.f, 0.f);
+  HeadAcc acc{0.f, 0.f, 0.f};
+
+  for (int t = 0; t < T; ++t) {
+    const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
+    V3 yin = v3(0.f, 0.f, 0.f);
+    if (L.active) {
+      const float *p = d.y + jf * 3;
+      yin = v3(p[0], p[1], p[2]);
+    }
+    V3 h = shfl(yin, L.base + HIPS), k = shfl(yin, L.base + NECK);
+    V3 dk = k - h;
+    float sc = sqrtf(dot(dk, dk));
+    V3 q = yin - h;
+    V3 xn = v3(q.x / sc, q.y / sc, q.z / sc);
+    bool f0 = isfinite(xn.x), f1 = isfinite(xn.y), f2 = isfinite(xn.z);
+    xn = v3(f0 ? xn.x : 0.f, f1 ? xn.y : 0.f, f2 ? xn.z : 0.f);
+    V3 x = xn * sref + href;
+    world_step(d, L, t, W);
+    if (!BWD && W.on) world_store(d, L, t, W);
+    V3 gx = frame_head<BWD>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext);
+    if (BWD) {
+      float inv = 1.f / sc;
+      bool ok = isfinite(inv) && sc != 0.f;
+      V3 gn = v3(f0 && ok ? gx.x * sref * inv : 0.f, f1 && ok ? gx.y * sref * inv : 0.f,
+                 f2 && ok ? gx.z * sref * inv : 0.f);  // d/dq
+      V3 S = v3(group_sum(gn.x), group_sum(gn.y), group_sum(gn.z));
+      float Cs = group_sum(gn.x * xn.x + gn.y * xn.y + gn.z * xn.z);
+      float rr = (sc > 0.f) ? -Cs / sc : 0.f;   // d/d sc  times 1/sc
+      V3 gk = dk * rr;
+      V3 gh = v3(-S.x, -S.y, -S.z) - gk;
+      V3 gy = gn;
+      if (L.j == HIPS) gy = gy + gh;
+      if (L.j == NECK) gy = gy + gk;
+      if (L.active) {
+        float *g = grad_y + jf * 3;
+        g[0] = gy.x, g[1] = gy.y, g[2] = gy.z;
+      }
+    }
+  }
+  if (!BWD) {
+    float s2 = wave_sum(acc.sum2), c2 = wave_sum(acc.cnt2), s3 = wave_sum(acc.sum3);
+    if (L.lane == 0) {
+      size_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+      float *p = d.partials + wave * 4;
+      p[0] = s2, p[1] = c2, p[2] = s3, p[3] = 0.f;
+    }
+  }
+}
+
+// =====================================================================================================================
+// deterministic second stage of the loss reduction (fixed order, fp64 accumulators)
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void loss_finalize(const float *partials, int n_waves, float n3_elems, int has2d,
+                                                     int has3d, float *loss_sums, float *losses) {
+  __shared__ double sh[3][256];
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < n_waves; i += 256) {
+    a += (double)partials[i * 4 + 0];
+    b += (double)partials[i * 4 + 1];
+    c += (double)partials[i * 4 + 2];
+  }
+  sh[0][threadIdx.x] = a, sh[1][threadIdx.x] = b, sh[2][threadIdx.x] = c;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+      sh[2][threadIdx.x] += sh[2][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double s2 = sh[0][0], n2 = sh[1][0], s3 = sh[2][0];
+    loss_sums[0] = (float)s2, loss_sums[1] = (float)n2, loss_sums[2] = (float)s3, loss_sums[3] = n3_elems;
+    const float nan = __builtin_nanf("");
+    float l2 = has2d ? (float)(s2 / (2.0 * n2)) : nan;  // MSELoss(mean) over the unmasked (x, y) pairs
+    float l3 = has3d ? (float)(s3 / (double)n3_elems) : nan;
+    losses[0] = l2, losses[1] = l3, losses[2] = l2 + l3;
+  }
+}
+
+}  // namespace p2c
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+using namespace p2c;
+
+static constexpr int kBlock = 64;  // one wavefront (two clips) per workgroup: no barriers, >= B/2 workgroups
+
+static int validate(const p2c_pose_head_desc *d) {
+  if (!d || !d->y || !d->skel_type || !d->partials || !d->loss_sums || !d->losses) return P2C_E_NULL;
+  if (d->B <= 0 || d->T <= 0 || d->t0 < 0 || d->t1 > d->T || d->t0 > d->t1) return P2C_E_SHAPE;
+  if (d->kind < 0 || d->kind > P2C_KIND_ABSOLUTE_LOC) return P2C_E_ENUM;
+  if (d->transform < 0 || d->transform > P2C_TRANSFORM_HIPS_NECK_BBOX) return P2C_E_ENUM;
+  if (d->kind == P2C_KIND_ABSOLUTE_LOC) {
+    if (!d->ref_hn_shift || !d->ref_hn_scale) return P2C_E_NULL;
+  } else {
+    if (!d->ref_rel_loc || !d->ref_rel_rot) return P2C_E_NULL;
+  }
+  if (d->n_hips < 1 || d->n_hips > 2 || d->n_neck < 1 || d->n_neck > 2) return P2C_E_INDEX;
+  for (int i = 0; i < d->n_hips; ++i)
+    if (d->hips_idx[i] < 0 || d->hips_idx[i] >= P2C_JOINTS) return P2C_E_INDEX;
+  for (int i = 0; i < d->n_neck; ++i)
+    if (d->neck_idx[i] < 0 || d->neck_idx[i] >= P2C_JOINTS) return P2C_E_INDEX;
+  if (d->hips_lane < -1 || d->hips_lane >= P2C_JOINTS) return P2C_E_INDEX;
+  int n2 = 0, n3 = 0;
+  for (int j = 0; j < P2C_JOINTS; ++j) {
+    if (d->gt2d && (d->gmap2d[j] < -1 || d->gmap2d[j] >= d->gt2d_joints)) return P2C_E_INDEX;
+    if (d->gt3d && (d->gmap3d[j] < -1 || d->gmap3d[j] >= d->gt3d_joints)) return P2C_E_INDEX;
+    n2 += d->gmap2d[j] >= 0;
+    n3 += d->gmap3d[j] >= 0;
+  }
+  if (d->gt2d && (d->gt2d_channels < 2 || n2 != d->n_common2d)) return P2C_E_SHAPE;
+  if (d->gt3d && n3 != d->n_common3d) return P2C_E_SHAPE;
+  return 0;
+}
+
+static inline unsigned grid_for(int B) {
+  int waves = (B + 1) / 2;
+  int waves_per_block = kBlock / 64;
+  return (unsigned)((waves + waves_per_block - 1) / waves_per_block);
+}
+
+extern "C" const char *p2c_version(void) { return "p2c-hip 0.1.0 gfx950"; }
+
+extern "C" int64_t p2c_pose_head_workspace_floats(int32_t B) {
+  if (B <= 0) return 0;
+  return (int64_t)grid_for(B) * (kBlock / 64) * 4;
+}
+
+extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  const p2c_pose_head_desc d = *desc;
+  hipStream_t stream = (hipStream_t)stream_;
+  dim3 grid(grid_for(d.B)), block(kBlock);
+  switch (d.kind) {
+    case P2C_KIND_POSE_CHANGES_6D:
+      if (!d.final_rel_rot) return P2C_E_NULL;
+      hipLaunchKernelGGL(pose_head_rot_fwd<P2C_KIND_POSE_CHANGES_6D>, grid, block, 0, stream, d);
+      break;
+    case P2C_KIND_POSE_CHANGES_MAT:
+      if (!d.final_rel_rot) return P2C_E_NULL;
+      hipLaunchKernelGGL(pose_head_rot_fwd<P2C_KIND_POSE_CHANGES_MAT>, grid, block, 0, stream, d);
+      break;
+    case P2C_KIND_RELATIVE_ROT_6D:
+      hipLaunchKernelGGL(pose_head_rot_fwd<P2C_KIND_RELATIVE_ROT_6D>, grid, block, 0, stream, d);
+      break;
+    case P2C_KIND_RELATIVE_ROT_MAT:
+      hipLaunchKernelGGL(pose_head_rot_fwd<P2C_KIND_RELATIVE_ROT_MAT>, grid, block, 0, stream, d);
+      break;
+    default:
+      hipLaunchKernelGGL(pose_head_absloc<false>, grid, block, 0, stream, d, (const float *)nullptr,
+                         (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  int n_waves = (int)(grid.x * (kBlock / 64));
+  float n3 = (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
+  hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, n_waves, n3,
+                     d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *grad_losses,
+                                 const float *grad_absolute_pose_loc, const float *grad_projection_2d_transformed,
+                                 float *grad_y, void *stream_) {
+  int rc = validate(desc);
+  if (rc) return rc;
+  if (!grad_y) return P2C_E_NULL;
+  const p2c_pose_head_desc d = *desc;
+  hipStream_t stream = (hipStream_t)stream_;
+  dim3 grid(grid_for(d.B)), block(kBlock);
+  const float *ga = grad_absolute_pose_loc, *gp = grad_projection_2d_transformed;
+  switch (d.kind) {
+    case P2C_KIND_POSE_CHANGES_6D:
+      if (!d.final_rel_rot) return P2C_E_NULL;
+      hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_POSE_CHANGES_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+      break;
+    case P2C_KIND_POSE_CHANGES_MAT:
+      if (!d.final_rel_rot) return P2C_E_NULL;
+      hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_POSE_CHANGES_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+      break;
+    case P2C_KIND_RELATIVE_ROT_6D:
+      hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_RELATIVE_ROT_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+      break;
+    case P2C_KIND_RELATIVE_ROT_MAT:
+      hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_RELATIVE_ROT_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+      break;
+    default:
+      hipLaunchKernelGGL(pose_head_absloc<true>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+  }
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

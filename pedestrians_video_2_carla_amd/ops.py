@@ -1,0 +1,231 @@
+"""Device ops of the hot path: thin ``torch.autograd.Function`` shims over the C ABI (include/p2c.h).
+
+PyTorch is plumbing here (device memory, streams, autograd graph); the arithmetic is in csrc/*.hip.
+No CPU path: host tensors raise.
+"""
+import ctypes
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from pedestrians_video_2_carla_amd import _lib
+from pedestrians_video_2_carla_amd._lib import KIND, TRANSFORM, P2C_JOINTS, PoseHeadDesc
+from pedestrians_video_2_carla_amd.data.carla import reference as ref
+
+J = P2C_JOINTS
+
+# names of the optional materialised tensors, in the order PoseHeadFunction returns them
+OUTPUT_KEYS = ('pose_changes', 'projection_2d', 'projection_2d_transformed', 'projection_2d_shift',
+               'projection_2d_scale', 'relative_pose_loc', 'relative_pose_rot', 'absolute_pose_loc',
+               'absolute_pose_rot', 'world_loc', 'world_rot')
+_DESC_FIELD = {'pose_changes': 'out_pose_changes', 'projection_2d': 'out_projection_2d',
+               'projection_2d_transformed': 'out_projection_2d_transformed', 'projection_2d_shift': 'out_shift',
+               'projection_2d_scale': 'out_scale', 'relative_pose_loc': 'out_relative_pose_loc',
+               'relative_pose_rot': 'out_relative_pose_rot', 'absolute_pose_loc': 'out_absolute_pose_loc',
+               'absolute_pose_rot': 'out_absolute_pose_rot', 'world_loc': 'out_world_loc',
+               'world_rot': 'out_world_rot'}
+
+
+def _require_device(t: Tensor, name: str, dtype=torch.float32) -> Tensor:
+    if not t.is_cuda:
+        raise _lib.P2CError(f'{name} must live on the GPU: the pose-head hot path has no CPU implementation')
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass(frozen=True)
+class PoseHeadSpec:
+    """Static configuration of one flow (everything that does not change from batch to batch)."""
+    kind: str = 'pose_changes_6d'                 # key of _lib.KIND
+    transform: str = 'hips_neck_bbox'             # key of _lib.TRANSFORM
+    mask_missing_joints: bool = True
+    hips_idx: Tuple[int, ...] = (1,)              # shift point joints of the normaliser (in the 26-joint output)
+    neck_idx: Tuple[int, ...] = (8,)
+    gmap2d: Tuple[int, ...] = tuple(range(J))     # predicted joint -> gt joint, -1 = not common
+    gmap3d: Tuple[int, ...] = tuple(range(J))
+    hips_lane: int = 1                            # predicted joint that is never masked, -1 = none
+    eval_slice: Tuple[Optional[int], Optional[int]] = (None, None)
+    near_zero: float = 1e-5
+    camera: Tuple[float, float, float, float, float] = (ref.CAMERA['f'], ref.CAMERA['cx'], ref.CAMERA['cy'],
+                                                        ref.CAMERA['dist'], ref.CAMERA['elev'])
+
+    def frames(self, T: int) -> Tuple[int, int]:
+        t0, t1, _ = slice(*self.eval_slice).indices(T)
+        return t0, max(t0, t1)
+
+
+def joint_maps(out_idx, in_idx, n_gt_joints: int = J) -> Tuple[int, ...]:
+    """(output_indices, input_indices) of ``get_common_indices`` -> per-predicted-joint gt index table."""
+    if isinstance(out_idx, slice):
+        return tuple(j if j < n_gt_joints else -1 for j in range(J))
+    table = [-1] * J
+    for o, i in zip(out_idx, in_idx):
+        table[o] = i
+    return tuple(table)
+
+
+def _fill_desc(spec: PoseHeadSpec, y: Tensor, skel_type: Tensor, dloc, drot, gt2d, gt3d, bufs: Dict[str, Tensor],
+               outs: Dict[str, Tensor]) -> PoseHeadDesc:
+    B, T = y.shape[0], y.shape[1]
+    d = PoseHeadDesc()
+    d.B, d.T = B, T
+    d.kind, d.transform = KIND[spec.kind], TRANSFORM[spec.transform]
+    d.t0, d.t1 = spec.frames(T)
+    d.mask_missing_joints = int(spec.mask_missing_joints)
+    d.hips_lane = spec.hips_lane
+    d.n_hips, d.n_neck = len(spec.hips_idx), len(spec.neck_idx)
+    for i, v in enumerate(spec.hips_idx):
+        d.hips_idx[i] = v
+    for i, v in enumerate(spec.neck_idx):
+        d.neck_idx[i] = v
+    d.gmap2d[:] = spec.gmap2d
+    d.gmap3d[:] = spec.gmap3d
+    d.n_common2d = sum(1 for v in spec.gmap2d if v >= 0)
+    d.n_common3d = sum(1 for v in spec.gmap3d if v >= 0)
+    d.cam_f, d.cam_cx, d.cam_cy, d.cam_dist, d.cam_elev = spec.camera
+    d.near_zero = spec.near_zero
+    dev = y.device
+    d.y, d.skel_type = y.data_ptr(), skel_type.data_ptr()
+    if spec.kind == 'absolute_loc':
+        shift, scale = ref.get_hips_neck_tables(dev)
+        d.ref_hn_shift, d.ref_hn_scale = shift.data_ptr(), scale.data_ptr()
+    else:
+        loc, rot = ref.get_relative_tensors(dev)
+        d.ref_rel_loc, d.ref_rel_rot = loc.data_ptr(), rot.data_ptr()
+    d.dloc, d.drot = _ptr(dloc), _ptr(drot)
+    if gt2d is not None:
+        d.gt2d, d.gt2d_joints, d.gt2d_channels = gt2d.data_ptr(), gt2d.shape[-2], gt2d.shape[-1]
+    if gt3d is not None:
+        d.gt3d, d.gt3d_joints = gt3d.data_ptr(), gt3d.shape[-2]
+    d.partials, d.loss_sums, d.losses = (bufs[k].data_ptr() for k in ('partials', 'loss_sums', 'losses'))
+    d.final_rel_rot = _ptr(bufs.get('final_rel_rot'))
+    for k, t in outs.items():
+        setattr(d, _DESC_FIELD[k], t.data_ptr())
+    return d
+
+
+def _check_shapes(spec: PoseHeadSpec, y, skel_type, dloc, drot, gt2d, gt3d):
+    B, T = y.shape[0], y.shape[1]
+    want = {'pose_changes_6d': (B, T, J, 6), 'relative_rot_6d': (B, T, J, 6), 'pose_changes': (B, T, J, 3, 3),
+            'relative_rot': (B, T, J, 3, 3), 'absolute_loc': (B, T, J, 3)}[spec.kind]
+    if tuple(y.shape) != want:
+        # same wording as the reference's rank checks (modules/layers/projection.py:90-98)
+        raise RuntimeError(f'{spec.kind} input should have shape {want}, got {tuple(y.shape)}')
+    if tuple(skel_type.shape) != (B,):
+        raise RuntimeError(f'skel_type should have shape ({B},), got {tuple(skel_type.shape)}')
+    if dloc is not None and tuple(dloc.shape) != (B, T, 3):
+        raise RuntimeError(f'world_loc_change_batch should have shape {(B, T, 3)}, got {tuple(dloc.shape)}')
+    if drot is not None and tuple(drot.shape) != (B, T, 3, 3):
+        raise RuntimeError(f'world_rot_change_batch should have shape {(B, T, 3, 3)}, got {tuple(drot.shape)}')
+    for name, g, c, gm in (('gt2d', gt2d, 2, spec.gmap2d), ('gt3d', gt3d, 3, spec.gmap3d)):
+        if g is None:
+            continue
+        if g.ndim != 4 or g.shape[0] != B or g.shape[1] != T or g.shape[3] < c or (name == 'gt3d' and g.shape[3] != 3):
+            raise RuntimeError(f'{name} should have shape ({B}, {T}, joints, {c}), got {tuple(g.shape)}')
+        if max(gm) >= g.shape[2]:
+            raise RuntimeError(f'{name} has {g.shape[2]} joints but the joint map needs index {max(gm)}')
+
+
+_OUT_SHAPES = {'pose_changes': (J, 3, 3), 'projection_2d': (J, 3), 'projection_2d_transformed': (J, 3),
+               'projection_2d_shift': (2,), 'projection_2d_scale': (), 'relative_pose_loc': (J, 3),
+               'relative_pose_rot': (J, 3, 3), 'absolute_pose_loc': (J, 3), 'absolute_pose_rot': (J, 3, 3),
+               'world_loc': (3,), 'world_rot': (3, 3)}
+
+
+def available_outputs(spec: PoseHeadSpec, world: bool) -> Tuple[str, ...]:
+    keys = ['projection_2d', 'absolute_pose_loc']
+    if spec.transform != 'none':
+        keys += ['projection_2d_transformed', 'projection_2d_shift', 'projection_2d_scale']
+    if spec.kind != 'absolute_loc':
+        keys += ['relative_pose_loc', 'relative_pose_rot', 'absolute_pose_rot']
+    if spec.kind in ('pose_changes_6d', 'pose_changes'):
+        keys += ['pose_changes']
+    if world:
+        keys += ['world_loc', 'world_rot']
+    return tuple(keys)
+
+
+class PoseHeadFunction(torch.autograd.Function):
+    """losses (3,) = (loc_2d, loc_3d, loc_2d_3d) [+ materialised tensors] = f(model output y)."""
+
+    @staticmethod
+    def forward(ctx, y, spec: PoseHeadSpec, skel_type, dloc, drot, gt2d, gt3d, want: Tuple[str, ...]):
+        lib = _lib.lib()
+        y = _require_device(y, 'pose_inputs')
+        skel_type = _require_device(skel_type, 'skel_type', torch.int32)
+        dloc = None if dloc is None else _require_device(dloc, 'world_loc_change_batch')
+        drot = None if drot is None else _require_device(drot, 'world_rot_change_batch')
+        gt2d = None if gt2d is None else _require_device(gt2d, 'gt2d')
+        gt3d = None if gt3d is None else _require_device(gt3d, 'gt3d')
+        _check_shapes(spec, y, skel_type, dloc, drot, gt2d, gt3d)
+        B, T = y.shape[0], y.shape[1]
+        dev = y.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        bufs = {
+            'partials': torch.empty(lib.p2c_pose_head_workspace_floats(B), **f32),
+            'loss_sums': torch.empty(4, **f32),
+            'losses': torch.empty(3, **f32),
+        }
+        if spec.kind in ('pose_changes_6d', 'pose_changes'):
+            bufs['final_rel_rot'] = torch.empty(B, J, 3, 3, **f32)
+        t0, t1 = spec.frames(T)
+        outs = {}
+        for k in want:
+            full = torch.zeros if (k.startswith('projection_2d_') and (t0, t1) != (0, T)) else torch.empty
+            outs[k] = full((B, T) + _OUT_SHAPES[k], **f32)
+        desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, outs)
+        with torch.cuda.device(dev):
+            _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), _stream()), 'p2c_pose_head_fwd')
+        ctx.spec, ctx.want = spec, want
+        ctx.save_for_backward(y, skel_type, dloc, drot, gt2d, gt3d, bufs['loss_sums'], bufs.get('final_rel_rot'))
+        ctx.bufs = bufs
+        result = [outs[k] for k in want]
+        nondiff = [outs[k] for k in want if k not in ('absolute_pose_loc', 'projection_2d_transformed')
+                   and not (k == 'projection_2d' and spec.transform == 'none')]
+        ctx.mark_non_differentiable(*nondiff)
+        return (bufs['losses'], *result)
+
+    @staticmethod
+    def backward(ctx, g_losses, *g_outs):
+        lib = _lib.lib()
+        spec = ctx.spec
+        y, skel_type, dloc, drot, gt2d, gt3d, loss_sums, final_rel_rot = ctx.saved_tensors
+        bufs = dict(ctx.bufs)
+        bufs['loss_sums'] = loss_sums
+        if final_rel_rot is not None:
+            bufs['final_rel_rot'] = final_rel_rot
+        g_abs = g_projt = None
+        for k, g in zip(ctx.want, g_outs):
+            if g is None:
+                continue
+            if k == 'absolute_pose_loc':
+                g_abs = _require_device(g, 'grad absolute_pose_loc')
+            elif k == 'projection_2d_transformed' or (k == 'projection_2d' and spec.transform == 'none'):
+                g_projt = _require_device(g, 'grad ' + k)
+        g_losses = None if g_losses is None else _require_device(g_losses, 'grad losses')
+        desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, {})
+        grad_y = torch.empty_like(y)
+        with torch.cuda.device(y.device):
+            _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), _ptr(g_losses), _ptr(g_abs), _ptr(g_projt),
+                                             grad_y.data_ptr(), _stream()), 'p2c_pose_head_bwd')
+        return grad_y, None, None, None, None, None, None, None
+
+
+def pose_head(y: Tensor, spec: PoseHeadSpec, skel_type: Tensor, dloc: Optional[Tensor] = None,
+              drot: Optional[Tensor] = None, gt2d: Optional[Tensor] = None, gt3d: Optional[Tensor] = None,
+              want: Sequence[str] = ()) -> Tuple[Tensor, Dict[str, Tensor]]:
+    """Fused pose head. Returns (losses (3,), {name: materialised tensor for name in want})."""
+    want = tuple(want)
+    res = PoseHeadFunction.apply(y, spec, skel_type, dloc, drot, gt2d, gt3d, want)
+    return res[0], dict(zip(want, res[1:]))

@@ -1,0 +1,283 @@
+"""GPU parity of the fused pose head (HIP, through the C ABI) against the oracle and the reference's golden vectors.
+
+Tolerance (BASELINE.json north_star): 1e-4 relative, fp32 -- enforced as max|a-b| <= 1e-4 * max|ref| per tensor, with the
+fp64 oracle as ``ref``. Gradients of ill-conditioned random poses (projected hips-neck distance of a fraction of a
+pixel) are the one place where fp32 itself is worse than that: there the bound is max(1e-4 * max|ref|, 2 x the error
+the fp32 evaluation of the same oracle -- i.e. the reference's own arithmetic -- makes against fp64).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import pose_head as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def close(a, b, what, rtol=RTOL, fp32_ref=None):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = b.abs().max().item()
+    err = (a - b).abs().max().item()
+    bound = rtol * scale + 1e-30
+    if fp32_ref is not None:
+        bound = max(bound, 2.0 * (fp32_ref.detach().double().cpu() - b).abs().max().item())
+    assert math.isfinite(err) and err <= bound, f'{what}: max err {err:.3e} vs scale {scale:.3e} (bound {bound:.3e})'
+
+
+def run_hip(y, spec, skel_type, dloc=None, drot=None, gt2d=None, gt3d=None, want=None, grad=True,
+            upstream=(0.0, 0.0, 1.0)):
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    yd = y.float().to(d).requires_grad_(grad)
+    mv = lambda t: None if t is None else t.float().to(d)
+    if want is None:
+        want = ops.available_outputs(spec, dloc is not None or drot is not None)
+    losses, outs = ops.pose_head(yd, spec, skel_type.to(d).int(), mv(dloc), mv(drot), mv(gt2d), mv(gt3d), want)
+    g = None
+    if grad:
+        w = torch.tensor(upstream, device=d)
+        total = (losses * w)[torch.tensor([u != 0 for u in upstream])].sum()
+        total.backward()
+        g = yd.grad
+    return losses, outs, g
+
+
+def run_oracle(y, kind, skel_type, dloc=None, drot=None, gt2d=None, gt3d=None, upstream=(0.0, 0.0, 1.0),
+               dtype=torch.float64, **kw):
+    dd = lambda t: None if t is None else t.to(dtype)
+    y64 = y.to(dtype).clone().requires_grad_(True)
+    o = O.pose_head(y64, kind, skel_type, dd(dloc), dd(drot), gt2d=dd(gt2d), gt3d=dd(gt3d), **kw)
+    total = 0.0
+    for name, u in zip(('loc_2d', 'loc_3d', 'loc_2d_3d'), upstream):
+        if u != 0:
+            total = total + u * o[name]
+    if isinstance(total, torch.Tensor):
+        total.backward()
+    return o, y64.grad
+
+
+OUT_KEYS = ('projection_2d', 'projection_2d_transformed', 'absolute_pose_loc', 'absolute_pose_rot',
+            'relative_pose_rot', 'relative_pose_loc', 'world_loc', 'world_rot', 'pose_changes')
+
+
+@pytest.mark.parametrize('tag', ['pose_changes', 'pose_changes_missing', 'pose_changes_world'])
+def test_golden_pose_changes_6d(golden, tag):
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    g = golden(tag)
+    world = g['dloc'].numel() > 0
+    losses, outs, grad = run_hip(g['y6d'], PoseHeadSpec(kind='pose_changes_6d'), g['skel_type'],
+                                 g['dloc'] if world else None, g['drot'] if world else None,
+                                 g['gt_projection_2d_transformed'], g['gt_absolute_pose_loc'])
+    for i, k in enumerate(('loc_2d', 'loc_3d', 'loc_2d_3d')):
+        close(losses[i], g[k], f'{tag}:{k}')
+    for k in OUT_KEYS:
+        if k in outs:
+            close(outs[k], g[k], f'{tag}:{k}')
+    close(outs['projection_2d_shift'], g['shift'], 'shift')
+    close(outs['projection_2d_scale'], g['scale'], 'scale')
+    close(grad, g['grad_y'], f'{tag}:grad_y')
+
+
+def test_golden_pose_changes_matrix_input(golden):
+    """The reference's API tensor: (B,T,J,3,3) rotation matrices from the model's _format_output."""
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    g = golden('pose_changes_missing')
+    m = g['pose_changes']
+    losses, outs, grad = run_hip(m, PoseHeadSpec(kind='pose_changes'), g['skel_type'], None, None,
+                                 g['gt_projection_2d_transformed'], g['gt_absolute_pose_loc'])
+    close(losses[2], g['loc_2d_3d'], 'loc_2d_3d')
+    close(outs['absolute_pose_loc'], g['absolute_pose_loc'], 'abs_loc')
+    o, gref = run_oracle(m, 'pose_changes', g['skel_type'], gt2d=g['gt_projection_2d_transformed'],
+                         gt3d=g['gt_absolute_pose_loc'])
+    close(grad, gref, 'grad wrt matrices')
+
+
+def test_golden_absolute_loc(golden):
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    g = golden('absolute_loc')
+    losses, outs, grad = run_hip(g['y'], PoseHeadSpec(kind='absolute_loc'), g['skel_type'], None, None,
+                                 g['gt_projection_2d_transformed'], g['gt_absolute_pose_loc'])
+    for i, k in enumerate(('loc_2d', 'loc_3d', 'loc_2d_3d')):
+        close(losses[i], g[k], k)
+    for k in ('projection_2d', 'projection_2d_transformed', 'absolute_pose_loc'):
+        close(outs[k], g[k], k)
+    close(grad, g['grad_y'], 'grad_y')
+
+
+def test_golden_relative_rot(golden):
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    g = golden('relative_rot')
+    spec = PoseHeadSpec(kind='relative_rot_6d', transform='none')
+    gt3 = torch.randn(4, 16, 26, 3, generator=torch.Generator().manual_seed(1))
+    gt2 = torch.randn(4, 16, 26, 2, generator=torch.Generator().manual_seed(2)) * 50 + 400
+    losses, outs, grad = run_hip(g['y6d'], spec, g['skel_type'], gt2d=gt2, gt3d=gt3)
+    for k in ('projection_2d', 'absolute_pose_loc', 'absolute_pose_rot', 'relative_pose_loc'):
+        close(outs[k], g[k], k)
+    o, gref = run_oracle(g['y6d'], 'relative_rot_6d', g['skel_type'], gt2d=gt2, gt3d=gt3, transform='none')
+    close(losses[2], o['loc_2d_3d'], 'loss')
+    close(grad, gref, 'grad')
+
+
+def _random_case(B, T, seed, missing=0.1):
+    gen = torch.Generator().manual_seed(seed)
+    y = torch.randn(B, T, 26, 6, generator=gen)
+    y[..., 0] += 1.5
+    y[..., 4] += 1.5
+    st = torch.randint(0, 4, (B,), generator=gen)
+    tgt = O.synthetic_batch(B, T, seed=seed + 1, missing_prob=0.0)
+    gt2 = tgt['projection_2d_transformed'].clone()
+    gt2[torch.rand(B, T, 26, generator=gen) < missing] = 0.0
+    return y, st, gt2, tgt['absolute_pose_loc'], tgt['projection_2d']
+
+
+@pytest.mark.parametrize('B,T', [(1, 1), (3, 5), (37, 7), (64, 16), (129, 30)])
+def test_random_ragged_sizes(B, T):
+    """Odd batch sizes (half-filled wavefronts), T != 16, masked gt joints, each loss requested on its own."""
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    y, st, gt2, gt3, _ = _random_case(B, T, seed=B * 100 + T)
+    for upstream in ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0)):
+        losses, outs, grad = run_hip(y, PoseHeadSpec(kind='pose_changes_6d'), st, gt2d=gt2, gt3d=gt3,
+                                     want=('projection_2d_transformed',), upstream=upstream)
+        o, gref = run_oracle(y, 'pose_changes_6d', st, gt2d=gt2, gt3d=gt3, upstream=upstream)
+        _, g32 = run_oracle(y, 'pose_changes_6d', st, gt2d=gt2, gt3d=gt3, upstream=upstream, dtype=torch.float32)
+        for i, k in enumerate(('loc_2d', 'loc_3d', 'loc_2d_3d')):
+            close(losses[i], o[k], k)
+        close(outs['projection_2d_transformed'], o['projection_2d_transformed'], 'proj_t')
+        close(grad, gref, f'grad {upstream}', fp32_ref=g32)
+
+
+@pytest.mark.parametrize('transform', ['none', 'hips_neck', 'bbox', 'hips_neck_bbox'])
+def test_transforms(transform):
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    B, T = 11, 9
+    y, st, gt2, gt3, gt2_px = _random_case(B, T, seed=7)
+    if transform == 'none':
+        gt2 = gt2_px
+    elif transform != 'hips_neck_bbox':
+        gt2 = O.normalize(gt2_px.double(), transform)[0].float()
+    losses, outs, grad = run_hip(y, PoseHeadSpec(kind='pose_changes_6d', transform=transform), st, gt2d=gt2, gt3d=gt3)
+    o, gref = run_oracle(y, 'pose_changes_6d', st, gt2d=gt2, gt3d=gt3, transform=transform)
+    close(losses[0], o['loc_2d'], 'loc_2d')
+    if transform != 'none':
+        close(outs['projection_2d_transformed'], o['projection_2d_transformed'], 'proj_t')
+        close(outs['projection_2d_scale'], o['projection_2d_scale'], 'scale')
+    close(grad, gref, 'grad')
+
+
+def test_bbox_fallback_path_with_world_motion():
+    """Pedestrian pushed off-screen: hips/neck project to negative pixels -> 'missing' -> bbox scale fallback
+    (hips_neck_bbox_fallback_extractor.py:25-38, tensors.py:16)."""
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    B, T = 6, 8
+    y, st, gt2, gt3, _ = _random_case(B, T, seed=21, missing=0.0)
+    dloc = torch.zeros(B, T, 3)
+    dloc[:, 0, 1] = 3.2      # world y: u = 400 - 400 * 3.2 / 3.1 < 0
+    dloc[:, 0, 2] = -3.55    # world z: v ~ 300 + 400 * (-3.55 + 1.2) / 3.1 ~ -3
+    dloc[:3, 0, 2] = -3.2    # first clips: hips v positive -> regular path in the same launch
+    losses, outs, grad = run_hip(y, PoseHeadSpec(kind='pose_changes_6d'), st, dloc=dloc, gt2d=gt2, gt3d=gt3)
+    o, gref = run_oracle(y, 'pose_changes_6d', st, dloc=dloc, gt2d=gt2, gt3d=gt3)
+    hips = o['projection_2d'][:, :, 1, :2]
+    assert (hips < 1e-5).all(-1).any() and not (hips < 1e-5).all(-1).all(), 'case must mix both paths'
+    close(outs['projection_2d_scale'], o['projection_2d_scale'], 'scale')
+    close(outs['projection_2d_transformed'], o['projection_2d_transformed'], 'proj_t')
+    close(losses[2], o['loc_2d_3d'], 'loss')
+    close(grad, gref, 'grad')
+
+
+def test_other_skeleton_targets_and_eval_slice():
+    """gt in BODY_25 layout (21 common joints, hips column from the input skeleton) and a PoseFormer-like eval slice."""
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec, joint_maps
+    from pedestrians_video_2_carla_amd.data.base.skeleton import get_common_indices
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.data.openpose.skeleton import BODY_25_SKELETON
+    B, T = 9, 12
+    y, st, gt2c, gt3c, _ = _random_case(B, T, seed=33)
+    out_idx, in_idx = get_common_indices(input_nodes=BODY_25_SKELETON, output_nodes=CARLA_SKELETON)
+    gt2 = torch.zeros(B, T, 25, 3)
+    gt3 = torch.zeros(B, T, 25, 3)
+    gt2[:, :, in_idx, :2] = gt2c[:, :, out_idx]
+    gt2[..., 2] = 0.7
+    gt3[:, :, in_idx] = gt3c[:, :, out_idx]
+    hips_col = in_idx.index(BODY_25_SKELETON.MidHip.value)
+    gm = joint_maps(out_idx, in_idx, 25)
+    spec = PoseHeadSpec(kind='pose_changes_6d', gmap2d=gm, gmap3d=gm, hips_lane=out_idx[hips_col], eval_slice=(4, 9))
+    losses, outs, grad = run_hip(y, spec, st, gt2d=gt2, gt3d=gt3, want=())
+    o, gref = run_oracle(y, 'pose_changes_6d', st, gt2d=gt2, gt3d=gt3, out_idx=out_idx, in_idx=in_idx,
+                         hips_col=hips_col, eval_slice=slice(4, 9))
+    for i, k in enumerate(('loc_2d', 'loc_3d', 'loc_2d_3d')):
+        close(losses[i], o[k], k)
+    close(grad, gref, 'grad')
+
+
+def test_external_gradients_of_materialised_outputs():
+    """A third-party loss on absolute_pose_loc / projection_2d_transformed back-propagates through the same kernel."""
+    from pedestrians_video_2_carla_amd import ops
+    B, T = 5, 6
+    y, st, _, _, _ = _random_case(B, T, seed=44)
+    d = dev()
+    gen = torch.Generator().manual_seed(5)
+    wa, wp = torch.randn(B, T, 26, 3, generator=gen), torch.randn(B, T, 26, 3, generator=gen)
+    yd = y.to(d).requires_grad_(True)
+    _, outs = ops.pose_head(yd, ops.PoseHeadSpec(kind='pose_changes_6d'), st.to(d).int(),
+                            want=('absolute_pose_loc', 'projection_2d_transformed'))
+    ((outs['absolute_pose_loc'] * wa.to(d)).sum() + (outs['projection_2d_transformed'][..., :2] * wp[..., :2].to(d)).sum()
+     ).backward()
+    y64 = y.double().requires_grad_(True)
+    o = O.pose_head(y64, 'pose_changes_6d', st)
+    ((o['absolute_pose_loc'] * wa).sum() + (o['projection_2d_transformed'][..., :2] * wp[..., :2]).sum()).backward()
+    close(yd.grad, y64.grad, 'grad')
+
+
+def test_degenerate_and_error_paths():
+    from pedestrians_video_2_carla_amd import ops, _lib
+    d = dev()
+    spec = ops.PoseHeadSpec(kind='pose_changes_6d')
+    st = torch.zeros(2, dtype=torch.int32, device=d)
+    with pytest.raises(RuntimeError):                                     # wrong rank (projection.py:90-98)
+        ops.pose_head(torch.zeros(2, 4, 26, 3, 3, device=d), spec, st)
+    with pytest.raises(_lib.P2CError):                                    # host tensor: no CPU fallback
+        ops.pose_head(torch.zeros(2, 4, 26, 6), spec, st)
+    # identity movement keeps the reference pose in every frame (tests/walker_control/test_p3d_pose_projection.py:75-128)
+    y = torch.zeros(4, 3, 26, 6, device=d)
+    y[..., 0] = 1.0
+    y[..., 4] = 1.0
+    _, outs = ops.pose_head(y, spec, torch.arange(4, dtype=torch.int32, device=d), want=('absolute_pose_loc', 'projection_2d'))
+    ref_abs, _ = O.absolute_tensors(torch.float32)
+    close(outs['absolute_pose_loc'][:, 2], ref_abs, 'identity movement')
+    close(outs['absolute_pose_loc'][:, 0], outs['absolute_pose_loc'][:, 2], 'frames equal')
+
+
+def test_full_size_properties():
+    """BASELINE.json sizes (B=1024 and 8192, T=16): finite, deterministic, and the batch loss equals the count-weighted
+    mean of per-shard losses (what the data-parallel ranks compute)."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    spec = ops.PoseHeadSpec(kind='pose_changes_6d')
+    for B in (1024, 8192):
+        gen = torch.Generator().manual_seed(B)
+        y = torch.randn(B, 16, 26, 6, generator=gen).to(d)
+        st = torch.randint(0, 4, (B,), generator=gen).int().to(d)
+        gt2 = torch.randn(B, 16, 26, 2, generator=gen).to(d)
+        gt2[torch.rand(B, 16, 26, generator=gen).to(d) < 0.1] = 0
+        gt3 = torch.randn(B, 16, 26, 3, generator=gen).to(d)
+        yr = y.clone().requires_grad_(True)
+        l1, _ = ops.pose_head(yr, spec, st, gt2d=gt2, gt3d=gt3)
+        l1[2].backward()
+        l2, _ = ops.pose_head(y, spec, st, gt2d=gt2, gt3d=gt3)
+        assert torch.isfinite(l1).all() and torch.isfinite(yr.grad).all()
+        assert torch.equal(l1, l2), 'forward must be bitwise deterministic'
+        h = B // 2
+        la, _ = ops.pose_head(y[:h], spec, st[:h], gt2d=gt2[:h], gt3d=gt3[:h])
+        lb, _ = ops.pose_head(y[h:], spec, st[h:], gt2d=gt2[h:], gt3d=gt3[h:])
+        na = (((gt2[:h] != 0).all(-1)) | (torch.arange(26, device=d) == 1)).sum()
+        nb = (((gt2[h:] != 0).all(-1)) | (torch.arange(26, device=d) == 1)).sum()
+        close((la[0] * na + lb[0] * nb) / (na + nb), l1[0], 'loc_2d shards', rtol=1e-5)
+        close((la[1] + lb[1]) / 2, l1[1], 'loc_3d shards', rtol=1e-5)
