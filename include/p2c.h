@@ -69,6 +69,8 @@ typedef struct p2c_pose_head_desc {
   int32_t gmap2d[P2C_JOINTS];   /* per predicted joint: index of its gt joint, -1 = not a common joint */
   int32_t gmap3d[P2C_JOINTS];
   int32_t n_common2d, n_common3d;       /* number of gmap entries >= 0 (loss denominators) */
+  int32_t world_absolute;               /* 0: dloc/drot are per-frame changes (utils/world.py:16-63); 1: they are the world
+                                           location / rotation of each frame (projection.py:215-226) */
   float cam_f, cam_cx, cam_cy, cam_dist, cam_elev;
   float near_zero;              /* 1e-5 */
   /* ---- inputs ---- */
@@ -78,7 +80,7 @@ typedef struct p2c_pose_head_desc {
   const float *ref_rel_rot;     /* (4,26,3,3) */
   const float *ref_hn_shift;    /* (4,3) hips of the reference absolute pose  (absolute_loc kind) */
   const float *ref_hn_scale;    /* (4)   |neck-hips| of the reference absolute pose */
-  const float *dloc;            /* (B,T,3)   world location changes or NULL (= ZeroTrajectory) */
+  const float *dloc;            /* (B,T,3)   world location changes (or locations) or NULL (= ZeroTrajectory) */
   const float *drot;            /* (B,T,3,3) world rotation changes or NULL */
   const float *gt2d;            /* targets['projection_2d_transformed'] (or 'projection_2d'); NULL = no loc_2d */
   const float *gt3d;            /* targets['absolute_pose_loc']; NULL = loc_3d unavailable */

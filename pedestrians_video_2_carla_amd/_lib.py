@@ -24,7 +24,7 @@ class PoseHeadDesc(ctypes.Structure):
         ('mask_missing_joints', _i32), ('hips_lane', _i32), ('n_hips', _i32), ('n_neck', _i32),
         ('hips_idx', _i32 * 2), ('neck_idx', _i32 * 2),
         ('gt2d_joints', _i32), ('gt2d_channels', _i32), ('gt3d_joints', _i32),
-        ('gmap2d', _i32 * P2C_JOINTS), ('gmap3d', _i32 * P2C_JOINTS), ('n_common2d', _i32), ('n_common3d', _i32),
+        ('gmap2d', _i32 * P2C_JOINTS), ('gmap3d', _i32 * P2C_JOINTS), ('n_common2d', _i32), ('n_common3d', _i32), ('world_absolute', _i32),
         ('cam_f', ctypes.c_float), ('cam_cx', ctypes.c_float), ('cam_cy', ctypes.c_float),
         ('cam_dist', ctypes.c_float), ('cam_elev', ctypes.c_float), ('near_zero', ctypes.c_float),
         ('y', _f32p), ('skel_type', _f32p), ('ref_rel_loc', _f32p), ('ref_rel_rot', _f32p),

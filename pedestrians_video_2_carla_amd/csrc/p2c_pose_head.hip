@@ -458,9 +458,12 @@ __device__ __forceinline__ void world_step(const p2c_pose_head_desc &d, const La
     M3 dr;
 #pragma unroll
     for (int i = 0; i < 9; ++i) dr.m[i] = d.drot[frame * 9 + i];
-    W.rot = mul(W.rot, dr);
+    W.rot = d.world_absolute ? dr : mul(W.rot, dr);
   }
-  if (d.dloc) W.loc = W.loc + v3(d.dloc[frame * 3 + 0], d.dloc[frame * 3 + 1], d.dloc[frame * 3 + 2]);
+  if (d.dloc) {
+    V3 dl = v3(d.dloc[frame * 3 + 0], d.dloc[frame * 3 + 1], d.dloc[frame * 3 + 2]);
+    W.loc = d.world_absolute ? dl : W.loc + dl;
+  }
 }
 __device__ __forceinline__ void world_store(const p2c_pose_head_desc &d, const LaneCtx &L, int t, const World &W) {
   if (L.j != 0 || L.clip >= d.B) return;
@@ -609,8 +612,11 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
   W.on = (d.dloc != nullptr) || (d.drot != nullptr);
   W.rot = identity();
   W.loc = v3(0.f, 0.f, 0.f);
-  if (W.on)
-    for (int t = 0; t < T; ++t) world_step(d, L, t, W);  // world state at the last frame
+  if (W.on) {  // world state at the last frame
+    if (d.world_absolute) world_step(d, L, T - 1, W);
+    else
+      for (int t = 0; t < T; ++t) world_step(d, L, t, W);
+  }
 
   HeadAcc acc{0.f, 0.f, 0.f};
   M3 carry = zero3();  // change[t+1]^T @ dL/d rel_rot[t+1]
@@ -677,7 +683,9 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
       }
     }
     // ---- world state of the previous frame (inverse step; drot is a rotation) ----
-    if (W.on && t > 0 && L.clip < d.B) {
+    if (W.on && t > 0 && d.world_absolute) {
+      world_step(d, L, t - 1, W);
+    } else if (W.on && t > 0 && L.clip < d.B) {
       size_t frame = (size_t)L.clip * T + t;
       if (d.drot) {
         M3 dr;

@@ -1,0 +1,34 @@
+"""``LitAutoencoderFlow``: 2-D pose -> model -> 2-D pose, loss = masked loc_2d (reference modules/flow/autoencoder.py).
+
+No projection layer; the model output *is* ``projection_2d_transformed`` (autoencoder.py:114-133). The masked MSE runs
+as the stand-alone HIP kernel p2c_loss2d_* through ``Loc2DPoseLoss``.
+"""
+from typing import Dict
+
+import torch
+
+from pedestrians_video_2_carla_amd.modules.flow.base import LitBaseFlow
+from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE
+from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2Seq, Seq2SeqEmbeddings
+from pedestrians_video_2_carla_amd.modules.movements.zero import ZeroMovements
+
+
+class LitAutoencoderFlow(LitBaseFlow):
+    @classmethod
+    def get_available_models(cls) -> Dict[str, Dict[str, torch.nn.Module]]:
+        return {'movements': {m.__name__: m for m in [ZeroMovements, LinearAE, Seq2Seq, Seq2SeqEmbeddings]}}
+
+    @classmethod
+    def get_default_models(cls) -> Dict[str, torch.nn.Module]:
+        return {'movements': Seq2SeqEmbeddings}
+
+    def _inner_step(self, frames, targets, edge_index=None, batch_vector=None, stage='train'):
+        model = self.movements_model
+        pose_inputs = model(frames, targets=targets if self.training and model.needs_targets else None,
+                            edge_index=None, batch_vector=None)
+        eval_slice = (slice(None), model.eval_slice)
+        return {
+            self._outputs_key: pose_inputs[eval_slice],
+            'inputs': frames[eval_slice],
+            'targets': {k: v[eval_slice[:v.ndim]] for k, v in targets.items()},
+        }

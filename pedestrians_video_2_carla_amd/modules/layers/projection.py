@@ -1,0 +1,117 @@
+"""The projection layer, HIP-backed (reference modules/layers/projection.py:19-226).
+
+Same seam as the reference: ``ProjectionModule(movements_output_type, trajectory_output_type)``,
+``on_batch_start(batch, batch_idx)`` then ``forward(pose_inputs, world_loc_change, world_rot_change) ->
+(projection (B,T,J,3), {relative_pose_loc, relative_pose_rot, absolute_pose_loc, absolute_pose_rot, world_loc, world_rot})``.
+
+What changed underneath:
+  * ``on_batch_start`` no longer builds one ``ControlledPedestrian`` (+ P3dPose, 26 mock carla.Transform objects) per
+    clip -- 120 ms of a 448 ms step at B=256 in the reference. Every clip uses one of four constant skeletons, so the
+    batch state is an int32 (B,) index tensor (data/carla/reference.py tables).
+  * ``forward`` is ONE kernel launch (p2c_pose_head_fwd) instead of T x 26 x (pad + 2 bmm + eye.repeat + 2 slice
+    writes) + T bmm + T camera transforms; ``fused_losses`` additionally folds transform_callable + loc_2d + loc_3d
+    in and writes nothing but three scalars (train-lean path).
+"""
+from typing import Dict, Optional, Sequence, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from pedestrians_video_2_carla_amd import ops
+from pedestrians_video_2_carla_amd.data.carla import reference as ref
+from pedestrians_video_2_carla_amd.modules.flow.output_types import (MovementsModelOutputType,
+                                                                   TrajectoryModelOutputType)
+
+_OUT_KEYS = ('relative_pose_loc', 'relative_pose_rot', 'absolute_pose_loc', 'absolute_pose_rot', 'world_loc',
+             'world_rot')
+
+
+class ProjectionModule(nn.Module):
+    def __init__(self,
+                 movements_output_type: MovementsModelOutputType = MovementsModelOutputType.pose_changes,
+                 trajectory_output_type: TrajectoryModelOutputType = TrajectoryModelOutputType.changes,
+                 **kwargs) -> None:
+        super().__init__()
+        if movements_output_type == MovementsModelOutputType.pose_2d:
+            raise ValueError('pose_2d outputs are not projected (autoencoder flow)')
+        self.movements_output_type = movements_output_type
+        self.trajectory_output_type = trajectory_output_type
+        # per-batch state (projection.py:46-50); not re-entrant, like the reference
+        self._skel_type: Optional[Tensor] = None
+        self._batch_size = 0
+
+    # ------------------------------------------------------------------------------------------------------------
+    def on_batch_start(self, batch, batch_idx):
+        (frames, _, meta) = batch
+        self._batch_size = len(frames)
+        # strict=True: ControlledPedestrian only knows the four CARLA (age, gender) pairs
+        # (walker_control/controlled_pedestrian.py:142-147, data/carla/utils.py:26-35)
+        self._skel_type = ref.skeleton_types_from_meta(meta, batch_size=self._batch_size, strict=True,
+                                                       device=frames.device)
+
+    # ------------------------------------------------------------------------------------------------------------
+    def kernel_kind(self, pose_inputs: Union[Tensor, Tuple[Tensor, Tensor]]) -> str:
+        """P2C_KIND_* for this output type and the tensor actually handed over (6-D or matrices)."""
+        t = self.movements_output_type
+        if t in (MovementsModelOutputType.pose_changes, MovementsModelOutputType.relative_rot):
+            base = 'pose_changes' if t == MovementsModelOutputType.pose_changes else 'relative_rot'
+            if pose_inputs.ndim == 4 and pose_inputs.shape[-1] == 6:
+                return base + '_6d'
+            if pose_inputs.ndim < 5:
+                raise RuntimeError('Pose changes should have shape of (N - batch_size, L - clip_length, B - bones, '
+                                   '3, 3 - rotations as rotation matrices)')
+            return base
+        if t == MovementsModelOutputType.absolute_loc:
+            if pose_inputs.ndim < 4:
+                raise RuntimeError('Absolute location should have shape of (N - batch_size, L - clip_length, '
+                                   'B - bones, 3 - absolute location coordinates)')
+            return 'absolute_loc'
+        if t == MovementsModelOutputType.absolute_loc_rot:
+            if not isinstance(pose_inputs, tuple):
+                raise RuntimeError('Absolute location with rotation should be a Tuple of tensors.')
+            return 'absolute_loc'
+        raise RuntimeError(f'unsupported movements output type {t}')
+
+    def _world_args(self, dloc, drot, identity_world: bool):
+        if identity_world:
+            return None, None, False
+        return dloc, drot, self.trajectory_output_type == TrajectoryModelOutputType.loc_rot
+
+    def _check_ready(self, pose_inputs):
+        if self._skel_type is None:
+            raise RuntimeError('ProjectionModule.on_batch_start(batch, batch_idx) must run before forward')
+        y = pose_inputs[0] if isinstance(pose_inputs, tuple) else pose_inputs
+        if len(y) != self._batch_size:
+            raise RuntimeError(f'batch of {len(y)} clips but on_batch_start saw {self._batch_size}')
+        return y
+
+    # ------------------------------------------------------------------------------------------------------------
+    def forward(self, pose_inputs_batch: Union[Tensor, Tuple[Tensor, Tensor]],
+                world_loc_change_batch: Tensor = None, world_rot_change_batch: Tensor = None,
+                identity_world: bool = False) -> Tuple[Tensor, Dict[str, Tensor]]:
+        """Materialising path (eval / predict / third-party losses): every tensor the reference returns."""
+        kind = self.kernel_kind(pose_inputs_batch)
+        y = self._check_ready(pose_inputs_batch)
+        dloc, drot, absolute = self._world_args(world_loc_change_batch, world_rot_change_batch, identity_world)
+        world = dloc is not None or drot is not None
+        spec = ops.PoseHeadSpec(kind=kind, transform='none', world_absolute=absolute)
+        want = [k for k in ops.available_outputs(spec, world) if k != 'pose_changes']
+        _, outs = ops.pose_head(y, spec, self._skel_type, dloc, drot, want=want)
+        B, T = y.shape[:2]
+        if not world:   # utils/world.py:33-38: initial transform repeated over the clip
+            outs['world_loc'] = torch.zeros(B, T, 3, device=y.device)
+            outs['world_rot'] = torch.eye(3, device=y.device).expand(B, T, 3, 3).contiguous()
+        if self.movements_output_type == MovementsModelOutputType.absolute_loc_rot:
+            outs['absolute_pose_rot'] = pose_inputs_batch[1]            # projection.py:138-142
+        return outs['projection_2d'], {k: outs.get(k) for k in _OUT_KEYS}
+
+    def fused_losses(self, pose_inputs_batch, world_loc_change_batch, world_rot_change_batch, identity_world: bool,
+                     spec_kwargs: dict, gt2d: Optional[Tensor], gt3d: Optional[Tensor],
+                     want: Sequence[str] = ()) -> Tuple[Tensor, Dict[str, Tensor]]:
+        """Train path: projection + transform + loc_2d/loc_3d/loc_2d_3d in one launch; ``want`` adds materialised
+        tensors on request. Returns (losses (3,), outputs)."""
+        kind = self.kernel_kind(pose_inputs_batch)
+        y = self._check_ready(pose_inputs_batch)
+        dloc, drot, absolute = self._world_args(world_loc_change_batch, world_rot_change_batch, identity_world)
+        spec = ops.PoseHeadSpec(kind=kind, world_absolute=absolute, **spec_kwargs)
+        return ops.pose_head(y, spec, self._skel_type, dloc, drot, gt2d, gt3d, want=want)

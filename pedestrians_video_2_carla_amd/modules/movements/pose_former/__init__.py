@@ -1,0 +1,1 @@
+from .pose_former import PoseFormer

@@ -1,0 +1,163 @@
+"""Seq2Seq movements model: LSTM encoder over the clip, LSTM decoder unrolled frame by frame
+(reference modules/movements/seq2seq/seq2seq.py:21-363; after Sutskever et al. 2014, arXiv:1409.3215).
+
+Parity notes:
+  * the recurrent layers are ``nn.LSTM`` (the "GRU" of BASELINE.json config 3 does not exist in the reference);
+  * ``_decode_frame`` does not carry the new hidden/cell state forward: every decoded frame starts from the ENCODER
+    state and only the previous output is fed back (seq2seq.py:272-288). Kept, checkpoints depend on it.
+Module / parameter names (``encoder.rnn``, ``decoder.rnn``, ``decoder.fc_out``) match the reference state_dict.
+"""
+import warnings
+from enum import Enum
+from typing import Dict, Iterable, Tuple, Union
+
+import torch
+from torch import Tensor, nn
+
+from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType
+from pedestrians_video_2_carla_amd.modules.movements.movements import MovementsModel, MovementsModelOutputTypeMixin
+from pedestrians_video_2_carla_amd.transforms.rotation_conversions import matrix_to_rotation_6d
+
+
+class TeacherMode(Enum):
+    no_force = 0
+    clip_force = 1
+    frames_force = 2
+
+
+def _stack(in_size, hid_dim, n_layers, dropout, bidirectional):
+    if isinstance(hid_dim, int):
+        return nn.LSTM(in_size, hid_dim, num_layers=n_layers, dropout=dropout, bidirectional=bidirectional)
+    sizes = [in_size] + list(hid_dim)
+    return nn.Sequential(*[nn.LSTM(a, b, num_layers=1, dropout=dropout, bidirectional=bidirectional)
+                           for a, b in zip(sizes[:-1], sizes[1:])])
+
+
+class Encoder(nn.Module):
+    def __init__(self, hid_dim=64, n_layers=2, dropout=0.2, input_size=26 * 2, bidirectional=True):
+        super().__init__()
+        self.hid_dim, self.n_layers, self.input_size = hid_dim, n_layers, input_size
+        self.rnn = _stack(input_size, hid_dim, n_layers, dropout, bidirectional)
+
+    def forward(self, x):
+        _, (hidden, cell) = self.rnn(x.reshape(*x.shape[0:2], self.input_size))
+        return hidden, cell
+
+
+class Decoder(nn.Module):
+    def __init__(self, hid_dim=64, n_layers=2, dropout=0.2, output_size=26 * 6, bidirectional=False):
+        super().__init__()
+        self.hid_dim, self.n_layers, self.output_size = hid_dim, n_layers, output_size
+        self.rnn = _stack(output_size, hid_dim, n_layers, dropout, bidirectional)
+        self.fc_out = nn.Linear(hid_dim * 2 if bidirectional else hid_dim, output_size)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, hidden, cell):
+        output, (hidden, cell) = self.rnn(x.unsqueeze(0), (hidden, cell))
+        return self.fc_out(output.squeeze(0)), hidden, cell
+
+
+class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
+    def __init__(self,
+                 hidden_size: Union[int, Iterable[int]] = 64,
+                 num_layers: int = 2,
+                 p_dropout: float = 0.2,
+                 teacher_mode: TeacherMode = TeacherMode.no_force,
+                 teacher_force_ratio: float = 0.2,
+                 teacher_force_drop: float = 0.02,
+                 input_features: int = 2,
+                 invert_sequence: bool = False,
+                 bidirectional: bool = False,
+                 input_size: int = None,
+                 **kwargs):
+        super().__init__(**kwargs)
+        if input_size is not None and input_features is not None:
+            warnings.warn('Both input_size and input_features were specified, using input_size.')
+        self.input_size = input_size if input_size is not None else input_features * len(self.input_nodes)
+        self.output_size = self.output_features * len(self.output_nodes)
+        self.teacher_mode = teacher_mode if isinstance(teacher_mode, TeacherMode) else TeacherMode[teacher_mode]
+        forcing = self.teacher_mode != TeacherMode.no_force
+        self.teacher_force_ratio = teacher_force_ratio if forcing else 0.0
+        self.teacher_force_drop = teacher_force_drop if forcing else 0.0
+        if not isinstance(hidden_size, int):
+            assert len(hidden_size) == num_layers, 'hidden_size must be an int or a list of num_layers ints'
+        self.encoder = Encoder(hid_dim=hidden_size, n_layers=num_layers, dropout=p_dropout,
+                               input_size=self.input_size, bidirectional=bidirectional)
+        self.decoder = Decoder(hid_dim=hidden_size if isinstance(hidden_size, int) else hidden_size[::-1],
+                               n_layers=num_layers, dropout=p_dropout, output_size=self.output_size,
+                               bidirectional=bidirectional)
+        self.invert_sequence = invert_sequence
+        self._hparams.update({
+            'hidden_size': hidden_size, 'num_layers': num_layers, 'p_dropout': p_dropout,
+            'teacher_mode': self.teacher_mode.name, 'teacher_force_ratio': self.teacher_force_ratio,
+            'teacher_force_drop': self.teacher_force_drop, 'invert_sequence': self.invert_sequence,
+            'bidirectional': bidirectional,
+        })
+
+    @property
+    def needs_targets(self) -> bool:
+        return self.teacher_mode != TeacherMode.no_force
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        parent_parser = MovementsModel.add_model_specific_args(parent_parser)
+        group = parent_parser.add_argument_group('Seq2Seq Movements Module')
+        MovementsModelOutputTypeMixin.add_cli_args(group)
+        group.add_argument('--num_layers', default=2, type=int)
+        group.add_argument('--hidden_size', default=64, type=int)
+        group.add_argument('--p_dropout', default=0.2, type=float)
+        group.add_argument('--teacher_mode', default=TeacherMode.no_force, choices=list(TeacherMode),
+                           type=TeacherMode.__getitem__)
+        group.add_argument('--teacher_force_ratio', default=0.2, type=float)
+        group.add_argument('--teacher_force_drop', default=0.02, type=float)
+        group.add_argument('--invert_sequence', default=False, type=lambda v: str(v).lower() in ('1', 'true'))
+        group.add_argument('--bidirectional', default=False, type=lambda v: str(v).lower() in ('1', 'true'))
+        return parent_parser
+
+    def forward(self, x: Tensor, targets: Dict[str, Tensor] = None, *args, **kwargs) -> Tensor:
+        original_shape = x.shape
+        batch_size, clip_length = original_shape[:2]
+        hidden, cell = self.encoder(self._format_input(x))
+        step_in = torch.zeros((batch_size, self.decoder.output_size), device=x.device)     # <sos>
+        needs_forcing, forced, force_idx = self._teacher_forcing(targets)
+        outputs = []
+        for t in range(clip_length):
+            # NB: (hidden, cell) are the encoder's for every frame -- see module docstring
+            out, _, _ = self.decoder(step_in, hidden, cell)
+            step_in = out
+            if needs_forcing:
+                step_in = torch.where(force_idx[t].unsqueeze(-1), forced[t], out)
+            outputs.append(out)
+        return self._format_output(original_shape, torch.stack(outputs, 0))
+
+    def _format_output(self, original_shape, outputs):
+        outputs = outputs.permute(1, 0, 2).reshape(*original_shape[:2], len(self.output_nodes), self.output_features)
+        return super()._format_output(outputs)
+
+    def _format_input(self, x: Tensor) -> Tensor:
+        x = x.permute(1, 0, *range(2, x.dim()))          # sequence first
+        return x.flip(0) if self.invert_sequence else x
+
+    def _teacher_forcing(self, targets) -> Tuple[bool, Tensor, Tensor]:
+        needs = (self.training and self.teacher_mode != TeacherMode.no_force and targets is not None
+                 and self.teacher_force_ratio > 0)
+        if not needs:
+            return False, None, None
+        if self.output_type == MovementsModelOutputType.pose_changes:
+            target = matrix_to_rotation_6d(targets['pose_changes'])
+        else:
+            target = targets['projection_2d_transformed']
+        B, T = target.shape[:2]
+        target = target.permute(1, 0, *range(2, target.dim())).reshape(T, B, self.decoder.output_size)
+        if self.teacher_mode == TeacherMode.clip_force:
+            idx = (torch.rand((1, B), device=target.device) < self.teacher_force_ratio).repeat(T, 1)
+        else:
+            idx = torch.rand((T, B), device=target.device) < self.teacher_force_ratio
+        return True, target, idx
+
+    def training_epoch_end(self, *args, **kwargs) -> Dict[str, float]:
+        if self.teacher_mode == TeacherMode.no_force:
+            return {}
+        current = self.teacher_force_ratio
+        self.teacher_force_ratio = max(0.0, current - self.teacher_force_drop) if current > self.teacher_force_drop else 0
+        return {'teacher_force_ratio/{}'.format(self.teacher_mode.name): current}

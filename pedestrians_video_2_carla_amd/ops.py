@@ -56,6 +56,7 @@ class PoseHeadSpec:
     gmap3d: Tuple[int, ...] = tuple(range(J))
     hips_lane: int = 1                            # predicted joint that is never masked, -1 = none
     eval_slice: Tuple[Optional[int], Optional[int]] = (None, None)
+    world_absolute: bool = False                  # trajectory output type loc_rot: dloc/drot are absolute per frame
     near_zero: float = 1e-5
     camera: Tuple[float, float, float, float, float] = (ref.CAMERA['f'], ref.CAMERA['cx'], ref.CAMERA['cy'],
                                                         ref.CAMERA['dist'], ref.CAMERA['elev'])
@@ -93,6 +94,7 @@ def _fill_desc(spec: PoseHeadSpec, y: Tensor, skel_type: Tensor, dloc, drot, gt2
     d.gmap3d[:] = spec.gmap3d
     d.n_common2d = sum(1 for v in spec.gmap2d if v >= 0)
     d.n_common3d = sum(1 for v in spec.gmap3d if v >= 0)
+    d.world_absolute = int(spec.world_absolute)
     d.cam_f, d.cam_cx, d.cam_cy, d.cam_dist, d.cam_elev = spec.camera
     d.near_zero = spec.near_zero
     dev = y.device
@@ -229,3 +231,113 @@ def pose_head(y: Tensor, spec: PoseHeadSpec, skel_type: Tensor, dloc: Optional[T
     want = tuple(want)
     res = PoseHeadFunction.apply(y, spec, skel_type, dloc, drot, gt2d, gt3d, want)
     return res[0], dict(zip(want, res[1:]))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# stand-alone normaliser (K4), masked 2-D MSE (K3), joint remap (K5)
+# ----------------------------------------------------------------------------------------------------------------------
+def _iarr(values: Sequence[int]):
+    return (ctypes.c_int32 * max(1, len(values)))(*values)
+
+
+class NormalizeFunction(torch.autograd.Function):
+    """Normalizer.__call__ on device: (out, shift, scale) = f(x); only ``out`` carries gradient (as in the reference,
+    where shift/scale are read back detached by the dataset, projection_2d_mixin.py:229-230)."""
+
+    @staticmethod
+    def forward(ctx, x, transform: str, dim: int, hips_idx, neck_idx, near_zero: float):
+        lib = _lib.lib()
+        x = _require_device(x, 'sample')
+        if x.ndim < 2 or x.shape[-1] < dim:
+            raise RuntimeError(f'sample should be (..., joints, >= {dim}), got {tuple(x.shape)}')
+        Jn, C = x.shape[-2], x.shape[-1]
+        N = x.numel() // (Jn * C)
+        out = torch.empty_like(x)
+        shift = torch.empty(x.shape[:-2] + (dim,), dtype=torch.float32, device=x.device)
+        scale = torch.empty(x.shape[:-2], dtype=torch.float32, device=x.device)
+        h, k = _iarr(hips_idx), _iarr(neck_idx)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.p2c_normalize_fwd(x.data_ptr(), out.data_ptr(), shift.data_ptr(), scale.data_ptr(), N, Jn, C,
+                                             dim, TRANSFORM[transform], len(hips_idx), h, len(neck_idx), k, near_zero,
+                                             _stream()), 'p2c_normalize_fwd')
+        ctx.save_for_backward(x)
+        ctx.cfg = (transform, dim, tuple(hips_idx), tuple(neck_idx), near_zero)
+        ctx.mark_non_differentiable(shift, scale)
+        return out, shift, scale
+
+    @staticmethod
+    def backward(ctx, g_out, g_shift, g_scale):
+        lib = _lib.lib()
+        (x,) = ctx.saved_tensors
+        transform, dim, hips_idx, neck_idx, near_zero = ctx.cfg
+        g_out = _require_device(g_out, 'grad')
+        Jn, C = x.shape[-2], x.shape[-1]
+        N = x.numel() // (Jn * C)
+        gx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.p2c_normalize_bwd(x.data_ptr(), g_out.data_ptr(), gx.data_ptr(), N, Jn, C, dim,
+                                             TRANSFORM[transform], len(hips_idx), _iarr(hips_idx), len(neck_idx),
+                                             _iarr(neck_idx), near_zero, _stream()), 'p2c_normalize_bwd')
+        return gx, None, None, None, None, None
+
+
+def normalize(x: Tensor, transform: str, dim: int = 2, hips_idx: Sequence[int] = (1,), neck_idx: Sequence[int] = (8,),
+              near_zero: float = 1e-5) -> Tuple[Tensor, Tensor, Tensor]:
+    return NormalizeFunction.apply(x, transform, dim, tuple(hips_idx), tuple(neck_idx), near_zero)
+
+
+class Loss2DFunction(torch.autograd.Function):
+    """Loc2DPoseLoss on device: masked MSE over the common joints of pred (...,Jp,>=2) and gt (...,Jg,>=2)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, pred_idx, gt_idx, hips_col: int, mask_missing_joints: bool):
+        lib = _lib.lib()
+        pred, gt = _require_device(pred, 'prediction'), _require_device(gt, 'target')
+        if pred.shape[:-2] != gt.shape[:-2]:
+            raise RuntimeError(f'prediction {tuple(pred.shape)} and target {tuple(gt.shape)} differ in leading dims')
+        Jp, Cp, Jg, Cg = pred.shape[-2], pred.shape[-1], gt.shape[-2], gt.shape[-1]
+        N = pred.numel() // (Jp * Cp)
+        f32 = dict(dtype=torch.float32, device=pred.device)
+        partials = torch.empty(lib.p2c_loss2d_workspace_floats(N), **f32)
+        sums, loss = torch.empty(2, **f32), torch.empty(1, **f32)
+        with torch.cuda.device(pred.device):
+            _lib.check(lib.p2c_loss2d_fwd(pred.data_ptr(), gt.data_ptr(), N, Jp, Cp, Jg, Cg, len(pred_idx),
+                                          _iarr(pred_idx), _iarr(gt_idx), hips_col, int(mask_missing_joints),
+                                          partials.data_ptr(), sums.data_ptr(), loss.data_ptr(), _stream()),
+                       'p2c_loss2d_fwd')
+        ctx.save_for_backward(pred, gt, sums)
+        ctx.cfg = (tuple(pred_idx), tuple(gt_idx), hips_col, bool(mask_missing_joints))
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        lib = _lib.lib()
+        pred, gt, sums = ctx.saved_tensors
+        pred_idx, gt_idx, hips_col, mask = ctx.cfg
+        Jp, Cp, Jg, Cg = pred.shape[-2], pred.shape[-1], gt.shape[-2], gt.shape[-1]
+        N = pred.numel() // (Jp * Cp)
+        g_loss = _require_device(g_loss, 'grad').reshape(1)
+        gp = torch.empty_like(pred)
+        with torch.cuda.device(pred.device):
+            _lib.check(lib.p2c_loss2d_bwd(pred.data_ptr(), gt.data_ptr(), N, Jp, Cp, Jg, Cg, len(pred_idx),
+                                          _iarr(pred_idx), _iarr(gt_idx), hips_col, int(mask), sums.data_ptr(),
+                                          g_loss.data_ptr(), gp.data_ptr(), _stream()), 'p2c_loss2d_bwd')
+        return gp, None, None, None, None, None
+
+
+def loss_loc_2d(pred: Tensor, gt: Tensor, pred_idx: Sequence[int], gt_idx: Sequence[int], hips_col: int = -1,
+                mask_missing_joints: bool = True) -> Tensor:
+    return Loss2DFunction.apply(pred, gt, tuple(pred_idx), tuple(gt_idx), hips_col, mask_missing_joints)
+
+
+def remap_nodes(src: Tensor, n_dst_joints: int, src_idx: Sequence[int], dst_idx: Sequence[int]) -> Tensor:
+    """BaseDataset._get_common_tensor on device: (N.., Jsrc, C) -> (N.., Jdst, C), unmapped joints zero."""
+    lib = _lib.lib()
+    src = _require_device(src, 'data_item')
+    Js, C = src.shape[-2], src.shape[-1]
+    N = src.numel() // (Js * C)
+    dst = torch.empty(src.shape[:-2] + (n_dst_joints, C), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        _lib.check(lib.p2c_remap_nodes(src.data_ptr(), dst.data_ptr(), N, Js, n_dst_joints, C, len(src_idx),
+                                       _iarr(src_idx), _iarr(dst_idx), _stream()), 'p2c_remap_nodes')
+    return dst

@@ -1,0 +1,164 @@
+"""Minimal trainer: the Lightning loop the reference delegates to, reduced to what the train step needs
+(reference modeling.py:275-282 ``pl.Trainer.from_argparse_args(...).fit(model, datamodule)``).
+
+Hook order per step is Lightning's: ``on_train_batch_start`` -> ``training_step`` -> backward -> optimizer step.
+Two execution modes:
+  * eager: every launch issued from Python;
+  * ``use_graph=True``: the step (model forward, HIP pose head forward/backward, optimizer) is captured once into a
+    HIP graph on static batch buffers and replayed -- the launch-bound regime at B=256 (about 50 kernels of a few
+    microseconds each) is exactly what hipGraphs are for. With more than one rank the gradient all-reduce stays outside
+    the graphs (capture A: zero-grad + forward + backward; eager RCCL all-reduce; capture B: optimizer).
+"""
+import os
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from pedestrians_video_2_carla_amd.parallel.flat import FlatParameters, GradientExchange
+
+
+def seed_everything(seed: int = 22742):
+    """``pl.seed_everything(seed, workers=True)`` (reference modeling.py:350-351; default seed :120-121)."""
+    import random
+    import numpy as np
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    os.environ['PL_GLOBAL_SEED'] = str(seed)
+
+
+def init_distributed(backend: Optional[str] = None) -> Dict[str, int]:
+    """One process per GPU, rendezvous from the torchrun env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # "nccl" IS RCCL on ROCm
+        if backend == 'nccl':
+            torch.cuda.set_device(local_rank)
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return {'world_size': world, 'rank': rank, 'local_rank': local_rank}
+
+
+class Trainer:
+    def __init__(self, max_steps: int = 100, use_graph: bool = False, device: Optional[torch.device] = None,
+                 flatten: bool = True, log_every_n_steps: int = 0):
+        self.max_steps = max_steps
+        self.use_graph = use_graph
+        self.device = device
+        self.flatten = flatten
+        self.log_every_n_steps = log_every_n_steps
+        self.datamodule = None
+        self.loggers: List = []
+        self.global_step = 0
+        self.flat: Optional[FlatParameters] = None
+        self.exchange: Optional[GradientExchange] = None
+        self.optimizers: List[torch.optim.Optimizer] = []
+        self._graphs = None
+        self._static_loss = None
+
+    # ------------------------------------------------------------------------------------------------------------
+    def setup(self, flow, datamodule):
+        self.datamodule = datamodule
+        flow.trainer = self
+        if self.device is not None:
+            flow.to(self.device)
+        flow.train()
+        configs = flow.configure_optimizers()
+        if self.flatten:
+            self.flat = FlatParameters(flow.parameters())
+            self.exchange = GradientExchange(self.flat)
+            self.exchange.broadcast_parameters(0)
+            extra = {}
+            if self.use_graph and self.flat.flat_param.is_cuda:
+                extra['capturable'] = True
+            if len(configs) != 1:
+                raise ValueError('exactly one trainable plugin expected (ZeroTrajectory has no optimizer)')
+            self.optimizers = [self.flat.rebuild_optimizer(configs[0]['optimizer'], **extra)]
+        else:
+            self.optimizers = [c['optimizer'] for c in configs]
+        return self
+
+    def _zero_grad(self):
+        if self.flat is not None:
+            self.flat.zero_grad()
+        else:
+            for o in self.optimizers:
+                o.zero_grad(set_to_none=True)
+
+    def _forward_backward(self, flow, batch, batch_idx):
+        self._zero_grad()
+        flow.on_train_batch_start(batch, batch_idx)
+        out = flow.training_step(batch, batch_idx)
+        out['loss'].backward()
+        return out['loss'].detach()
+
+    def _optimizer_step(self):
+        for o in self.optimizers:
+            o.step()
+
+    # ------------------------------------------------------------------------------------------------------------
+    def train_step(self, flow, batch, batch_idx: int = 0) -> torch.Tensor:
+        """One optimisation step on ``batch``; returns the (device) loss tensor."""
+        if not self.use_graph:
+            loss = self._forward_backward(flow, batch, batch_idx)
+            if self.exchange is not None:
+                self.exchange.all_reduce_gradients()
+            self._optimizer_step()
+        else:
+            if self._graphs is None:
+                self._capture(flow, batch, batch_idx)
+            g_fb, g_opt = self._graphs
+            g_fb.replay()
+            if g_opt is not None:
+                self.exchange.all_reduce_gradients()
+                g_opt.replay()
+            loss = self._static_loss
+        self.global_step += 1
+        flow.global_step = self.global_step
+        return loss
+
+    def _capture(self, flow, batch, batch_idx):
+        """Capture on the given batch: its tensors become the static input buffers (copy new data into them)."""
+        distributed = self.exchange is not None and self.exchange.enabled
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up outside capture (allocator, lazy inits, autotuning)
+            for _ in range(3):
+                self._forward_backward(flow, batch, batch_idx)
+                if distributed:
+                    self.exchange.all_reduce_gradients()
+                self._optimizer_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g_fb = torch.cuda.CUDAGraph()
+        if distributed:
+            with torch.cuda.graph(g_fb):
+                self._static_loss = self._forward_backward(flow, batch, batch_idx)
+            g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_opt):
+                self._optimizer_step()
+        else:
+            g_opt = None
+            with torch.cuda.graph(g_fb):
+                self._static_loss = self._forward_backward(flow, batch, batch_idx)
+                self._optimizer_step()
+        self._graphs = (g_fb, g_opt)
+
+    def fit(self, flow, datamodule, batches: Optional[Iterable] = None):
+        self.setup(flow, datamodule)
+        device = self.device or flow.device
+        if batches is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            batches = datamodule.train_batches(device, self.max_steps, rank=rank)
+        losses = []
+        for i, batch in enumerate(batches):
+            if i >= self.max_steps:
+                break
+            losses.append(self.train_step(flow, batch, i))
+            if self.log_every_n_steps and (i + 1) % self.log_every_n_steps == 0:
+                flow.check_finite('train')
+        return losses

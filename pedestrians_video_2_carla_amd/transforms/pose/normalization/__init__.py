@@ -1,0 +1,3 @@
+from .extractor import Extractor
+from .normalizer import Normalizer
+from .denormalizer import DeNormalizer

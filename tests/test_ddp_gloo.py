@@ -1,0 +1,91 @@
+"""Data-parallel path on CPU: world_size 2, gloo backend (the N>1 path of bench.py / Trainer without GPUs).
+
+Checks the contract of parallel/flat.py against what DDP would do: after each step every rank holds the same
+parameters, and they equal a single-process run whose loss is the mean of the per-rank losses.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+STEPS = 3
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _make_flow():
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.pose_lifting import LitPoseLiftingFlow
+    from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE
+    from pedestrians_video_2_carla_amd.trainer import seed_everything
+    seed_everything(22742)
+    model = LinearAE(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON)
+    return LitPoseLiftingFlow(movements_model=model, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
+
+
+def _shard(batch, rank, world):
+    frames, targets, meta = batch
+    n = len(frames) // world
+    sl = slice(rank * n, (rank + 1) * n)
+    return frames[sl], {k: v[sl] for k, v in targets.items()}, {k: v[sl] for k, v in meta.items()}
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cpu_backend import StubDataModule, batch_from_oracle, oracle_backend
+    from pedestrians_video_2_carla_amd.trainer import Trainer, init_distributed
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    info = init_distributed('gloo')
+    assert info == {'world_size': world, 'rank': rank, 'local_rank': rank}
+    flow = _make_flow()
+    if rank == 1:       # different initial weights on purpose: the rank-0 broadcast must win
+        with torch.no_grad():
+            for p in flow.parameters():
+                p.add_(1.0)
+    trainer = Trainer(max_steps=STEPS).setup(flow, StubDataModule())
+    assert trainer.exchange.enabled and trainer.exchange.world == world
+    with oracle_backend():
+        for step in range(STEPS):
+            batch = _shard(batch_from_oracle(8, seed=100 + step, missing=0.1), rank, world)
+            trainer.train_step(flow, batch, step)
+    torch.save(trainer.flat.flat_param.detach().clone(), os.path.join(out_dir, f'rank{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_match_single_process_mean_of_losses(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cpu_backend import StubDataModule, batch_from_oracle, oracle_backend
+    from pedestrians_video_2_carla_amd.trainer import Trainer
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    p0, p1 = (torch.load(os.path.join(tmp_path, f'rank{r}.pt')) for r in range(world))
+    assert torch.equal(p0, p1), 'ranks diverged'
+
+    # single process, loss = mean over ranks of the per-rank loss (DDP semantics)
+    flow = _make_flow()
+    trainer = Trainer(max_steps=STEPS).setup(flow, StubDataModule())
+    with oracle_backend():
+        for step in range(STEPS):
+            full = batch_from_oracle(8, seed=100 + step, missing=0.1)
+            trainer.flat.zero_grad()
+            for r in range(world):
+                b = _shard(full, r, world)
+                flow.on_train_batch_start(b, step)
+                (flow.training_step(b, step)['loss'] / world).backward()
+            trainer._optimizer_step()
+    assert torch.allclose(trainer.flat.flat_param, p0, rtol=1e-5, atol=1e-7)
+    assert p0.numel() == 17530                 # LinearAE pose_changes: the 70 120-byte all-reduce payload

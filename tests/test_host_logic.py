@@ -1,0 +1,216 @@
+"""Host-side logic and the C-ABI surface -- CPU only, no compute calls."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------------------------------------ C ABI
+def test_library_loads_and_exports_every_declared_symbol():
+    from pedestrians_video_2_carla_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = _lib.lib()
+    header = open(os.path.join(ROOT, 'include', 'p2c.h')).read()
+    declared = set(re.findall(r'P2C_API[^;(]*?\b(p2c_\w+)\s*\(', header))
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.p2c_version().startswith(b'p2c-hip')
+    assert lib.p2c_pose_head_workspace_floats(256) >= 128 * 3
+
+
+def test_descriptor_layout_matches_the_header(tmp_path):
+    """ctypes mirror vs the C struct: same size and same offset for every field."""
+    from pedestrians_video_2_carla_amd._lib import PoseHeadDesc
+    fields = [f[0] for f in PoseHeadDesc._fields_]
+    src = tmp_path / 'layout.c'
+    body = '\n'.join(f'  printf("{f} %zu\\n", offsetof(p2c_pose_head_desc, {f}));' for f in fields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "p2c.h"\nint main(void) {\n'
+                   '  printf("sizeof %zu\\n", sizeof(p2c_pose_head_desc));\n' + body + '\n  return 0;\n}\n')
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True)
+               .stdout.strip().splitlines())
+    assert int(out['sizeof']) == ctypes.sizeof(PoseHeadDesc)
+    for f in fields:
+        assert int(out[f]) == getattr(PoseHeadDesc, f).offset, f
+
+
+def test_ops_refuse_host_tensors():
+    from pedestrians_video_2_carla_amd import ops, _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    with pytest.raises(_lib.P2CError):
+        ops.pose_head(torch.zeros(1, 2, 26, 6), ops.PoseHeadSpec(), torch.zeros(1, dtype=torch.int32))
+    with pytest.raises(_lib.P2CError):
+        ops.normalize(torch.zeros(2, 26, 2), 'hips_neck')
+
+
+# ----------------------------------------------------------------------------------------------------- skeleton registry
+def test_common_indices_match_reference(golden):
+    from pedestrians_video_2_carla_amd.data.base.skeleton import get_common_indices
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.data.openpose.skeleton import BODY_25_SKELETON, COCO_SKELETON
+    g = golden('common_indices')
+    sk = {'body25': BODY_25_SKELETON, 'coco': COCO_SKELETON, 'carla': CARLA_SKELETON}
+    for a in sk:
+        for b in sk:
+            if a == b:
+                continue
+            o, i = get_common_indices(input_nodes=sk[a], output_nodes=sk[b])
+            assert list(o) == g[f'in_{a}__out_{b}__out_idx'].tolist()
+            assert list(i) == g[f'in_{a}__out_{b}__in_idx'].tolist()
+    assert get_common_indices(CARLA_SKELETON, CARLA_SKELETON) == (slice(None), slice(None))
+    assert CARLA_SKELETON.get_hips_point().value == 1 and CARLA_SKELETON.get_neck_point().value == 8
+    assert len(CARLA_SKELETON) == 26 and len(BODY_25_SKELETON) == 25 and len(COCO_SKELETON) == 18
+
+
+def test_reference_tables_match_reference(golden):
+    from pedestrians_video_2_carla_amd.data.carla import reference as R
+    g = golden('reference_tables')
+    for got, key in ((R.get_relative_tensors()[0], 'rel_loc'), (R.get_relative_tensors()[1], 'rel_rot'),
+                     (R.get_absolute_tensors()[0], 'abs_loc'), (R.get_absolute_tensors()[1], 'abs_rot')):
+        assert torch.allclose(got, g[key], atol=1e-6), key
+    assert torch.allclose(R.get_projections(), g['projections'], rtol=1e-6, atol=1e-4)
+    st = R.skeleton_types_from_meta({'age': ['adult', 'child', 'senior'], 'gender': ['male', 'female', 'neutral']})
+    assert st.tolist() == [1, 2, 0]
+    with pytest.raises(KeyError):      # ControlledPedestrian knows only the four CARLA types
+        R.skeleton_types_from_meta({'age': ['senior'], 'gender': ['male']}, strict=True)
+
+
+# ---------------------------------------------------------------------------------------------------------- model plugins
+def _load(golden, name, cls, **kw):
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    g = golden(name)
+    model = cls(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, **kw).eval()
+    model.load_state_dict({k[4:]: v for k, v in g.items() if k.startswith('sd__')})   # reference checkpoint keys
+    assert sum(p.numel() for p in model.parameters()) == int(g['n_params'])
+    return g, model
+
+
+@pytest.mark.parametrize('otype', ['pose_changes', 'absolute_loc', 'pose_2d'])
+def test_linear_ae_drops_in(golden, otype):
+    from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    g, model = _load(golden, 'model_linear_ae_' + otype, LinearAE, movements_output_type=MT[otype])
+    assert torch.allclose(model(g['frames']), g['out'], atol=1e-6)
+    if otype == 'pose_changes':         # fused format: raw 6-D, orthonormalised later by the pose head
+        from pedestrians_video_2_carla_amd.transforms.rotation_conversions import rotation_6d_to_matrix
+        model.rotation_output_format = 'rotation_6d'
+        y6 = model(g['frames'])
+        assert y6.shape == (4, 16, 26, 6) and torch.allclose(rotation_6d_to_matrix(y6), g['out'], atol=1e-6)
+
+
+def test_seq2seq_embeddings_drops_in(golden):
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2SeqEmbeddings
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    g, model = _load(golden, 'model_seq2seq_embeddings_pose_2d', Seq2SeqEmbeddings, movements_output_type=MT.pose_2d)
+    assert torch.allclose(model(g['frames']), g['out'], atol=1e-5)      # pins the decoder-restarts-from-encoder quirk
+
+
+def test_pose_former_wrapper_window_semantics():
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.movements.pose_former import PoseFormer
+    from pedestrians_video_2_carla_amd.utils.exceptions import NotAvailableException
+
+    class Inner(torch.nn.Module):
+        def forward(self, x):
+            return x[:, 4:5, :, :1].repeat(1, 1, 1, 3) + x.mean(1, keepdim=True)[..., 1:].repeat(1, 1, 1, 3)
+
+    T = 81
+    pf = PoseFormer(clip_length=T, inner_model=Inner(), input_nodes=CARLA_SKELETON)
+    x = torch.randn(2, T, 26, 2)
+    ref = torch.zeros(2, T, 26, 3)
+    for i in range(T - 9 + 1):                      # the reference's loop, pose_former.py:122-125
+        ref[:, i + 4:i + 9 + 4] = Inner()(x[:, i:i + 9])
+    assert torch.allclose(pf(x), ref, atol=1e-6)
+    assert pf.eval_slice == slice(4, 77) and pf.output_type.name == 'absolute_loc'
+    with pytest.raises(NotAvailableException):
+        PoseFormer(clip_length=T, input_nodes=CARLA_SKELETON)
+
+
+# ------------------------------------------------------------------------------------------------------------------ flows
+def _flow(loss_modes, **kw):
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.pose_lifting import LitPoseLiftingFlow
+    from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE
+    model = LinearAE(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON)
+    return LitPoseLiftingFlow(movements_model=model, loss_modes=loss_modes, **kw)
+
+
+def test_loss_mode_resolution_and_hparams():
+    flow = _flow(['loc_2d_3d'])
+    assert [m[0] for m in flow._losses_to_calculate] == ['loc_2d', 'loc_3d', 'loc_2d_3d']   # requirements first
+    assert flow.outputs_key == 'projection_2d_transformed'
+    assert flow.crucial_keys[0] == 'projection_2d_transformed' and 'absolute_pose_loc' in flow.crucial_keys
+    assert flow.hparams['loss_modes'] == ['loc_2d_3d'] and flow.hparams['movements_model_name'] == 'LinearAE'
+    assert flow.hparams['movements_lr'] == 1e-4 and flow.hparams['movements_weight_decay'] == 1e-8
+    assert flow.movements_model.rotation_output_format == 'rotation_6d'
+    opt = flow.configure_optimizers()
+    assert len(opt) == 1 and isinstance(opt[0]['optimizer'], torch.optim.AdamW)              # ZeroTrajectory has none
+    assert _flow(None)._loss_modes[0].name == 'loc_2d'
+    assert _flow(['loc_2d'], transform='none').outputs_key == 'projection_2d'
+    assert set(type(flow).get_available_models()['movements']) >= {'LinearAE', 'Seq2SeqEmbeddings', 'PoseFormer'}
+
+
+def test_flow_without_datamodule_or_gpu_fails_loudly():
+    flow = _flow(['loc_2d_3d'])
+    frames = torch.zeros(2, 4, 26, 2)
+    batch = (frames, {'projection_2d_transformed': frames, 'absolute_pose_loc': torch.zeros(2, 4, 26, 3)},
+             {'age': ['adult', 'child'], 'gender': ['female', 'male']})
+    flow.on_train_batch_start(batch, 0)
+    with pytest.raises(RuntimeError, match='datamodule'):
+        flow.training_step(batch, 0)
+
+    class DM:
+        transform_callable = None
+    flow.attach_datamodule(DM())
+    from pedestrians_video_2_carla_amd._lib import P2CError
+    with pytest.raises(P2CError):                       # CPU tensors: no fallback
+        flow.training_step(batch, 0)
+
+
+def test_get_outputs_contract_and_nan_policy():
+    flow = _flow(['loc_2d_3d'])
+    sliced = {'targets': {}, 'pose_inputs': None}
+    out = flow._get_outputs('train', 2, sliced, {'loc_2d': torch.tensor(1.0), 'loc_2d_3d': torch.tensor(3.0)})
+    assert float(out['loss']) == 3.0 and set(out) == {'loss', 'preds', 'targets'}
+    assert set(out['preds']) >= {'pose_changes', 'world_rot_changes', 'world_loc_changes', 'projection_2d_transformed'}
+    with pytest.raises(RuntimeError, match="Couldn't calculate any loss"):
+        flow._get_outputs('train', 2, sliced, {'loc_2d': torch.tensor(1.0)})
+    strict = _flow(['loc_2d_3d'], strict_nan_check=True)
+    assert not strict._loss_is_usable(torch.tensor(float('nan'))) and strict._loss_is_usable(torch.tensor(1.0))
+    flow.log('train_loss/loc_2d', torch.tensor(float('nan')))
+    with pytest.raises(RuntimeError):
+        flow.check_finite('train')
+
+
+def test_flat_parameters_keep_optimizer_semantics():
+    """AdamW over the single flat tensor == AdamW over the parameter list (element-wise update)."""
+    from pedestrians_video_2_carla_amd.parallel.flat import FlatParameters
+    torch.manual_seed(0)
+    a = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    b = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.ReLU(), torch.nn.Linear(7, 3))
+    b.load_state_dict(a.state_dict())
+    oa = torch.optim.AdamW(a.parameters(), lr=1e-2, weight_decay=1e-2)
+    flat = FlatParameters(b.parameters())
+    ob = flat.rebuild_optimizer(torch.optim.AdamW(b.parameters(), lr=1e-2, weight_decay=1e-2))
+    x = torch.randn(11, 5)
+    for _ in range(5):
+        oa.zero_grad()
+        a(x).pow(2).sum().backward()
+        oa.step()
+        flat.zero_grad()
+        b(x).pow(2).sum().backward()
+        ob.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, atol=1e-6)
+    assert flat.nbytes() == 4 * sum(p.numel() for p in a.parameters())
