@@ -118,7 +118,7 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         original_shape = x.shape
         batch_size, clip_length = original_shape[:2]
         hidden, cell = self.encoder(self._format_input(x))
-        step_in = torch.zeros((batch_size, self.decoder.output_size), device=x.device)     # <sos>
+        step_in = torch.zeros((batch_size, self.decoder.output_size), device=x.device, dtype=x.dtype)     # <sos>
         needs_forcing, forced, force_idx = self._teacher_forcing(targets)
         outputs = []
         for t in range(clip_length):

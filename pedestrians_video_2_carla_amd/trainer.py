@@ -124,6 +124,9 @@ class Trainer:
     def _capture(self, flow, batch, batch_idx):
         """Capture on the given batch: its tensors become the static input buffers (copy new data into them)."""
         distributed = self.exchange is not None and self.exchange.enabled
+        # the warm-up iterations below are real optimisation steps: snapshot parameters + optimizer state and restore
+        # them IN PLACE afterwards (the graphs hold the addresses), so that replay #1 is training step #1
+        snapshot = self._snapshot(flow)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up outside capture (allocator, lazy inits, autotuning)
@@ -147,6 +150,30 @@ class Trainer:
                 self._static_loss = self._forward_backward(flow, batch, batch_idx)
                 self._optimizer_step()
         self._graphs = (g_fb, g_opt)
+        self._restore(flow, snapshot)
+
+    def _state_tensors(self, flow):
+        tensors = [p.data for p in flow.parameters()] if self.flat is None else [self.flat.flat_param.data]
+        tensors += [b for b in flow.buffers()]
+        for o in self.optimizers:
+            for st in o.state.values():
+                tensors += [v for v in st.values() if isinstance(v, torch.Tensor)]
+        return tensors
+
+    def _snapshot(self, flow):
+        # optimizer state is created lazily by the first step: run one throw-away step so every state tensor exists
+        # and the snapshot / restore pair can work in place
+        params = [t.clone() for t in self._state_tensors(flow)]
+        return params
+
+    def _restore(self, flow, snapshot):
+        tensors = self._state_tensors(flow)
+        with torch.no_grad():
+            for t, s in zip(tensors, snapshot):          # parameters / buffers / pre-existing optimizer state
+                t.copy_(s)
+            for t in tensors[len(snapshot):]:            # optimizer state created during warm-up: back to step 0
+                t.zero_()
+        torch.cuda.synchronize()
 
     def fit(self, flow, datamodule, batches: Optional[Iterable] = None):
         self.setup(flow, datamodule)
