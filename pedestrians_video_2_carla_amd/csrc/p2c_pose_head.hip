@@ -33,6 +33,15 @@ __constant__ int c_parent[GROUP] = {IDL, 0, 1, 2, 3, 4, 5, 6, 3, 8, 9, 9, 3, 12,
 // last lane of the subtree rooted at each joint
 __constant__ int c_subtree_end[GROUP] = {25, 25, 15, 15, 7, 7, 7, 7, 11, 11, 10, 11, 15, 15, 15, 15, 20, 20, 20, 20, 20,
                                          25, 25, 25, 25, 25, 26, 27, 28, 29, 30, 31};
+// Tree walk schedule of the forward kinematics (pointer doubling, 3 rounds):
+//   round 1: joints whose parent is the previous lane ("interior" joints of a limb chain) absorb it via DPP row_shr:1;
+//   round 2: every joint composes with the transform of its first not-yet-absorbed ancestor c_anc_r2[j];
+//   round 3: likewise with c_anc_r3[j]; afterwards every path reaches the root (checked on the host).
+constexpr unsigned kInteriorMask = 0x3dee6feu;
+__constant__ int c_anc_r2[GROUP] = {26, 26, 0, 1, 2, 3, 4, 5, 3, 3, 8, 9, 3, 3, 12, 13, 1, 1, 16, 17, 18, 1, 1, 21, 22, 23,
+                                    26, 27, 28, 29, 30, 31};
+__constant__ int c_anc_r3[GROUP] = {26, 26, 26, 26, 0, 1, 2, 3, 1, 1, 3, 3, 1, 1, 3, 3, 26, 26, 1, 1, 16, 26, 26, 1, 1, 21,
+                                    26, 27, 28, 29, 30, 31};
 
 struct V3 {
   float x, y, z;
@@ -107,11 +116,29 @@ __device__ __forceinline__ M3 shfl(const M3 &a, int s) {
   for (int i = 0; i < 9; ++i) c.m[i] = shfl(a.m[i], s);
   return c;
 }
-__device__ __forceinline__ float group_sum(float v) {
-#pragma unroll
-  for (int d = 16; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+// ---- DPP (data-parallel primitives): cross-lane moves executed by the VALU itself, no LDS round trip ---------------
+// dpp_ctrl encodings (GFX9): row_shr:n = 0x110+n, row_bcast15 = 0x142. bound_ctrl=true: lanes without a source read 0.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp0(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+// inclusive prefix sum over the lanes of a 32-lane group (lane order = DFS order of the joints): four shifts inside the
+// 16-lane rows, then lane 15 of the even rows is added to the odd rows (row_mask 0b1010)
+__device__ __forceinline__ float group_prefix(float v) {
+  v += dpp0<0x111>(v);
+  v += dpp0<0x112>(v);
+  v += dpp0<0x114>(v);
+  v += dpp0<0x118>(v);
+  v += dpp0<0x142, 0xA>(v);
   return v;
 }
+// value of lane `j` of this lane's own group, for a wave-uniform j (v_readlane x2 + select)
+__device__ __forceinline__ float group_bcast(float v, int j, bool upper) {
+  float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
+  float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j + 32));
+  return upper ? hi : lo;
+}
+__device__ __forceinline__ float group_sum(float v, bool upper) { return group_bcast(group_prefix(v), 31, upper); }
 __device__ __forceinline__ float group_min(float v) {
 #pragma unroll
   for (int d = 16; d >= 1; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
@@ -122,20 +149,16 @@ __device__ __forceinline__ float group_max(float v) {
   for (int d = 16; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
   return v;
 }
-// inclusive prefix sum over the lanes of a group (lane order = DFS order of the joints)
-__device__ __forceinline__ float group_prefix(float v, int j) {
-#pragma unroll
-  for (int d = 1; d < GROUP; d <<= 1) {
-    float n = __shfl_up(v, d, GROUP);
-    if (j >= d) v += n;
-  }
-  return v;
-}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
   return v;
 }
+
+// 1-ulp hardware reciprocal / square root (v_rcp_f32, v_sqrt_f32): the IEEE-exact division and sqrt sequences cost ~10
+// VALU each and the parity budget is 1e-4 relative
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 __device__ __forceinline__ float nan_to_zero(float v) { return (isfinite(v)) ? v : 0.f; }  // utils/tensors.py:43-53
 
@@ -148,16 +171,16 @@ struct SixD {
 __device__ __forceinline__ M3 rot6d_fwd(const float *y6, SixD &s) {
   s.a1 = v3(y6[0], y6[1], y6[2]);
   s.a2 = v3(y6[3], y6[4], y6[5]);
-  float n1 = sqrtf(dot(s.a1, s.a1));
+  float n1 = fsqrt(dot(s.a1, s.a1));
   s.c1 = n1 > 1e-12f;
   s.n1 = fmaxf(n1, 1e-12f);
-  s.b1 = s.a1 * (1.f / s.n1);
+  s.b1 = s.a1 * frcp(s.n1);
   s.d = dot(s.b1, s.a2);
   V3 u2 = s.a2 - s.b1 * s.d;
-  float n2 = sqrtf(dot(u2, u2));
+  float n2 = fsqrt(dot(u2, u2));
   s.c2 = n2 > 1e-12f;
   s.n2 = fmaxf(n2, 1e-12f);
-  s.b2 = u2 * (1.f / s.n2);
+  s.b2 = u2 * frcp(s.n2);
   V3 b3 = cross(s.b1, s.b2);
   return M3{{s.b1.x, s.b1.y, s.b1.z, s.b2.x, s.b2.y, s.b2.z, b3.x, b3.y, b3.z}};
 }
@@ -166,12 +189,12 @@ __device__ __forceinline__ void rot6d_bwd(const SixD &s, const M3 &g, float *gy6
   V3 g1 = v3(g.m[0], g.m[1], g.m[2]), g2 = v3(g.m[3], g.m[4], g.m[5]), g3 = v3(g.m[6], g.m[7], g.m[8]);
   V3 gb1 = g1 + cross(s.b2, g3);
   V3 gb2 = g2 + cross(g3, s.b1);
-  float r2 = 1.f / s.n2;
+  float r2 = frcp(s.n2);
   V3 gu2 = s.c2 ? (gb2 - s.b2 * dot(s.b2, gb2)) * r2 : gb2 * r2;
   float k = dot(gu2, s.b1);
   V3 ga2 = gu2 - s.b1 * k;
   gb1 = gb1 - gu2 * s.d - s.a2 * k;
-  float r1 = 1.f / s.n1;
+  float r1 = frcp(s.n1);
   V3 ga1 = s.c1 ? (gb1 - s.b1 * dot(s.b1, gb1)) * r1 : gb1 * r1;
   gy6[0] = ga1.x, gy6[1] = ga1.y, gy6[2] = ga1.z, gy6[3] = ga2.x, gy6[4] = ga2.y, gy6[5] = ga2.z;
 }
@@ -180,9 +203,11 @@ __device__ __forceinline__ void rot6d_bwd(const SixD &s, const M3 &g, float *gy6
 struct LaneCtx {
   int lane, j, base, clip;
   bool active;  // real joint of a real clip
-  int anc0, anc1, anc2, sub_end;
+  int anc0, anc1, anc2, sub_end;  // parent lane; round-2 / round-3 ancestors of the FK tree walk
+  bool interior;                  // parent is the previous lane
   int gm2, gm3;
   bool never_masked;
+  bool has2, has3;  // this lane's joint takes part in loc_2d / loc_3d
 };
 
 __device__ __forceinline__ LaneCtx make_lane(const p2c_pose_head_desc &d) {
@@ -193,14 +218,16 @@ __device__ __forceinline__ LaneCtx make_lane(const p2c_pose_head_desc &d) {
   int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   L.clip = wave * 2 + (L.lane >> 5);
   L.active = (L.j < J) && (L.clip < d.B);
-  int p = c_parent[L.j];
-  L.anc0 = p;
-  L.anc1 = c_parent[p];
-  L.anc2 = c_parent[c_parent[L.anc1]];
+  L.anc0 = c_parent[L.j];
+  L.anc1 = c_anc_r2[L.j];
+  L.anc2 = c_anc_r3[L.j];
+  L.interior = (kInteriorMask >> L.j) & 1u;
   L.sub_end = c_subtree_end[L.j];
   L.gm2 = (L.j < J) ? d.gmap2d[L.j] : -1;
   L.gm3 = (L.j < J) ? d.gmap3d[L.j] : -1;
   L.never_masked = (L.j == d.hips_lane);
+  L.has2 = L.active && d.gt2d && L.gm2 >= 0;
+  L.has3 = L.active && d.gt3d && L.gm3 >= 0;
   return L;
 }
 
@@ -208,10 +235,17 @@ __device__ __forceinline__ LaneCtx make_lane(const p2c_pose_head_desc &d) {
 //   abs_rot[j] = rel_rot[j] @ abs_rot[parent], abs_loc[j] = rel_loc[j] @ abs_rot[parent] + abs_loc[parent].
 __device__ __forceinline__ void fk_doubling(const LaneCtx &L, M3 &R, V3 &l) {
   {
-    M3 Ra = shfl(R, L.base + L.anc0);
-    V3 la = shfl(l, L.base + L.anc0);
-    l = vmul(l, Ra) + la;
-    R = mul(R, Ra);
+    // round 1 without LDS: DPP row_shr:1 hands every lane the transform of lane-1
+    M3 Ra;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ra.m[i] = dpp0<0x111>(R.m[i]);
+    V3 la = v3(dpp0<0x111>(l.x), dpp0<0x111>(l.y), dpp0<0x111>(l.z));
+    V3 l1 = vmul(l, Ra) + la;
+    M3 R1 = mul(R, Ra);
+    if (L.interior) {
+      l = l1;
+      R = R1;
+    }
   }
   {
     M3 Ra = shfl(R, L.base + L.anc1);
@@ -220,7 +254,6 @@ __device__ __forceinline__ void fk_doubling(const LaneCtx &L, M3 &R, V3 &l) {
     R = mul(R, Ra);
   }
   {
-    // after two rounds a node has absorbed 4 path nodes; its next unabsorbed ancestor is 4 levels up
     M3 Ra = shfl(R, L.base + L.anc2);
     V3 la = shfl(l, L.base + L.anc2);
     l = vmul(l, Ra) + la;
@@ -245,7 +278,7 @@ struct HeadAcc {
 template <bool BWD>
 __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const LaneCtx &L, int t, V3 x, const World &W,
                                          HeadAcc &acc, float coef2, float coef3, const float *g_abs_ext,
-                                         const float *g_projt_ext) {
+                                         const float *g_projt_ext, const float *gt2v, const float *gt3v) {
   const bool in_slice = (t >= d.t0) && (t < d.t1);
   const size_t frame = (size_t)L.clip * d.T + t;
 
@@ -253,7 +286,7 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
   V3 w = v3(x.y, -x.x, x.z);  // x @ p3d_2_world
   V3 p = W.on ? vmul(w, W.rot) + W.loc : w;
   float Z = d.cam_dist - p.x;
-  float invZ = 1.f / Z;
+  float invZ = frcp(Z);
   float u = d.cam_cx - d.cam_f * p.y * invZ;
   float v = d.cam_cy + d.cam_f * (p.z + d.cam_elev) * invZ;
   if (!L.active) { u = 0.f; v = 0.f; invZ = 0.f; }
@@ -279,20 +312,21 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
   bool missing = false;
   if (tr != P2C_TRANSFORM_NONE) {
     if (tr != P2C_TRANSFORM_BBOX) {  // hips_neck_extractor.py:6-13 (mean over the point tuple)
-      hu = shfl(u, L.base + d.hips_idx[0]);
-      hv = shfl(v, L.base + d.hips_idx[0]);
+      const bool up = L.base != 0;
+      hu = group_bcast(u, d.hips_idx[0], up);
+      hv = group_bcast(v, d.hips_idx[0], up);
       if (d.n_hips == 2) {
-        hu = 0.5f * (hu + shfl(u, L.base + d.hips_idx[1]));
-        hv = 0.5f * (hv + shfl(v, L.base + d.hips_idx[1]));
+        hu = 0.5f * (hu + group_bcast(u, d.hips_idx[1], up));
+        hv = 0.5f * (hv + group_bcast(v, d.hips_idx[1], up));
       }
-      ku = shfl(u, L.base + d.neck_idx[0]);
-      kv = shfl(v, L.base + d.neck_idx[0]);
+      ku = group_bcast(u, d.neck_idx[0], up);
+      kv = group_bcast(v, d.neck_idx[0], up);
       if (d.n_neck == 2) {
-        ku = 0.5f * (ku + shfl(u, L.base + d.neck_idx[1]));
-        kv = 0.5f * (kv + shfl(v, L.base + d.neck_idx[1]));
+        ku = 0.5f * (ku + group_bcast(u, d.neck_idx[1], up));
+        kv = 0.5f * (kv + group_bcast(v, d.neck_idx[1], up));
       }
       float du = ku - hu, dv = kv - hv;
-      hn_scale = sqrtf(fmaf(du, du, dv * dv));  // extractor.py:27-28
+      hn_scale = fsqrt(fmaf(du, du, dv * dv));  // extractor.py:27-28
       su = hu, sv = hv, scale = hn_scale;
     }
     bool need_bb = (tr == P2C_TRANSFORM_BBOX);
@@ -312,7 +346,7 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
       float cu = 0.5f * (minu + maxu), cv = 0.5f * (minv + maxv);
       float top_v = fminf(minv, maxv);
       float dx = cu - cu, dy = top_v - cv;  // literal: inf - inf = nan when every joint is missing
-      bb_scale = sqrtf(fmaf(dx, dx, dy * dy));
+      bb_scale = fsqrt(fmaf(dx, dx, dy * dy));
       if (tr == P2C_TRANSFORM_BBOX) {
         su = cu, sv = cv, scale = bb_scale;
       } else if (use_bb_scale) {
@@ -324,9 +358,9 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
   bool fin_u = true, fin_v = true, keep = true;
   float inv_scale = 1.f;
   if (tr != P2C_TRANSFORM_NONE) {
-    inv_scale = 1.f / scale;
-    nu = (u - su) / scale;  // normalizer.py:24-25
-    nv = (v - sv) / scale;
+    inv_scale = frcp(scale);
+    nu = (u - su) * inv_scale;  // normalizer.py:24-25
+    nv = (v - sv) * inv_scale;
     fin_u = isfinite(nu), fin_v = isfinite(nv);
     nu = fin_u ? nu : 0.f;  // :30
     nv = fin_v ? nv : 0.f;
@@ -349,9 +383,8 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
   V3 gx = v3(0.f, 0.f, 0.f);
   float dnu = 0.f, dnv = 0.f;  // d total / d normalised (u, v)
   if (in_slice) {
-    if (d.gt2d && L.active && L.gm2 >= 0) {
-      const float *g = d.gt2d + (frame * d.gt2d_joints + L.gm2) * d.gt2d_channels;
-      float g0 = g[0], g1 = g[1];
+    if (L.has2) {
+      float g0 = gt2v[0], g1 = gt2v[1];
       bool m = !d.mask_missing_joints || L.never_masked || ((g0 != 0.f) && (g1 != 0.f));  // tensors.py:29-40
       if (m) {
         float e0 = nu - g0, e1 = nv - g1;
@@ -364,9 +397,8 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
         }
       }
     }
-    if (d.gt3d && L.active && L.gm3 >= 0) {
-      const float *g = d.gt3d + (frame * d.gt3d_joints + L.gm3) * 3;
-      float e0 = x.x - g[0], e1 = x.y - g[1], e2 = x.z - g[2];
+    if (L.has3) {
+      float e0 = x.x - gt3v[0], e1 = x.y - gt3v[1], e2 = x.z - gt3v[2];
       if (!BWD)
         acc.sum3 += fmaf(e0, e0, fmaf(e1, e1, e2 * e2));
       else
@@ -394,8 +426,8 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
     bool ok = isfinite(inv_scale) && (scale != 0.f);
     gu = ok ? dnu * inv_scale : 0.f;
     gv = ok ? dnv * inv_scale : 0.f;
-    float Au = group_sum(gu), Av = group_sum(gv);                 // -d/d shift
-    float Cs = group_sum(fmaf(gu, nu, gv * nv));                  // -d/d scale  (n = (p - shift)/scale)
+    float Au = group_sum(gu, L.base != 0), Av = group_sum(gv, L.base != 0);                 // -d/d shift
+    float Cs = group_sum(fmaf(gu, nu, gv * nv), L.base != 0);                  // -d/d scale  (n = (p - shift)/scale)
     float g_scale = -Cs;
     float gsu = -Au, gsv = -Av;                                   // gradient wrt the shift point
     float g_bbs = 0.f;
@@ -405,7 +437,7 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
       g_bbs = g_scale * 0.5748f;
     } else {
       // scale = |neck - hips| (torch.linalg.norm backward; zero norm -> zero gradient)
-      float r = (hn_scale > 0.f) ? g_scale / hn_scale : 0.f;
+      float r = (hn_scale > 0.f) ? g_scale * frcp(hn_scale) : 0.f;
       float gku = r * (ku - hu), gkv = r * (kv - hv);
       gsu -= gku, gsv -= gkv;
       float kn = 1.f / (float)d.n_neck;
@@ -423,7 +455,7 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
       }
       if (tr == P2C_TRANSFORM_BBOX || use_bb_scale) {
         float dy = fminf(minv, maxv) - 0.5f * (minv + maxv);
-        float g_dy = (bb_scale > 0.f) ? g_bbs * dy / bb_scale : 0.f;
+        float g_dy = (bb_scale > 0.f) ? g_bbs * dy * frcp(bb_scale) : 0.f;
         g_minv += 0.5f * g_dy;   // top_v = minv (+g_dy), centre (-g_dy/2 each)
         g_maxv -= 0.5f * g_dy;
       }
@@ -507,6 +539,37 @@ __device__ __forceinline__ void load_y(const float *y, size_t idx, float *dst) {
     for (int i = 0; i < NY; ++i) dst[i] = p[i];
   }
 }
+// everything one lane reads from HBM for one frame; loaded one frame AHEAD of its use (software prefetch: the loads
+// of frame t+1 are in flight while frame t is computed)
+template <int NY>
+struct FrameIn {
+  float y[NY];
+  float g2[2];
+  float g3[3];
+};
+template <int NY>
+__device__ __forceinline__ void load_frame(const p2c_pose_head_desc &d, const LaneCtx &L, int t, FrameIn<NY> &f) {
+  const size_t frame = (size_t)L.clip * d.T + t;
+  if (L.active) {
+    load_y<NY>(d.y, frame * J + L.j, f.y);
+  } else {  // identity rotation / zero location for idle lanes
+#pragma unroll
+    for (int i = 0; i < NY; ++i) f.y[i] = 0.f;
+    if (NY == 6) f.y[0] = 1.f, f.y[4] = 1.f;
+    if (NY == 9) f.y[0] = 1.f, f.y[4] = 1.f, f.y[8] = 1.f;
+  }
+  f.g2[0] = f.g2[1] = 0.f;
+  f.g3[0] = f.g3[1] = f.g3[2] = 0.f;
+  if (L.has2) {
+    const float *g = d.gt2d + (frame * d.gt2d_joints + L.gm2) * d.gt2d_channels;
+    f.g2[0] = g[0], f.g2[1] = g[1];
+  }
+  if (L.has3) {
+    const float *g = d.gt3d + (frame * d.gt3d_joints + L.gm3) * 3;
+    f.g3[0] = g[0], f.g3[1] = g[1], f.g3[2] = g[2];
+  }
+}
+
 __device__ __forceinline__ void store_m3(float *base, size_t idx, const M3 &a) {
   float *p = base + idx * 9;
 #pragma unroll
@@ -540,19 +603,18 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
   W.loc = v3(0.f, 0.f, 0.f);
   HeadAcc acc{0.f, 0.f, 0.f};
 
+  FrameIn<K::NY> cur, nxt;
+  load_frame<K::NY>(d, L, 0, cur);
   for (int t = 0; t < T; ++t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
-    M3 c = identity();
-    if (L.active) {
-      float yv[K::NY];
-      load_y<K::NY>(d.y, jf, yv);
-      if (K::SIXD) {
-        SixD s;
-        c = rot6d_fwd(yv, s);
-      } else {
+    if (t + 1 < T) load_frame<K::NY>(d, L, t + 1, nxt);
+    M3 c;
+    if (K::SIXD) {
+      SixD s;
+      c = rot6d_fwd(cur.y, s);
+    } else {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) c.m[i] = yv[i];
-      }
+      for (int i = 0; i < 9; ++i) c.m[i] = cur.y[i];
     }
     R = K::SCAN ? mul(c, R) : c;  // p3d_pose.py:98-114
     if (L.active) {
@@ -569,7 +631,8 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
     if (L.active && d.out_absolute_pose_rot) store_m3(d.out_absolute_pose_rot, jf, A);
     world_step(d, L, t, W);
     if (W.on) world_store(d, L, t, W);
-    frame_head<false>(d, L, t, x, W, acc, 0.f, 0.f, nullptr, nullptr);
+    frame_head<false>(d, L, t, x, W, acc, 0.f, 0.f, nullptr, nullptr, cur.g2, cur.g3);
+    cur = nxt;
   }
   if (L.active && K::SCAN && d.final_rel_rot) store_m3(d.final_rel_rot, (size_t)L.clip * J + L.j, R);
 
@@ -621,30 +684,29 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
   HeadAcc acc{0.f, 0.f, 0.f};
   M3 carry = zero3();  // change[t+1]^T @ dL/d rel_rot[t+1]
 
+  FrameIn<K::NY> cur, nxt;
+  load_frame<K::NY>(d, L, T - 1, cur);
   for (int t = T - 1; t >= 0; --t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
-    M3 c = identity();
+    if (t > 0) load_frame<K::NY>(d, L, t - 1, nxt);
+    M3 c;
     SixD s;
-    if (L.active) {
-      float yv[K::NY];
-      load_y<K::NY>(d.y, jf, yv);
-      if (K::SIXD) {
-        c = rot6d_fwd(yv, s);
-      } else {
+    if (K::SIXD) {
+      c = rot6d_fwd(cur.y, s);
+    } else {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) c.m[i] = yv[i];
-      }
+      for (int i = 0; i < 9; ++i) c.m[i] = cur.y[i];
     }
     if (!K::SCAN) R = c;
     // ---- forward of this frame ----
     M3 A = R;
     V3 x = l;
     fk_doubling(L, A, x);
-    V3 F = frame_head<true>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext);
+    V3 F = frame_head<true>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
     // ---- FK backward: subtree sums via prefix sums over the DFS-ordered lanes ----
     // SubF[j] = sum of F over subtree(j);  Z[j] = sum over strict descendants m of r_m^T (x) SubF[m],
     // r_m = x_m - x_parent(m);  dL/dA_j = A_j Z_j ;  dL/d rel_rot_j = dL/dA_j @ A_parent^T
-    V3 P = v3(group_prefix(F.x, L.j), group_prefix(F.y, L.j), group_prefix(F.z, L.j));
+    V3 P = v3(group_prefix(F.x), group_prefix(F.y), group_prefix(F.z));
     V3 Pe = shfl(P, L.base + L.sub_end);
     V3 SubF = Pe - (P - F);
     V3 xp = shfl(x, L.base + L.anc0);
@@ -655,7 +717,7 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
     M3 Zm;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      float py = group_prefix(Y.m[i], L.j);
+      float py = group_prefix(Y.m[i]);
       Zm.m[i] = shfl(py, L.base + L.sub_end) - py;
     }
     M3 GR = mulNT(mul(A, Zm), Ap);
@@ -695,6 +757,7 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
       }
       if (d.dloc) W.loc = W.loc - v3(d.dloc[frame * 3 + 0], d.dloc[frame * 3 + 1], d.dloc[frame * 3 + 2]);
     }
+    cur = nxt;
   }
 }
 
@@ -724,32 +787,33 @@ __global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc
   W.loc = v3(0.f, 0.f, 0.f);
   HeadAcc acc{0.f, 0.f, 0.f};
 
+  FrameIn<3> cur, nxt;
+  load_frame<3>(d, L, 0, cur);
   for (int t = 0; t < T; ++t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
-    V3 yin = v3(0.f, 0.f, 0.f);
-    if (L.active) {
-      const float *p = d.y + jf * 3;
-      yin = v3(p[0], p[1], p[2]);
-    }
-    V3 h = shfl(yin, L.base + HIPS), k = shfl(yin, L.base + NECK);
+    if (t + 1 < T) load_frame<3>(d, L, t + 1, nxt);
+    V3 yin = v3(cur.y[0], cur.y[1], cur.y[2]);
+    const bool up = L.base != 0;
+    V3 h = v3(group_bcast(yin.x, HIPS, up), group_bcast(yin.y, HIPS, up), group_bcast(yin.z, HIPS, up));
+    V3 k = v3(group_bcast(yin.x, NECK, up), group_bcast(yin.y, NECK, up), group_bcast(yin.z, NECK, up));
     V3 dk = k - h;
-    float sc = sqrtf(dot(dk, dk));
+    float sc = fsqrt(dot(dk, dk));
+    float inv = frcp(sc);
     V3 q = yin - h;
-    V3 xn = v3(q.x / sc, q.y / sc, q.z / sc);
+    V3 xn = v3(q.x * inv, q.y * inv, q.z * inv);
     bool f0 = isfinite(xn.x), f1 = isfinite(xn.y), f2 = isfinite(xn.z);
     xn = v3(f0 ? xn.x : 0.f, f1 ? xn.y : 0.f, f2 ? xn.z : 0.f);
     V3 x = xn * sref + href;
     world_step(d, L, t, W);
     if (!BWD && W.on) world_store(d, L, t, W);
-    V3 gx = frame_head<BWD>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext);
+    V3 gx = frame_head<BWD>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
     if (BWD) {
-      float inv = 1.f / sc;
       bool ok = isfinite(inv) && sc != 0.f;
       V3 gn = v3(f0 && ok ? gx.x * sref * inv : 0.f, f1 && ok ? gx.y * sref * inv : 0.f,
                  f2 && ok ? gx.z * sref * inv : 0.f);  // d/dq
-      V3 S = v3(group_sum(gn.x), group_sum(gn.y), group_sum(gn.z));
-      float Cs = group_sum(gn.x * xn.x + gn.y * xn.y + gn.z * xn.z);
-      float rr = (sc > 0.f) ? -Cs / sc : 0.f;   // d/d sc  times 1/sc
+      V3 S = v3(group_sum(gn.x, L.base != 0), group_sum(gn.y, L.base != 0), group_sum(gn.z, L.base != 0));
+      float Cs = group_sum(gn.x * xn.x + gn.y * xn.y + gn.z * xn.z, L.base != 0);
+      float rr = (sc > 0.f) ? -Cs * inv : 0.f;   // d/d sc  times 1/sc
       V3 gk = dk * rr;
       V3 gh = v3(-S.x, -S.y, -S.z) - gk;
       V3 gy = gn;
@@ -760,6 +824,7 @@ __global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc
         g[0] = gy.x, g[1] = gy.y, g[2] = gy.z;
       }
     }
+    cur = nxt;
   }
   if (!BWD) {
     float s2 = wave_sum(acc.sum2), c2 = wave_sum(acc.cnt2), s3 = wave_sum(acc.sum3);
@@ -810,7 +875,7 @@ __global__ __launch_bounds__(256) void loss_finalize(const float *partials, int 
 // =====================================================================================================================
 using namespace p2c;
 
-static constexpr int kBlock = 64;  // one wavefront (two clips) per workgroup: no barriers, >= B/2 workgroups
+static constexpr int kBlock = 256;  // four independent wavefronts (two clips each) per workgroup; no barriers
 
 static int validate(const p2c_pose_head_desc *d) {
   if (!d || !d->y || !d->skel_type || !d->partials || !d->loss_sums || !d->losses) return P2C_E_NULL;
