@@ -275,10 +275,14 @@ struct HeadAcc {
   float sum2, cnt2, sum3;
 };
 
-template <bool BWD>
+enum { MODE_FWD = 0, MODE_FWD_MATERIALIZE = 1, MODE_BWD = 2 };
+
+template <int MODE>
 __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const LaneCtx &L, int t, V3 x, const World &W,
                                          HeadAcc &acc, float coef2, float coef3, const float *g_abs_ext,
                                          const float *g_projt_ext, const float *gt2v, const float *gt3v) {
+  constexpr bool BWD = (MODE == MODE_BWD);
+  constexpr bool MAT = (MODE == MODE_FWD_MATERIALIZE);
   const bool in_slice = (t >= d.t0) && (t < d.t1);
   const size_t frame = (size_t)L.clip * d.T + t;
 
@@ -291,7 +295,7 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
   float v = d.cam_cy + d.cam_f * (p.z + d.cam_elev) * invZ;
   if (!L.active) { u = 0.f; v = 0.f; invZ = 0.f; }
 
-  if (!BWD) {
+  if (MAT) {
     if (L.active && d.out_projection_2d) {
       float *o = d.out_projection_2d + (frame * J + L.j) * 3;
       o[0] = u, o[1] = v, o[2] = invZ;
@@ -368,7 +372,7 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
     keep = wch >= d.near_zero;  // :35-37 third channel (1/depth) acts as the confidence
     if (!keep) { nu = 0.f; nv = 0.f; }
   }
-  if (!BWD && tr != P2C_TRANSFORM_NONE && in_slice && L.clip < d.B) {
+  if (MAT && tr != P2C_TRANSFORM_NONE && in_slice && L.clip < d.B) {
     if (L.active && d.out_projection_2d_transformed) {
       float *o = d.out_projection_2d_transformed + (frame * J + L.j) * 3;
       o[0] = nu, o[1] = nv, o[2] = wch;
@@ -547,11 +551,26 @@ struct FrameIn {
   float g2[2];
   float g3[3];
 };
+// per-lane read cursors: computed once, then advanced by one frame (a constant stride) per iteration
+struct FramePtrs {
+  const float *y, *g2, *g3;
+  int sy, s2, s3;  // floats per frame
+};
 template <int NY>
-__device__ __forceinline__ void load_frame(const p2c_pose_head_desc &d, const LaneCtx &L, int t, FrameIn<NY> &f) {
+__device__ __forceinline__ FramePtrs frame_ptrs(const p2c_pose_head_desc &d, const LaneCtx &L, int t) {
+  FramePtrs p;
   const size_t frame = (size_t)L.clip * d.T + t;
+  p.sy = J * NY, p.s2 = d.gt2d_joints * d.gt2d_channels, p.s3 = d.gt3d_joints * 3;
+  p.y = L.active ? d.y + (frame * J + L.j) * NY : nullptr;
+  p.g2 = L.has2 ? d.gt2d + (frame * d.gt2d_joints + L.gm2) * d.gt2d_channels : nullptr;
+  p.g3 = L.has3 ? d.gt3d + (frame * d.gt3d_joints + L.gm3) * 3 : nullptr;
+  return p;
+}
+template <int NY, int DIR>
+__device__ __forceinline__ void load_frame(const LaneCtx &L, FramePtrs &p, FrameIn<NY> &f) {
   if (L.active) {
-    load_y<NY>(d.y, frame * J + L.j, f.y);
+    load_y<NY>(p.y, 0, f.y);
+    p.y += DIR * p.sy;
   } else {  // identity rotation / zero location for idle lanes
 #pragma unroll
     for (int i = 0; i < NY; ++i) f.y[i] = 0.f;
@@ -561,12 +580,12 @@ __device__ __forceinline__ void load_frame(const p2c_pose_head_desc &d, const La
   f.g2[0] = f.g2[1] = 0.f;
   f.g3[0] = f.g3[1] = f.g3[2] = 0.f;
   if (L.has2) {
-    const float *g = d.gt2d + (frame * d.gt2d_joints + L.gm2) * d.gt2d_channels;
-    f.g2[0] = g[0], f.g2[1] = g[1];
+    f.g2[0] = p.g2[0], f.g2[1] = p.g2[1];
+    p.g2 += DIR * p.s2;
   }
   if (L.has3) {
-    const float *g = d.gt3d + (frame * d.gt3d_joints + L.gm3) * 3;
-    f.g3[0] = g[0], f.g3[1] = g[1], f.g3[2] = g[2];
+    f.g3[0] = p.g3[0], f.g3[1] = p.g3[1], f.g3[2] = p.g3[2];
+    p.g3 += DIR * p.s3;
   }
 }
 
@@ -579,7 +598,7 @@ __device__ __forceinline__ void store_m3(float *base, size_t idx, const M3 &a) {
 // =====================================================================================================================
 // forward, rotation kinds (pose_changes / relative_rot; projection.py:144-195)
 // =====================================================================================================================
-template <int KIND>
+template <int KIND, bool MAT>
 __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_desc d) {
   using K = KindTraits<KIND>;
   const LaneCtx L = make_lane(d);
@@ -604,10 +623,11 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
   HeadAcc acc{0.f, 0.f, 0.f};
 
   FrameIn<K::NY> cur, nxt;
-  load_frame<K::NY>(d, L, 0, cur);
+  FramePtrs ptrs = frame_ptrs<K::NY>(d, L, 0);
+  load_frame<K::NY, 1>(L, ptrs, cur);
   for (int t = 0; t < T; ++t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
-    if (t + 1 < T) load_frame<K::NY>(d, L, t + 1, nxt);
+    if (t + 1 < T) load_frame<K::NY, 1>(L, ptrs, nxt);
     M3 c;
     if (K::SIXD) {
       SixD s;
@@ -617,7 +637,7 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
       for (int i = 0; i < 9; ++i) c.m[i] = cur.y[i];
     }
     R = K::SCAN ? mul(c, R) : c;  // p3d_pose.py:98-114
-    if (L.active) {
+    if (MAT && L.active) {
       if (d.out_pose_changes && K::SCAN) store_m3(d.out_pose_changes, jf, c);
       if (d.out_relative_pose_rot) store_m3(d.out_relative_pose_rot, jf, R);
       if (d.out_relative_pose_loc) {
@@ -628,10 +648,10 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
     M3 A = R;
     V3 x = l;
     fk_doubling(L, A, x);
-    if (L.active && d.out_absolute_pose_rot) store_m3(d.out_absolute_pose_rot, jf, A);
+    if (MAT && L.active && d.out_absolute_pose_rot) store_m3(d.out_absolute_pose_rot, jf, A);
     world_step(d, L, t, W);
-    if (W.on) world_store(d, L, t, W);
-    frame_head<false>(d, L, t, x, W, acc, 0.f, 0.f, nullptr, nullptr, cur.g2, cur.g3);
+    if (MAT && W.on) world_store(d, L, t, W);
+    frame_head<MAT ? MODE_FWD_MATERIALIZE : MODE_FWD>(d, L, t, x, W, acc, 0.f, 0.f, nullptr, nullptr, cur.g2, cur.g3);
     cur = nxt;
   }
   if (L.active && K::SCAN && d.final_rel_rot) store_m3(d.final_rel_rot, (size_t)L.clip * J + L.j, R);
@@ -685,10 +705,11 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
   M3 carry = zero3();  // change[t+1]^T @ dL/d rel_rot[t+1]
 
   FrameIn<K::NY> cur, nxt;
-  load_frame<K::NY>(d, L, T - 1, cur);
+  FramePtrs ptrs = frame_ptrs<K::NY>(d, L, T - 1);
+  load_frame<K::NY, -1>(L, ptrs, cur);
   for (int t = T - 1; t >= 0; --t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
-    if (t > 0) load_frame<K::NY>(d, L, t - 1, nxt);
+    if (t > 0) load_frame<K::NY, -1>(L, ptrs, nxt);
     M3 c;
     SixD s;
     if (K::SIXD) {
@@ -702,7 +723,7 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
     M3 A = R;
     V3 x = l;
     fk_doubling(L, A, x);
-    V3 F = frame_head<true>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
+    V3 F = frame_head<MODE_BWD>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
     // ---- FK backward: subtree sums via prefix sums over the DFS-ordered lanes ----
     // SubF[j] = sum of F over subtree(j);  Z[j] = sum over strict descendants m of r_m^T (x) SubF[m],
     // r_m = x_m - x_parent(m);  dL/dA_j = A_j Z_j ;  dL/d rel_rot_j = dL/dA_j @ A_parent^T
@@ -765,10 +786,11 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
 // absolute_loc kind (projection.py:125-136 + reference_skeletons_denormalizer.py:67-91)
 //   x^ = nan_to_zero((y - y[hips]) / |y[neck] - y[hips]|) ;  abs_loc = x^ * s_ref + h_ref
 // =====================================================================================================================
-template <bool BWD>
+template <int MODE>
 __global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc d, const float *grad_losses,
                                                         const float *g_abs_ext, const float *g_projt_ext,
                                                         float *grad_y) {
+  constexpr bool BWD = (MODE == MODE_BWD);
   const LaneCtx L = make_lane(d);
   const int T = d.T;
   constexpr int HIPS = 1, NECK = 8;  // HipsNeckExtractor(CARLA_SKELETON), reference_skeletons_denormalizer.py:37
@@ -788,10 +810,11 @@ __global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc
   HeadAcc acc{0.f, 0.f, 0.f};
 
   FrameIn<3> cur, nxt;
-  load_frame<3>(d, L, 0, cur);
+  FramePtrs ptrs = frame_ptrs<3>(d, L, 0);
+  load_frame<3, 1>(L, ptrs, cur);
   for (int t = 0; t < T; ++t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
-    if (t + 1 < T) load_frame<3>(d, L, t + 1, nxt);
+    if (t + 1 < T) load_frame<3, 1>(L, ptrs, nxt);
     V3 yin = v3(cur.y[0], cur.y[1], cur.y[2]);
     const bool up = L.base != 0;
     V3 h = v3(group_bcast(yin.x, HIPS, up), group_bcast(yin.y, HIPS, up), group_bcast(yin.z, HIPS, up));
@@ -805,8 +828,8 @@ __global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc
     xn = v3(f0 ? xn.x : 0.f, f1 ? xn.y : 0.f, f2 ? xn.z : 0.f);
     V3 x = xn * sref + href;
     world_step(d, L, t, W);
-    if (!BWD && W.on) world_store(d, L, t, W);
-    V3 gx = frame_head<BWD>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
+    if (MODE == MODE_FWD_MATERIALIZE && W.on) world_store(d, L, t, W);
+    V3 gx = frame_head<MODE>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
     if (BWD) {
       bool ok = isfinite(inv) && sc != 0.f;
       V3 gn = v3(f0 && ok ? gx.x * sref * inv : 0.f, f1 && ok ? gx.y * sref * inv : 0.f,
@@ -924,25 +947,27 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
   const p2c_pose_head_desc d = *desc;
   hipStream_t stream = (hipStream_t)stream_;
   dim3 grid(grid_for(d.B)), block(kBlock);
+  const bool mat = d.out_pose_changes || d.out_projection_2d || d.out_projection_2d_transformed || d.out_shift ||
+                   d.out_scale || d.out_relative_pose_loc || d.out_relative_pose_rot || d.out_absolute_pose_loc ||
+                   d.out_absolute_pose_rot || d.out_world_loc || d.out_world_rot;
+  if ((d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_POSE_CHANGES_MAT) && !d.final_rel_rot) return P2C_E_NULL;
+#define P2C_LAUNCH_ROT_FWD(KIND)                                                                  \
+  if (mat) hipLaunchKernelGGL((pose_head_rot_fwd<KIND, true>), grid, block, 0, stream, d);        \
+  else hipLaunchKernelGGL((pose_head_rot_fwd<KIND, false>), grid, block, 0, stream, d)
   switch (d.kind) {
-    case P2C_KIND_POSE_CHANGES_6D:
-      if (!d.final_rel_rot) return P2C_E_NULL;
-      hipLaunchKernelGGL(pose_head_rot_fwd<P2C_KIND_POSE_CHANGES_6D>, grid, block, 0, stream, d);
-      break;
-    case P2C_KIND_POSE_CHANGES_MAT:
-      if (!d.final_rel_rot) return P2C_E_NULL;
-      hipLaunchKernelGGL(pose_head_rot_fwd<P2C_KIND_POSE_CHANGES_MAT>, grid, block, 0, stream, d);
-      break;
-    case P2C_KIND_RELATIVE_ROT_6D:
-      hipLaunchKernelGGL(pose_head_rot_fwd<P2C_KIND_RELATIVE_ROT_6D>, grid, block, 0, stream, d);
-      break;
-    case P2C_KIND_RELATIVE_ROT_MAT:
-      hipLaunchKernelGGL(pose_head_rot_fwd<P2C_KIND_RELATIVE_ROT_MAT>, grid, block, 0, stream, d);
-      break;
+    case P2C_KIND_POSE_CHANGES_6D: P2C_LAUNCH_ROT_FWD(P2C_KIND_POSE_CHANGES_6D); break;
+    case P2C_KIND_POSE_CHANGES_MAT: P2C_LAUNCH_ROT_FWD(P2C_KIND_POSE_CHANGES_MAT); break;
+    case P2C_KIND_RELATIVE_ROT_6D: P2C_LAUNCH_ROT_FWD(P2C_KIND_RELATIVE_ROT_6D); break;
+    case P2C_KIND_RELATIVE_ROT_MAT: P2C_LAUNCH_ROT_FWD(P2C_KIND_RELATIVE_ROT_MAT); break;
     default:
-      hipLaunchKernelGGL(pose_head_absloc<false>, grid, block, 0, stream, d, (const float *)nullptr,
-                         (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
+      if (mat)
+        hipLaunchKernelGGL((pose_head_absloc<MODE_FWD_MATERIALIZE>), grid, block, 0, stream, d, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
+      else
+        hipLaunchKernelGGL((pose_head_absloc<MODE_FWD>), grid, block, 0, stream, d, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
   }
+#undef P2C_LAUNCH_ROT_FWD
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   int n_waves = (int)(grid.x * (kBlock / 64));
@@ -979,7 +1004,7 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *gr
       hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_RELATIVE_ROT_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
       break;
     default:
-      hipLaunchKernelGGL(pose_head_absloc<true>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+      hipLaunchKernelGGL((pose_head_absloc<MODE_BWD>), grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
