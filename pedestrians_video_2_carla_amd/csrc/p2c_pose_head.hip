@@ -783,6 +783,127 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
 }
 
 // =====================================================================================================================
+// backward for the 6-D kinds in the tangent space of SO(3) ("rigid body" form; derivation + fp64 check against autograd
+// in tools/proto_bwd_math.py). With F_m = dL/d abs_loc_m:
+//   world torque about joint j      tau_j  = sum_{m in subtree(j)} F_m x (x_m - x_j) = Sub(F x x)_j - Sub(F)_j x x_j
+//   in the right-tangent of rel_rot tau'_j = tau_j A_parent^T = tau_j A_j^T R_j            (A_j = R_j A_parent)
+//   rel_rot[t] = change[t] rel_rot[t-1]: a right-perturbation eps of change[s] turns every rel_rot[t], t >= s, by the
+//   SAME vector eps rel_rot[s-1]  ->  g_s = (sum_{t>=s} tau'_t) rel_rot[s-1]^T : the time scan is a plain suffix sum
+//   6-D pull-back of the tangent gradient g (G = 1/2 rows(c) x g), closed form in the Gram-Schmidt basis (b1,b2,b3):
+//   d/da1 = ((g.b2 + (g.b1) d/n2) b3 - (g.b3) b2) / n1 ,  d/da2 = -(g.b1)/n2 b3
+// Two prefix sums of 3-vectors replace the twelve of the matrix form; nothing 3x3 is carried between frames.
+// =====================================================================================================================
+#ifndef P2C_BWD_WAVES
+#define P2C_BWD_WAVES 1
+#endif
+template <int KIND>
+__global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(const p2c_pose_head_desc d, const float *grad_losses,
+                                                                 const float *g_abs_ext, const float *g_projt_ext,
+                                                                 float *grad_y) {
+  using K = KindTraits<KIND>;
+  static_assert(K::SIXD, "tangent-space backward is for the 6-D kinds");
+  const LaneCtx L = make_lane(d);
+  const int T = d.T;
+
+  V3 l = v3(0.f, 0.f, 0.f);
+  M3 Rref = identity(), R = identity();
+  if (L.active) {
+    int st = d.skel_type[L.clip];
+    const float *pl = d.ref_rel_loc + ((size_t)st * J + L.j) * 3;
+    l = v3(pl[0], pl[1], pl[2]);
+    if (K::SCAN) {
+      const float *pr = d.ref_rel_rot + ((size_t)st * J + L.j) * 9;
+      const float *pf = d.final_rel_rot + ((size_t)L.clip * J + L.j) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rref.m[i] = pr[i], R.m[i] = pf[i];
+    }
+  }
+  float coef2 = 0.f, coef3 = 0.f;
+  loss_coefs(d, grad_losses, coef2, coef3);
+
+  World W;
+  W.on = (d.dloc != nullptr) || (d.drot != nullptr);
+  W.rot = identity();
+  W.loc = v3(0.f, 0.f, 0.f);
+  if (W.on) {
+    if (d.world_absolute) world_step(d, L, T - 1, W);
+    else
+      for (int t = 0; t < T; ++t) world_step(d, L, t, W);
+  }
+
+  HeadAcc acc{0.f, 0.f, 0.f};
+  V3 S = v3(0.f, 0.f, 0.f);  // suffix sum over time of the parent-frame torques
+
+  FrameIn<6> cur, nxt;
+  FramePtrs ptrs = frame_ptrs<6>(d, L, T - 1);
+  load_frame<6, -1>(L, ptrs, cur);
+  float *gy = L.active ? grad_y + (((size_t)L.clip * T + (T - 1)) * J + L.j) * 6 : nullptr;
+  for (int t = T - 1; t >= 0; --t) {
+    if (t > 0) load_frame<6, -1>(L, ptrs, nxt);
+    SixD s;
+    M3 c = rot6d_fwd(cur.y, s);
+    if (!K::SCAN) R = c;
+    M3 A = R;
+    V3 x = l;
+    fk_doubling(L, A, x);
+    V3 F = frame_head<MODE_BWD>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
+    // subtree sums of F and F x x through prefix sums over the DFS-ordered lanes
+    V3 FX = cross(F, x);
+    V3 PF = v3(group_prefix(F.x), group_prefix(F.y), group_prefix(F.z));
+    V3 PX = v3(group_prefix(FX.x), group_prefix(FX.y), group_prefix(FX.z));
+    V3 SubF = shfl(PF, L.base + L.sub_end) - (PF - F);
+    V3 SubX = shfl(PX, L.base + L.sub_end) - (PX - FX);
+    V3 tau = SubX - cross(SubF, x);
+    V3 taup = vmul(vmulT(tau, A), R);  // tau A^T R
+    V3 g;
+    if (K::SCAN) {
+      S = S + taup;
+      M3 Rprev = (t > 0) ? mulTN(c, R) : Rref;  // change is a rotation: rel_rot[t-1] = change^T rel_rot[t]
+      g = vmulT(S, Rprev);
+      R = Rprev;
+    } else {
+      g = taup;
+    }
+    if (L.active) {
+      float gy6[6];
+      if (s.c1 && s.c2) {
+        V3 b3 = v3(c.m[6], c.m[7], c.m[8]);
+        float al = dot(g, s.b1), be = dot(g, s.b2), ga = dot(g, b3);
+        float r1 = frcp(s.n1), r2 = frcp(s.n2);
+        float k3 = (be + al * s.d * r2) * r1, k2 = -ga * r1, k5 = -al * r2;
+        gy6[0] = fmaf(k3, b3.x, k2 * s.b2.x), gy6[1] = fmaf(k3, b3.y, k2 * s.b2.y), gy6[2] = fmaf(k3, b3.z, k2 * s.b2.z);
+        gy6[3] = k5 * b3.x, gy6[4] = k5 * b3.y, gy6[5] = k5 * b3.z;
+      } else {  // a norm sits on the 1e-12 clamp: generic chain rule through the Gram-Schmidt steps
+        M3 G;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          V3 ci = v3(c.m[i * 3], c.m[i * 3 + 1], c.m[i * 3 + 2]);
+          V3 h = cross(ci, g) * 0.5f;
+          G.m[i * 3] = h.x, G.m[i * 3 + 1] = h.y, G.m[i * 3 + 2] = h.z;
+        }
+        rot6d_bwd(s, G, gy6);
+      }
+      float2 *q = reinterpret_cast<float2 *>(gy);
+      q[0] = make_float2(gy6[0], gy6[1]), q[1] = make_float2(gy6[2], gy6[3]), q[2] = make_float2(gy6[4], gy6[5]);
+      gy -= J * 6;
+    }
+    if (W.on && t > 0 && d.world_absolute) {
+      world_step(d, L, t - 1, W);
+    } else if (W.on && t > 0 && L.clip < d.B) {
+      size_t frame = (size_t)L.clip * T + t;
+      if (d.drot) {
+        M3 dr;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dr.m[i] = d.drot[frame * 9 + i];
+        W.rot = mulNT(W.rot, dr);
+      }
+      if (d.dloc) W.loc = W.loc - v3(d.dloc[frame * 3 + 0], d.dloc[frame * 3 + 1], d.dloc[frame * 3 + 2]);
+    }
+    cur = nxt;
+  }
+}
+
+// =====================================================================================================================
 // absolute_loc kind (projection.py:125-136 + reference_skeletons_denormalizer.py:67-91)
 //   x^ = nan_to_zero((y - y[hips]) / |y[neck] - y[hips]|) ;  abs_loc = x^ * s_ref + h_ref
 // =====================================================================================================================
@@ -991,14 +1112,14 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *gr
   switch (d.kind) {
     case P2C_KIND_POSE_CHANGES_6D:
       if (!d.final_rel_rot) return P2C_E_NULL;
-      hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_POSE_CHANGES_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+      hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_POSE_CHANGES_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
       break;
     case P2C_KIND_POSE_CHANGES_MAT:
       if (!d.final_rel_rot) return P2C_E_NULL;
       hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_POSE_CHANGES_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
       break;
     case P2C_KIND_RELATIVE_ROT_6D:
-      hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_RELATIVE_ROT_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+      hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_RELATIVE_ROT_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
       break;
     case P2C_KIND_RELATIVE_ROT_MAT:
       hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_RELATIVE_ROT_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);

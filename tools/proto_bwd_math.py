@@ -87,3 +87,38 @@ with torch.no_grad():
         Mr = Mr @ Ar
         anc = [anc[a] for a in anc]
     print('doubling FK err rot %.2e loc %.2e' % ((Mr[:, :J] - A[:, 2]).abs().max(), (Ml[:, :J] - x[:, 2]).abs().max()))
+
+# ---- tangent-space ("rigid body") backward: torques instead of 3x3 matrix adjoints ----
+with torch.no_grad():
+    gy2 = torch.zeros_like(y)
+    S = torch.zeros(B, J, 3, dtype=dt)                      # suffix sum over time of parent-frame torques
+    Rt = R[:, T - 1].clone()
+    for t in reversed(range(T)):
+        At, xt, Ft = A[:, t], x[:, t], F[:, t]
+        FX = torch.cross(Ft, xt, dim=-1)
+        P = torch.cumsum(torch.cat((Ft, FX), -1), 1)
+        Pm1 = torch.cat((torch.zeros(B, 1, 6, dtype=dt), P[:, :-1]), 1)
+        Sub = P[:, end] - Pm1
+        SubF, SubFX = Sub[..., :3], Sub[..., 3:]
+        tau = SubFX - torch.cross(SubF, xt, dim=-1)           # world-frame torque about joint j
+        ct = c[:, t]
+        Rprev = ct.transpose(-1, -2) @ Rt if t > 0 else Rref
+        # parent-frame torque: tau @ A_p^T with A_p^T = A^T R   (A = R A_p, R orthonormal)
+        taup = ((tau[..., None, :] @ At.transpose(-1, -2)) @ Rt)[..., 0, :]
+        S = S + taup
+        g = (S[..., None, :] @ Rprev.transpose(-1, -2))[..., 0, :]      # gradient in the right-tangent of c_t
+        G = 0.5 * torch.cross(ct, g[..., None, :].expand_as(ct), dim=-1)  # rows: (c_i x g) / 2
+        Rt = Rprev
+        a1, a2 = y.detach()[:, t, :, :3], y.detach()[:, t, :, 3:]
+        n1 = a1.norm(dim=-1, keepdim=True); b1 = a1 / n1
+        d = (b1 * a2).sum(-1, keepdim=True); u2 = a2 - d * b1
+        n2 = u2.norm(dim=-1, keepdim=True); b2 = u2 / n2
+        g1, g2, g3 = G[..., 0, :], G[..., 1, :], G[..., 2, :]
+        gb1 = g1 + torch.cross(b2, g3, dim=-1)
+        gb2 = g2 + torch.cross(g3, b1, dim=-1)
+        gu2 = (gb2 - b2 * (b2 * gb2).sum(-1, keepdim=True)) / n2
+        ga2 = gu2 - b1 * (b1 * gu2).sum(-1, keepdim=True)
+        gb1 = gb1 - d * gu2 - (gu2 * b1).sum(-1, keepdim=True) * a2
+        ga1 = (gb1 - b1 * (b1 * gb1).sum(-1, keepdim=True)) / n1
+        gy2[:, t] = torch.cat((ga1, ga2), -1)
+print('tangent-space backward, max rel err vs autograd: %.3e' % ((gy2 - g_ref).abs().max() / g_ref.abs().max()))
