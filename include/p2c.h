@@ -17,6 +17,7 @@
  *   p2c_normalize_fwd / _bwd   transforms/pose/normalization/normalizer.py:20-41 stand-alone (any skeleton)
  *   p2c_loss2d_fwd / _bwd      loss/base_pose_loss.py:36-66 + loss/loc_2d.py:69-89 (autoencoder flow)
  *   p2c_remap_nodes            data/base/base_dataset.py:156-167 (_get_common_tensor, zero-filled joint scatter)
+ *   p2c_mlp_fwd / _bwd         modules/movements/linear_ae/linear_ae.py:25-59 (the six nn.Linear + ReLU of LinearAE)
  *
  * Conventions: every pointer is a DEVICE pointer unless named host_*; tensors are dense row-major fp32; `stream` is a
  * hipStream_t passed as void*; nothing is allocated, freed or synchronised inside; no exception crosses the ABI.
@@ -144,6 +145,29 @@ P2C_API int p2c_loss2d_bwd(const float *pred, const float *gt, int64_t N, int32_
 /* Zero-filled joint remap: dst[n, dst_idx[k], :] = src[n, src_idx[k], :], every other dst joint = 0. */
 P2C_API int p2c_remap_nodes(const float *src, float *dst, int64_t N, int32_t Jsrc, int32_t Jdst, int32_t C, int32_t K,
                     const int32_t *host_src_idx, const int32_t *host_dst_idx, void *stream);
+
+/* ---- fused small MLP (LinearAE: modules/movements/linear_ae/linear_ae.py:25-59) on fp32 MFMA -------------------------
+ * y = W_{L-1} relu( ... relu(W_0 x + b_0) ... ) + b_{L-1} over N rows; dims[l] -> dims[l+1], every width <= 159.
+ * Forward: x (N,dims[0]) -> y (N,dims[L]). Backward (activations recomputed): gy (N,dims[L]) -> gW[l] (dims[l+1],dims[l]),
+ * gb[l] (dims[l+1]) -- WRITTEN, not accumulated -- through `partials` (p2c_mlp_workspace_floats floats) and a fixed-order
+ * reduction (bitwise reproducible). x receives no gradient (the flows feed data). */
+#define P2C_MLP_MAX_LAYERS 8
+typedef struct p2c_mlp_desc {
+  int32_t n_layers;
+  int32_t dims[P2C_MLP_MAX_LAYERS + 1];
+  int64_t N;
+  const float *x;
+  const float *W[P2C_MLP_MAX_LAYERS];   /* row-major (out, in), as nn.Linear.weight */
+  const float *b[P2C_MLP_MAX_LAYERS];
+  float *y;                             /* forward output */
+  const float *gy;                      /* backward input */
+  float *gW[P2C_MLP_MAX_LAYERS];
+  float *gb[P2C_MLP_MAX_LAYERS];
+  float *partials;
+} p2c_mlp_desc;
+P2C_API int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *desc);
+P2C_API int p2c_mlp_fwd(const p2c_mlp_desc *desc, void *stream);
+P2C_API int p2c_mlp_bwd(const p2c_mlp_desc *desc, void *stream);
 
 #ifdef __cplusplus
 }

@@ -38,6 +38,18 @@ class PoseHeadDesc(ctypes.Structure):
     ]
 
 
+P2C_MLP_MAX_LAYERS = 8
+
+
+class MlpDesc(ctypes.Structure):
+    """Mirror of ``p2c_mlp_desc`` (include/p2c.h)."""
+    _fields_ = [
+        ('n_layers', _i32), ('dims', _i32 * (P2C_MLP_MAX_LAYERS + 1)), ('N', ctypes.c_int64), ('x', _f32p),
+        ('W', _f32p * P2C_MLP_MAX_LAYERS), ('b', _f32p * P2C_MLP_MAX_LAYERS), ('y', _f32p), ('gy', _f32p),
+        ('gW', _f32p * P2C_MLP_MAX_LAYERS), ('gb', _f32p * P2C_MLP_MAX_LAYERS), ('partials', _f32p),
+    ]
+
+
 # every symbol include/p2c.h declares: (restype, argtypes)
 _vp, _i64, _ip = ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)
 SYMBOLS = {
@@ -55,6 +67,9 @@ SYMBOLS = {
     'p2c_loss2d_bwd': (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _i32, _vp, _vp,
                                       _vp, _vp]),
     'p2c_remap_nodes': (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _ip, _ip, _vp]),
+    'p2c_mlp_workspace_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
+    'p2c_mlp_fwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
+    'p2c_mlp_bwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
 }
 
 _lib = None

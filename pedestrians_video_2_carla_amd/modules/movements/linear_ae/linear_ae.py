@@ -3,7 +3,12 @@
 Per-frame MLP 2P -> P -> P/2 -> P/4 -> O/4 -> O/2 -> O with ReLU between (P = input joints * 2, O = output joints *
 output_features). Attribute names are kept (``__encoder`` / ``__decoder`` inside class ``LinearAE``) so state_dict keys
 (``_LinearAE__encoder.0.weight`` ...) match reference checkpoints.
+
+On the GPU the six Linear(+ReLU) layers run as ONE fp32-MFMA kernel forward and one backward (csrc/p2c_mlp.hip,
+``ops.fused_mlp``) instead of ~50 ATen launches; ``fused_mlp=False`` (or host tensors, which the plugin still accepts for
+checkpoint / golden-vector work) uses the plain ``nn.Sequential``. Both paths compute the same fp32 function.
 """
+import torch
 from torch import nn
 
 from pedestrians_video_2_carla_amd.modules.movements.movements import MovementsModel, MovementsModelOutputTypeMixin
@@ -19,8 +24,10 @@ def _mlp(sizes, last_activation):
 
 
 class LinearAE(MovementsModelOutputTypeMixin, MovementsModel):
-    def __init__(self, **kwargs):
+    def __init__(self, fused_mlp: bool = True, **kwargs):
         super().__init__(**kwargs)
+        self.fused_mlp = fused_mlp
+        self.grad_sink = False          # set by the trainer: write parameter gradients straight into .grad
         self.__n_out = len(self.output_nodes)
         self.__in = len(self.input_nodes) * 2                  # (x, y) per joint
         out = self.__n_out * self.output_features
@@ -33,7 +40,20 @@ class LinearAE(MovementsModelOutputTypeMixin, MovementsModel):
         MovementsModelOutputTypeMixin.add_cli_args(parent_parser.add_argument_group('LinearAE Model'))
         return parent_parser
 
+    def _linears(self):
+        return [m for m in list(self.__encoder) + list(self.__decoder) if isinstance(m, nn.Linear)]
+
     def forward(self, x, *args, **kwargs):
         lead = x.shape[0:2]
-        h = self.__decoder(self.__encoder(x.view((-1, self.__in))))
+        flat = x.reshape((-1, self.__in))
+        if self.fused_mlp and flat.is_cuda and flat.dtype == torch.float32:
+            from pedestrians_video_2_carla_amd import ops
+            layers = self._linears()
+            if ops.mlp_supported([self.__in] + [m.out_features for m in layers]):
+                sinks = None
+                if self.grad_sink and torch.is_grad_enabled() and all(m.weight.grad is not None for m in layers):
+                    sinks = [g for m in layers for g in (m.weight.grad, m.bias.grad)]
+                h = ops.fused_mlp(flat, [m.weight for m in layers], [m.bias for m in layers], sinks)
+                return self._format_output(h.view(*lead, self.__n_out, self.output_features))
+        h = self.__decoder(self.__encoder(flat))
         return self._format_output(h.view(*lead, self.__n_out, self.output_features))

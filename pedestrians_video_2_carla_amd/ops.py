@@ -341,3 +341,83 @@ def remap_nodes(src: Tensor, n_dst_joints: int, src_idx: Sequence[int], dst_idx:
         _lib.check(lib.p2c_remap_nodes(src.data_ptr(), dst.data_ptr(), N, Js, n_dst_joints, C, len(src_idx),
                                        _iarr(src_idx), _iarr(dst_idx), _stream()), 'p2c_remap_nodes')
     return dst
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# fused small MLP (LinearAE) on fp32 MFMA
+# ----------------------------------------------------------------------------------------------------------------------
+def _mlp_desc(x, weights, biases):
+    from pedestrians_video_2_carla_amd._lib import MlpDesc, P2C_MLP_MAX_LAYERS
+    n = len(weights)
+    if not 1 <= n <= P2C_MLP_MAX_LAYERS:
+        raise RuntimeError(f'fused MLP supports 1..{P2C_MLP_MAX_LAYERS} layers, got {n}')
+    d = MlpDesc()
+    d.n_layers = n
+    d.dims[0] = weights[0].shape[1]
+    for l, (w, b) in enumerate(zip(weights, biases)):
+        if w.shape[1] != d.dims[l] or b.shape[0] != w.shape[0]:
+            raise RuntimeError('layer shapes do not chain')
+        d.dims[l + 1] = w.shape[0]
+        d.W[l], d.b[l] = w.data_ptr(), b.data_ptr()
+    d.N = x.shape[0]
+    d.x = x.data_ptr()
+    return d
+
+
+def mlp_supported(dims: Sequence[int]) -> bool:
+    """Widths the kernel handles: every layer < 160 wide and at most 96 16x16 weight-gradient tiles."""
+    tiles = sum(((o + 15) // 16) * ((i + 1 + 15) // 16) for i, o in zip(dims[:-1], dims[1:]))
+    return len(dims) - 1 <= 8 and max(dims) < 160 and tiles <= 96
+
+
+class FusedMLPFunction(torch.autograd.Function):
+    """y = Linear_{L-1}(relu(... relu(Linear_0(x)))) in one launch; backward recomputes activations.
+
+    ``sinks``: optional list [gW_0, gb_0, gW_1, ...] of pre-existing gradient tensors (e.g. views of the trainer's flat
+    gradient buffer). When given, the backward WRITES the parameter gradients there and returns no gradient tensors --
+    no per-parameter accumulate kernels, no zero_grad memset -- valid when this op is the parameters' only use in the
+    step (true for the flows here; do not combine with gradient accumulation)."""
+
+    @staticmethod
+    def forward(ctx, x, n_layers, sinks, *params):
+        lib = _lib.lib()
+        x = _require_device(x, 'x')
+        weights = [_require_device(p, 'weight') for p in params[:n_layers]]
+        biases = [_require_device(p, 'bias') for p in params[n_layers:]]
+        desc = _mlp_desc(x, weights, biases)
+        y = torch.empty(x.shape[0], weights[-1].shape[0], dtype=torch.float32, device=x.device)
+        desc.y = y.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.p2c_mlp_fwd(ctypes.byref(desc), _stream()), 'p2c_mlp_fwd')
+        ctx.save_for_backward(x, *weights, *biases)
+        ctx.n_layers, ctx.sinks = n_layers, sinks
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        n = ctx.n_layers
+        x, *rest = ctx.saved_tensors
+        weights, biases = rest[:n], rest[n:]
+        gy = _require_device(gy, 'grad')
+        desc = _mlp_desc(x, weights, biases)
+        desc.gy = gy.data_ptr()
+        if ctx.sinks is not None:
+            gws, gbs = ctx.sinks[0::2], ctx.sinks[1::2]
+        else:
+            gws = [torch.empty_like(w) for w in weights]
+            gbs = [torch.empty_like(b) for b in biases]
+        for l in range(n):
+            desc.gW[l], desc.gb[l] = gws[l].data_ptr(), gbs[l].data_ptr()
+        partials = torch.empty(lib.p2c_mlp_workspace_floats(ctypes.byref(desc)), dtype=torch.float32, device=x.device)
+        desc.partials = partials.data_ptr()
+        with torch.cuda.device(x.device):
+            _lib.check(lib.p2c_mlp_bwd(ctypes.byref(desc), _stream()), 'p2c_mlp_bwd')
+        if ctx.sinks is not None:
+            return (None, None, None) + (None,) * (2 * n)
+        return (None, None, None, *gws, *gbs)
+
+
+def fused_mlp(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor],
+              sinks: Optional[Sequence[Tensor]] = None) -> Tensor:
+    return FusedMLPFunction.apply(x, len(weights), None if sinks is None else list(sinks), *weights, *biases)

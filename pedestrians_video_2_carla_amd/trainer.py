@@ -73,8 +73,13 @@ class Trainer:
             self.exchange = GradientExchange(self.flat)
             self.exchange.broadcast_parameters(0)
             extra = {}
-            if self.use_graph and self.flat.flat_param.is_cuda:
-                extra['capturable'] = True
+            if self.flat.flat_param.is_cuda:
+                extra['fused'] = True              # one kernel for the whole (flat) parameter
+                extra['capturable'] = bool(self.use_graph)
+                # plugins with a fused backward write their parameter gradients straight into the flat buffer
+                for m in flow.modules():
+                    if hasattr(m, 'grad_sink'):
+                        m.grad_sink = True
             if len(configs) != 1:
                 raise ValueError('exactly one trainable plugin expected (ZeroTrajectory has no optimizer)')
             self.optimizers = [self.flat.rebuild_optimizer(configs[0]['optimizer'], **extra)]

@@ -1,0 +1,74 @@
+"""GPU: fused fp32-MFMA MLP (LinearAE) against the plain nn.Sequential evaluated in fp64."""
+import copy
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, what, rtol=2e-5):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale, err = b.abs().max().item(), (a - b).abs().max().item()
+    assert a.shape == b.shape and math.isfinite(err) and err <= rtol * scale + 1e-30, \
+        f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+@pytest.mark.parametrize('otype', ['pose_changes', 'absolute_loc', 'pose_2d'])
+@pytest.mark.parametrize('B,T', [(1, 1), (3, 5), (16, 16), (37, 7), (256, 16)])
+def test_fused_linear_ae_matches_sequential(otype, B, T):
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE
+    d = torch.device('cuda:0')
+    torch.manual_seed(B * 31 + T)
+    model = LinearAE(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT[otype]).to(d)
+    model.rotation_output_format = 'rotation_6d'
+    ref = copy.deepcopy(model).double()
+    ref.fused_mlp = False
+    x = torch.randn(B, T, 26, 2, device=d)
+    w = torch.randn(B, T, 26, model.output_features, device=d)
+    y = model(x)
+    (y * w).sum().backward()
+    yr = ref(x.double())
+    (yr * w.double()).sum().backward()
+    close(y, yr, 'forward')
+    for (n, p), q in zip(model.named_parameters(), ref.parameters()):
+        close(p.grad, q.grad, n)
+    # gradient sink: same numbers written straight into pre-existing .grad tensors, bitwise reproducible
+    g1 = [p.grad.clone() for p in model.parameters()]
+    model.grad_sink = True
+    for p in model.parameters():
+        p.grad.fill_(123.0)
+    (model(x) * w).sum().backward()
+    for a, p in zip(g1, model.parameters()):
+        assert torch.equal(a, p.grad)
+
+
+def test_fused_mlp_other_widths():
+    """BODY_25 input (50 features) and an odd stack, through ops.fused_mlp directly."""
+    from pedestrians_video_2_carla_amd import ops
+    d = torch.device('cuda:0')
+    torch.manual_seed(0)
+    for dims in ([50, 25, 12, 6, 39, 78, 156], [7, 33, 5], [52, 159]):
+        assert ops.mlp_supported(dims)
+        layers = [torch.nn.Linear(i, o) for i, o in zip(dims[:-1], dims[1:])]
+        seq = []
+        for i, l in enumerate(layers):
+            seq.append(l)
+            if i < len(layers) - 1:
+                seq.append(torch.nn.ReLU())
+        seq = torch.nn.Sequential(*seq).to(d)
+        ref = copy.deepcopy(seq).double()
+        x = torch.randn(101, dims[0], device=d)
+        w = torch.randn(101, dims[-1], device=d)
+        lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+        y = ops.fused_mlp(x, [m.weight for m in lin], [m.bias for m in lin])
+        (y * w).sum().backward()
+        yr = ref(x.double())
+        (yr * w.double()).sum().backward()
+        close(y, yr, f'forward {dims}')
+        for p, q in zip(seq.parameters(), ref.parameters()):
+            close(p.grad, q.grad, f'grad {dims}')
+    assert not ops.mlp_supported([52, 200, 10])
