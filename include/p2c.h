@@ -163,8 +163,11 @@ typedef struct p2c_mlp_desc {
   const float *gy;                      /* backward input */
   float *gW[P2C_MLP_MAX_LAYERS];
   float *gb[P2C_MLP_MAX_LAYERS];
-  float *partials;
+  float *partials;                      /* backward workspace, p2c_mlp_workspace_floats floats */
+  float *w_image;                       /* p2c_mlp_image_floats floats: packed weights, WRITTEN by p2c_mlp_fwd and
+                                           read by p2c_mlp_bwd (same weights: call bwd before the optimizer) */
 } p2c_mlp_desc;
+P2C_API int64_t p2c_mlp_image_floats(const p2c_mlp_desc *desc);
 P2C_API int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *desc);
 P2C_API int p2c_mlp_fwd(const p2c_mlp_desc *desc, void *stream);
 P2C_API int p2c_mlp_bwd(const p2c_mlp_desc *desc, void *stream);

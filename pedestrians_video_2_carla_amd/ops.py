@@ -386,10 +386,11 @@ class FusedMLPFunction(torch.autograd.Function):
         biases = [_require_device(p, 'bias') for p in params[n_layers:]]
         desc = _mlp_desc(x, weights, biases)
         y = torch.empty(x.shape[0], weights[-1].shape[0], dtype=torch.float32, device=x.device)
-        desc.y = y.data_ptr()
+        image = torch.empty(lib.p2c_mlp_image_floats(ctypes.byref(desc)), dtype=torch.float32, device=x.device)
+        desc.y, desc.w_image = y.data_ptr(), image.data_ptr()
         with torch.cuda.device(x.device):
             _lib.check(lib.p2c_mlp_fwd(ctypes.byref(desc), _stream()), 'p2c_mlp_fwd')
-        ctx.save_for_backward(x, *weights, *biases)
+        ctx.save_for_backward(x, image, *weights, *biases)
         ctx.n_layers, ctx.sinks = n_layers, sinks
         return y
 
@@ -397,11 +398,11 @@ class FusedMLPFunction(torch.autograd.Function):
     def backward(ctx, gy):
         lib = _lib.lib()
         n = ctx.n_layers
-        x, *rest = ctx.saved_tensors
+        x, image, *rest = ctx.saved_tensors
         weights, biases = rest[:n], rest[n:]
         gy = _require_device(gy, 'grad')
         desc = _mlp_desc(x, weights, biases)
-        desc.gy = gy.data_ptr()
+        desc.gy, desc.w_image = gy.data_ptr(), image.data_ptr()
         if ctx.sinks is not None:
             gws, gbs = ctx.sinks[0::2], ctx.sinks[1::2]
         else:
