@@ -7,10 +7,10 @@
 // backward (+ a small deterministic reduction of the per-workgroup weight-gradient partials).
 //
 // Structure ("cooperative 16-sample tile"):
-//   * a workgroup of four wavefronts walks over tiles of 16 frames ("samples"). Activations live TRANSPOSED in LDS,
+//   * a workgroup of eight wavefronts walks over tiles of 16 frames ("samples"). Activations live TRANSPOSED in LDS,
 //     H^T[n][sample]: the sample index sits on lane&15 for the MFMA B operand (B[k][col]: lane = col + 16*k) *and* for
 //     the C/D tile (col = lane&15, row = 4*(lane>>4)+reg), so layer l+1 reads what layer l wrote with plain
-//     ds_read_b32 -- no transpose anywhere. The 16-row output tiles of a layer are dealt round-robin to the four waves
+//     ds_read_b32 -- no transpose anywhere. The 16-row output tiles of a layer are dealt round-robin to the eight waves
 //     (one barrier per layer): the dependent-MFMA chain a single wave would walk is what bounds small batches;
 //   * ALL weights are staged once per workgroup into a zero-padded LDS image [pad16(n_out)][pitch] with the bias in
 //     column n_in and the activations carrying a constant-one row n_in: the inner loops are select-free
@@ -32,8 +32,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int MAXW = 160;        // widest layer (padded to 16)
 constexpr int TS = 16;           // samples per tile
-constexpr int WAVES = 4;         // waves per workgroup
-constexpr int MAX_SLOTS = 24;    // dW tiles per wave held in accumulators
+constexpr int TP = 17;           // LDS pitch of an activation row (odd: the dW phase reads [row = lane&15][sample])
+constexpr int WAVES = 8;         // waves per workgroup
+constexpr int MAX_SLOTS = 12;    // dW tiles per wave held in accumulators
 constexpr int NL = P2C_MLP_MAX_LAYERS;
 
 struct MlpArgs {
@@ -53,14 +54,16 @@ struct MlpArgs {
   int32_t w_off[NL];             // offset of that image (floats)
   int32_t w_total;               // floats of all images
   int32_t h_off[NL + 1];         // row offset of H_l^T (l = 0..L) in the activation area; rows = pad16(dims[l]) + 16
-  int32_t act_rows;              // rows of the H area (the G area has the same layout)
+  int32_t act_rows;              // rows of H_0 .. H_L
+  int32_t vec_x, vec_y, vec_gy;  // 16-byte row loads/stores are legal (row length % 4 == 0 and base aligned)
   float *w_image;                // packed, zero-padded weight images in HBM (w_total floats), written by mlp_pack_kernel
 };
 
 __device__ __forceinline__ int pad16(int n) { return (n + 15) & ~15; }
 
 // Pack kernel (once per forward): the zero-padded image of every [W_l | b_l] -- rows 0..rows_l-1, pitch ld_l, bias in
-// column n_in -- laid out exactly as the workgroups want it in LDS.
+// column n_in, and a unit row n_out that copies the constant-one input row to the output (so that the next layer finds
+// its ones row without any select in the epilogue) -- laid out exactly as the workgroups want it in LDS.
 __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpArgs a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.w_total) return;
@@ -73,18 +76,20 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpArgs a) {
   if (n < n_out) {
     if (k < n_in) v = a.W[l][n * n_in + k];
     else if (k == n_in) v = a.b[l][n];
+  } else if (n == n_out && k == n_in) {
+    v = 1.f;
   }
   a.w_image[i] = v;
 }
 
-// Workgroup copy of the packed image HBM -> LDS: 16-byte loads, eight in flight per thread; every workgroup starts at
+// Workgroup copy of the packed image HBM -> LDS: 16-byte loads, several in flight per thread; every workgroup starts at
 // a different offset so that the 256 CUs do not ask the L2 for the same line at the same moment.
 __device__ __forceinline__ void stage_image(const MlpArgs &a, float *dst) {
   const int total4 = a.w_total >> 2, nth = blockDim.x;
   const f32x4 *src = reinterpret_cast<const f32x4 *>(a.w_image);
   f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
   const int rot = (int)((blockIdx.x * 2654435761u) % (unsigned)total4);
-  constexpr int U = 8;
+  constexpr int U = 6;
   for (int i0 = threadIdx.x; i0 < total4; i0 += U * nth) {
     f32x4 v[U];
     int idx[U];
@@ -101,78 +106,138 @@ __device__ __forceinline__ void stage_image(const MlpArgs &a, float *dst) {
   }
 }
 
+#ifdef P2C_MLP_TRACE   // developer build only (tools/mlptrace.py): shader-clock stamps of workgroup 0
+__device__ unsigned long long g_trace[2][40];
+#define TR(k, i)                                                                      \
+  do {                                                                                \
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                        \
+      g_trace[k][i] = __builtin_readcyclecounter();                                   \
+      if ((i) == 0 || (i) == 39) g_trace[k][(i) == 0 ? 38 : 37] = wall_clock64();    \
+    }                                                                                 \
+  } while (0)
+#else
+#define TR(k, i)
+#endif
+
 struct Lane {
   int lane, c, g, wave;   // c = lane & 15 (sample / column), g = lane >> 4
 };
 
-// x tile (16 samples x n0 features, contiguous rows in HBM) -> H_0^T[k][sample] with the ones row and zero padding
-__device__ __forceinline__ void load_x_tile(const MlpArgs &a, int64_t row0, float *h0) {
-  const int n0 = a.dims[0], rows = pad16(n0) + 16;
-  for (int i = threadIdx.x; i < rows * TS; i += blockDim.x) {
-    const int k = i >> 4, s = i & 15;      // consecutive threads -> consecutive samples of one feature (conflict-free)
-    float v = 0.f;
-    if (k < n0) {
-      const int64_t r = row0 + s;
-      v = (r < a.N) ? a.x[r * n0 + k] : 0.f;
-    } else if (k == n0) {
-      v = 1.f;
-    }
-    h0[i] = v;
-  }
-}
-
-// out^T[n][s] = act( sum_k Waug[n][k] in^T_aug[k][s] ) for the output tiles owned by this wave (nt = wave, wave+4, ..)
-// in: LDS rows [k][16] incl. ones row; out: LDS rows (ones row n_out written as 1, padding rows as 0) and/or HBM rows y.
-__device__ __forceinline__ void layer_forward(const Lane &L, const float *wl, int ld, int n_in, int n_out, bool relu,
-                                              const float *in, float *out, float *y_row, bool row_ok, int y_stride) {
-  const int ksteps = (((n_in + 1 + 3) >> 2) + 3) & ~3;   // multiple of 4: image and activations are zero beyond n_in
-  const int ntiles = (n_out + 16) >> 4;    // tiles covering rows 0..n_out (the ones row included)
-  for (int nt = L.wave; nt < ntiles; nt += 3 * WAVES) {
-    // up to three tiles of this wave per pass: independent accumulators hide the 40-cycle MFMA latency
-    const int nt1 = nt + WAVES, nt2 = nt + 2 * WAVES;
-    const bool two = nt1 < ntiles, three = nt2 < ntiles;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-    const float *a0p = wl + (nt * 16 + L.c) * ld + L.g;
-    const float *a1p = wl + ((two ? nt1 : nt) * 16 + L.c) * ld + L.g;
-    const float *a2p = wl + ((three ? nt2 : nt) * 16 + L.c) * ld + L.g;
-    const float *bp = in + L.g * TS + L.c;
-    for (int s = 0; s < ksteps; s += 4) {
-      float bv[4], a0[4], a1[4], a2[4];
+// 16 consecutive rows of a row-major [N][n] HBM matrix (one contiguous span) -> LDS transposed dst[k * TP + sample];
+// rows beyond N read as zero. All loads of a thread are issued before the first LDS store.
+__device__ __forceinline__ void load_tile_T(const float *src, int64_t row0, int64_t N, int n, float *dst, bool vec) {
+  const int64_t left = N - row0;
+  const int valid = (int)(left < TS ? left : TS) * n;      // floats of this tile that exist
+  const float *p = src + row0 * n;
+  const int nth = blockDim.x;
+  if (vec) {                                               // n % 4 == 0: a float4 never straddles two rows
+    const int total4 = (TS * n) >> 2;
+    const f32x4 *p4 = reinterpret_cast<const f32x4 *>(p);
+    constexpr int U = 2;
+    for (int i0 = threadIdx.x; i0 < total4; i0 += U * nth) {
+      f32x4 v[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        bv[u] = bp[(s + u) * 4 * TS];
-        a0[u] = a0p[(s + u) * 4], a1[u] = a1p[(s + u) * 4], a2[u] = a2p[(s + u) * 4];
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * nth;
+        v[u] = (i < total4 && 4 * i < valid) ? p4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv[u], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bv[u], acc1, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[u], bv[u], acc2, 0, 0, 0);
-      }
-    }
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * nth;
+        if (i < total4) {
+          const int e = 4 * i, sidx = e / n, k = e - sidx * n;
 #pragma unroll
-    for (int h = 0; h < 3; ++h) {
-      if ((h == 1 && !two) || (h == 2 && !three)) break;
-      f32x4 acc = (h == 0) ? acc0 : ((h == 1) ? acc1 : acc2);
-      const int nb = (nt + h * WAVES) * 16 + 4 * L.g;   // first of this lane's 4 output rows
-      if (relu) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = fmaxf(acc[r], 0.f);
-      }
-      if (out) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[(nb + r) * TS + L.c] = (nb + r == n_out) ? 1.f : acc[r];
-      }
-      if (y_row && row_ok) {
-        if (nb + 3 < n_out && (y_stride & 3) == 0) {   // 16-byte aligned only when the row pitch is a multiple of 4
-          *reinterpret_cast<f32x4 *>(y_row + nb) = acc;
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (nb + r < n_out) y_row[nb + r] = acc[r];
+          for (int j = 0; j < 4; ++j) dst[(k + j) * TP + sidx] = v[u][j];
         }
       }
     }
+  } else {
+    const int total = TS * n;
+    constexpr int U = 8;
+    for (int i0 = threadIdx.x; i0 < total; i0 += U * nth) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * nth;
+        v[u] = (i < valid) ? p[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = i0 + u * nth;
+        if (i < total) {
+          const int sidx = i / n, k = i - sidx * n;
+          dst[k * TP + sidx] = v[u];
+        }
+      }
+    }
+  }
+}
+
+// zero `rows` activation rows and set the constant-one row of H_0
+__device__ __forceinline__ void init_activations(float *area, int rows) {
+  for (int i = threadIdx.x; i < rows * TP; i += blockDim.x) area[i] = 0.f;
+}
+
+// out^T[n][s] = act( sum_k Waug[n][k] in^T_aug[k][s] ) for NT output tiles of this wave (nt0, nt0 + WAVES)
+template <int NT>
+__device__ __forceinline__ void layer_forward_nt(const Lane &L, const float *wl, int ld, int ksteps, int nt0, int n_out,
+                                                 bool relu, const float *in, float *out, float *y_row, bool row_ok,
+                                                 bool vec_y) {
+  f32x4 acc[NT];
+  const float *ap[NT];
+#pragma unroll
+  for (int h = 0; h < NT; ++h) {
+    acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ap[h] = wl + ((nt0 + h * WAVES) * 16 + L.c) * ld + L.g;
+  }
+  const float *bp = in + L.g * TP + L.c;
+  for (int s = 0; s < ksteps; s += 4) {
+    float bv[4], av[NT][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bv[u] = bp[(s + u) * 4 * TP];
+#pragma unroll
+      for (int h = 0; h < NT; ++h) av[h][u] = ap[h][(s + u) * 4];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int h = 0; h < NT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][u], bv[u], acc[h], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < NT; ++h) {
+    f32x4 v = acc[h];
+    const int nb = (nt0 + h * WAVES) * 16 + 4 * L.g;   // first of this lane's 4 output rows
+    if (relu) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+    }
+    if (out) {   // the unit row of the image makes row n_out == 1, rows beyond it == 0
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(nb + r) * TP + L.c] = v[r];
+    }
+    if (y_row && row_ok) {
+      if (nb + 3 < n_out && vec_y) {
+        *reinterpret_cast<f32x4 *>(y_row + nb) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nb + r < n_out) y_row[nb + r] = v[r];
+      }
+    }
+  }
+}
+
+// in: LDS rows [k][TP] incl. ones row; out: LDS rows and/or HBM rows y. The output tiles (rows 0..n_out, ones row
+// included) are dealt round-robin to the waves.
+__device__ __forceinline__ void layer_forward(const Lane &L, const float *wl, int ld, int n_in, int n_out, bool relu,
+                                              const float *in, float *out, float *y_row, bool row_ok, bool vec_y) {
+  const int ksteps = (((n_in + 1 + 3) >> 2) + 3) & ~3;   // multiple of 4: image and activations are zero beyond n_in
+  const int ntiles = (n_out + 16) >> 4;
+  for (int nt = L.wave; nt < ntiles; nt += 2 * WAVES) {
+    if (nt + WAVES < ntiles) layer_forward_nt<2>(L, wl, ld, ksteps, nt, n_out, relu, in, out, y_row, row_ok, vec_y);
+    else layer_forward_nt<1>(L, wl, ld, ksteps, nt, n_out, relu, in, out, y_row, row_ok, vec_y);
   }
 }
 
@@ -181,36 +246,25 @@ __device__ __forceinline__ void layer_dgrad(const Lane &L, const float *wl, int 
                                             const float *Hprev, float *gout) {
   const int ksteps = (((n_out + 3) >> 2) + 3) & ~3;      // multiple of 4: image rows and G rows are zero beyond n_out
   const int mtiles = (n_in + 15) >> 4;
-  for (int mt = L.wave; mt < mtiles; mt += 2 * WAVES) {
-    const int mt1 = mt + WAVES;
-    const bool two = mt1 < mtiles;
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+  for (int mt = L.wave; mt < mtiles; mt += WAVES) {
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
     const float *a0p = wl + L.g * ld + mt * 16 + L.c;
-    const float *a1p = wl + L.g * ld + (two ? mt1 : mt) * 16 + L.c;
-    const float *bp = gin + L.g * TS + L.c;
+    const float *bp = gin + L.g * TP + L.c;
     for (int s = 0; s < ksteps; s += 4) {
-      float bv[4], a0[4], a1[4];
+      float bv[4], a0[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        bv[u] = bp[(s + u) * 4 * TS];
-        a0[u] = a0p[(s + u) * 4 * ld], a1[u] = a1p[(s + u) * 4 * ld];
+        bv[u] = bp[(s + u) * 4 * TP];
+        a0[u] = a0p[(s + u) * 4 * ld];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv[u], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bv[u], c1, 0, 0, 0);
-      }
+      for (int u = 0; u < 4; ++u) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv[u], c0, 0, 0, 0);
     }
+    const int mb = mt * 16 + 4 * L.g;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (h == 1 && !two) break;
-      f32x4 cc = h ? c1 : c0;
-      const int mb = (h ? mt1 : mt) * 16 + 4 * L.g;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float hv = Hprev[(mb + r) * TS + L.c];
-        gout[(mb + r) * TS + L.c] = (mb + r < n_in && hv > 0.f) ? cc[r] : 0.f;
-      }
+    for (int r = 0; r < 4; ++r) {
+      const float hv = Hprev[(mb + r) * TP + L.c];
+      gout[(mb + r) * TP + L.c] = (mb + r < n_in && hv > 0.f) ? c0[r] : 0.f;
     }
   }
 }
@@ -235,38 +289,72 @@ __device__ __forceinline__ TileRef locate_tile(const int32_t *dims, int t) {
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
-// LDS: [weight images | H area: H_0 .. H_{L-1}]   (the input rows of layer l are H_l, its output H_{l+1})
-__global__ __launch_bounds__(256) void mlp_fwd_kernel(const MlpArgs a) {
-  extern __shared__ float lds[];
-  Lane L;
-  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = threadIdx.x >> 6;
-  stage_image(a, lds);
-  float *H = lds + a.w_total;
-  const int64_t n_tiles = (a.N + TS - 1) / TS;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row0 = tile * TS, row = row0 + L.c;
-    const bool row_ok = row < a.N;
-    __syncthreads();                                        // previous tile fully consumed (and weights staged)
-    load_x_tile(a, row0, H + a.h_off[0] * TS);
-    for (int l = 0; l < a.n_layers; ++l) {
-      __syncthreads();
-      const bool last = (l == a.n_layers - 1);
-      layer_forward(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], !last, H + a.h_off[l] * TS,
-                    last ? nullptr : H + a.h_off[l + 1] * TS, last ? a.y + row * a.dims[l + 1] : nullptr, row_ok,
-                    a.dims[l + 1]);
-    }
-  }
-}
-
-// ---- backward --------------------------------------------------------------------------------------------------------
-// LDS: [weight images | H area (H_0 .. H_{L-1}) | G area (G_1 .. G_L, G_l at the offset of H_l; G_L = gy tile)]
-__global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpArgs a) {
+// LDS: [weight images | H_0 .. H_{L-1}]   (the input rows of layer l are H_l, its output H_{l+1})
+__global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
   Lane L;
   L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = threadIdx.x >> 6;
   const int nl = a.n_layers;
+  TR(0, 0);
+  float *H = lds + a.w_total;
+  init_activations(H, a.h_off[nl]);
   stage_image(a, lds);
-  float *H = lds + a.w_total, *G = H + a.act_rows * TS;
+  __syncthreads();
+  if (threadIdx.x < TS) H[(a.h_off[0] + a.dims[0]) * TP + threadIdx.x] = 1.f;
+  TR(0, 1);
+  const int64_t n_tiles = (a.N + TS - 1) / TS;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * TS, row = row0 + L.c;
+    const bool row_ok = row < a.N;
+    TR(0, 2);
+    load_tile_T(a.x, row0, a.N, a.dims[0], H + a.h_off[0] * TP, a.vec_x != 0);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (l >= nl) break;
+      __syncthreads();
+      TR(0, 3 + l);
+      const bool last = (l == nl - 1);
+      layer_forward(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], !last, H + a.h_off[l] * TP,
+                    last ? nullptr : H + a.h_off[l + 1] * TP, last ? a.y + row * a.dims[l + 1] : nullptr, row_ok,
+                    a.vec_y != 0);
+    }
+    TR(0, 12);
+    // the next tile's x rows overwrite H_0 only after every wave has passed layer 0's barrier chain: the barrier of
+    // layer 1 (or, for a single layer, the one below) orders them
+    if (nl == 1) __syncthreads();
+  }
+  TR(0, 39);
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------------
+// LDS: [weight images | H_0 .. H_{L-1} | G_1 .. G_L (G_L = gy tile) | dW tile table]
+__global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
+  extern __shared__ float lds[];
+  Lane L;
+  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = threadIdx.x >> 6;
+  const int nl = a.n_layers;
+  TR(1, 0);
+  float *H = lds + a.w_total;
+  float *G = H + (a.h_off[nl] - a.h_off[1]) * TP;          // G_l lives at row h_off[l] of this base (l = 1..L)
+  int *tab = reinterpret_cast<int *>(H + (a.h_off[nl] + a.act_rows - a.h_off[1]) * TP);
+  init_activations(H, a.h_off[nl] + a.act_rows - a.h_off[1]);
+  if (threadIdx.x < MAX_SLOTS * WAVES) {   // LDS float offsets of the A (G rows) and B (H rows) fragments of dW tile t
+    const int t = threadIdx.x < a.n_tiles_w ? threadIdx.x : 0;
+    const TileRef tr = locate_tile(a.dims, t);
+    tab[2 * threadIdx.x] = (a.h_off[nl] - a.h_off[1] + a.h_off[tr.l + 1] + tr.ntile * 16) * TP;   // G rows, H-relative
+    tab[2 * threadIdx.x + 1] = (a.h_off[tr.l] + tr.mtile * 16) * TP;
+  }
+  stage_image(a, lds);
+  __syncthreads();
+  if (threadIdx.x < TS) H[(a.h_off[0] + a.dims[0]) * TP + threadIdx.x] = 1.f;
+  int goff[MAX_SLOTS], hoff[MAX_SLOTS];
+#pragma unroll
+  for (int slot = 0; slot < MAX_SLOTS; ++slot) {
+    const int t = slot * WAVES + L.wave;
+    goff[slot] = tab[2 * t] + L.c * TP + L.g;
+    hoff[slot] = tab[2 * t + 1] + L.c * TP + L.g;
+  }
+  TR(1, 1);
 
   f32x4 acc[MAX_SLOTS];
 #pragma unroll
@@ -275,91 +363,94 @@ __global__ __launch_bounds__(256) void mlp_bwd_kernel(const MlpArgs a) {
   const int64_t n_tiles = (a.N + TS - 1) / TS;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * TS;
-    __syncthreads();
-    load_x_tile(a, row0, H + a.h_off[0] * TS);
-    {   // gy tile -> G_L^T[n][sample], zero padded (rows >= n_out and samples beyond N)
-      const int n_out = a.dims[nl], rows = pad16(n_out) + 16;
-      float *gl = G + a.h_off[nl] * TS;
-      for (int i = threadIdx.x; i < rows * TS; i += blockDim.x) {
-        const int k = i >> 4, s = i & 15;
-        const int64_t r = row0 + s;
-        gl[i] = (k < n_out && r < a.N) ? a.gy[r * n_out + k] : 0.f;
-      }
-    }
+    __syncthreads();                       // previous tile's dW phase has consumed H and G
+    load_tile_T(a.x, row0, a.N, a.dims[0], H + a.h_off[0] * TP, a.vec_x != 0);
+    load_tile_T(a.gy, row0, a.N, a.dims[nl], G + a.h_off[nl] * TP, a.vec_gy != 0);
     // ---- phase F: activations H_1 .. H_{L-1}
-    for (int l = 0; l < nl - 1; ++l) {
+    TR(1, 2);
+#pragma unroll
+    for (int l = 0; l < NL - 1; ++l) {
+      if (l >= nl - 1) break;
       __syncthreads();
-      layer_forward(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], true, H + a.h_off[l] * TS,
-                    H + a.h_off[l + 1] * TS, nullptr, false, 0);
+      TR(1, 3 + l);
+      layer_forward(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], true, H + a.h_off[l] * TP,
+                    H + a.h_off[l + 1] * TP, nullptr, false, false);
     }
     // ---- phase D: G_l = relu'(H_l) .* (W_l^T G_{l+1}), l = L-1 .. 1
-    for (int l = nl - 1; l >= 1; --l) {
+#pragma unroll
+    for (int l = NL - 1; l >= 1; --l) {
+      if (l > nl - 1) continue;
       __syncthreads();
-      layer_dgrad(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], G + a.h_off[l + 1] * TS, H + a.h_off[l] * TS,
-                  G + a.h_off[l] * TS);
+      TR(1, 12 + l);
+      layer_dgrad(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], G + a.h_off[l + 1] * TP, H + a.h_off[l] * TP,
+                  G + a.h_off[l] * TP);
     }
     __syncthreads();
-    // ---- phase W: dW_aug_l[n][m] += sum_s G_{l+1}^T[n][s] * H_l^T_aug[m][s]; tile t belongs to wave (t & 3), slot (t >> 2)
-    // (rows of samples beyond N carry G = 0, so they add nothing)
+    TR(1, 22);
+    // ---- phase W: dW_aug_l[n][m] += sum_s G_{l+1}^T[n][s] * H_l^T_aug[m][s]; tile t = slot * WAVES + wave.
+    // Branch-free: slots past the last tile alias tile 0 and are never written out. Samples beyond N carry G = 0.
 #pragma unroll
     for (int slot = 0; slot < MAX_SLOTS; ++slot) {
-      const int t = slot * WAVES + L.wave;
-      if (t < a.n_tiles_w) {
-        const TileRef tr = locate_tile(a.dims, t);
-        const float *gp = G + (a.h_off[tr.l + 1] + tr.ntile * 16 + L.c) * TS + L.g;   // A[n][k = sample]
-        const float *hp = H + (a.h_off[tr.l] + tr.mtile * 16 + L.c) * TS + L.g;       // B[k = sample][m]
-        f32x4 c = acc[slot];
+      const float *gp = H + goff[slot];   // A[n][k = sample]   (offsets are relative to H)
+      const float *hp = H + hoff[slot];   // B[k = sample][m]
+      float av[4], bv[4];
 #pragma unroll
-        for (int s = 0; s < TS / 4; ++s) c = __builtin_amdgcn_mfma_f32_16x16x4f32(gp[4 * s], hp[4 * s], c, 0, 0, 0);
-        acc[slot] = c;
-      }
+      for (int s = 0; s < TS / 4; ++s) av[s] = gp[4 * s], bv[s] = hp[4 * s];
+#pragma unroll
+      for (int s = 0; s < TS / 4; ++s) acc[slot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[slot], 0, 0, 0);
     }
   }
-  // ---- per-workgroup partial gradients: partials[block][param], parameter order = (W_0, b_0, W_1, b_1, ...)
-  float *part = a.partials + (size_t)blockIdx.x * a.n_params;
+  TR(1, 23);
+  // ---- per-workgroup partial gradients, tile-major in MFMA C layout: partials[block][tile][lane][4] (one coalesced
+  // 16-byte store per lane and tile; mlp_reduce_kernel maps them to the parameter tensors)
+  f32x4 *part = reinterpret_cast<f32x4 *>(a.partials) + (size_t)blockIdx.x * a.n_tiles_w * 64;
 #pragma unroll
   for (int slot = 0; slot < MAX_SLOTS; ++slot) {
     const int t = slot * WAVES + L.wave;
-    if (t < a.n_tiles_w) {
-      const TileRef tr = locate_tile(a.dims, t);
-      const int n_in = a.dims[tr.l], n_out = a.dims[tr.l + 1];
-      const int m = tr.mtile * 16 + L.c;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = tr.ntile * 16 + 4 * L.g + r;
-        if (n < n_out) {
-          if (m < n_in) part[tr.base + n * n_in + m] = acc[slot][r];
-          else if (m == n_in) part[tr.base + n_out * n_in + n] = acc[slot][r];
-        }
-      }
-    }
+    if (t < a.n_tiles_w) part[t * 64 + L.lane] = acc[slot];
   }
+  TR(1, 39);
 }
 
-// grad[i] = sum over workgroups of partials[w][i], fixed order; scattered to the per-layer gradient tensors
-__global__ __launch_bounds__(256) void mlp_reduce_kernel(const MlpArgs a, int n_blocks) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n_params) return;
-  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  int w = 0;
-  for (; w + 8 <= n_blocks; w += 8) {
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s8[u] += a.partials[(size_t)(w + u) * a.n_params + i];
+// grad = sum over workgroups of their partial tiles, in a fixed order (bitwise reproducible), scattered to the per-layer
+// gradient tensors. One workgroup per dW tile: 64 lanes x 16 groups; group q adds workgroups q, q+16, ...
+constexpr int RG = 16;
+__global__ __launch_bounds__(64 * RG) void mlp_reduce_kernel(const MlpArgs a, int n_blocks) {
+  __shared__ f32x4 red[RG][64];
+  const int t = blockIdx.x, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const size_t stride = (size_t)a.n_tiles_w * 64;
+  const f32x4 *p = reinterpret_cast<const f32x4 *>(a.partials) + (size_t)t * 64 + lane;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int w = q;
+  for (; w + 3 * RG < n_blocks; w += 4 * RG) {
+    const f32x4 v0 = p[(size_t)w * stride], v1 = p[(size_t)(w + RG) * stride], v2 = p[(size_t)(w + 2 * RG) * stride],
+                v3 = p[(size_t)(w + 3 * RG) * stride];
+    s += v0, s += v1, s += v2, s += v3;
   }
-  for (; w < n_blocks; ++w) s8[0] += a.partials[(size_t)w * a.n_params + i];
-  float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-  int base = 0;
-  for (int l = 0; l < a.n_layers; ++l) {
-    const int nw = a.dims[l + 1] * a.dims[l], nb = a.dims[l + 1];
-    if (i < base + nw) { a.gW[l][i - base] = s; return; }
-    if (i < base + nw + nb) { a.gb[l][i - base - nw] = s; return; }
-    base += nw + nb;
+  for (; w < n_blocks; w += RG) s += p[(size_t)w * stride];
+  red[q][lane] = s;
+  __syncthreads();
+  if (q != 0) return;
+#pragma unroll
+  for (int i = 1; i < RG; ++i) s += red[i][lane];
+  const TileRef tr = locate_tile(a.dims, t);
+  const int n_in = a.dims[tr.l], n_out = a.dims[tr.l + 1];
+  const int m = tr.mtile * 16 + (lane & 15);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = tr.ntile * 16 + 4 * (lane >> 4) + r;
+    if (n < n_out) {
+      if (m < n_in) a.gW[tr.l][n * n_in + m] = s[r];
+      else if (m == n_in) a.gb[tr.l][n] = s[r];
+    }
   }
 }
 
 }  // namespace p2c_mlp
 
 using namespace p2c_mlp;
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int fill(MlpArgs &a, const p2c_mlp_desc *d) {
   if (!d || !d->x) return P2C_E_NULL;
@@ -386,14 +477,24 @@ static int fill(MlpArgs &a, const p2c_mlp_desc *d) {
     while ((ld & 3) != 2) ++ld;                                // pitch == 2 (mod 4)
     a.ld[l] = ld;
     a.w_off[l] = wtot;
-    // rows: forward tiles cover 0..n_out (ones row), dgrad k-steps cover up to 4*ceil(n_out/4)
+    // rows: forward tiles cover 0..n_out (unit row), dgrad k-steps cover up to pad16(n_out)
     wtot += (((a.dims[l + 1] + 16) & ~15)) * ld;
   }
   a.act_rows = rows;
   a.n_tiles_w = tiles;
   a.n_params = params;
   a.w_total = (wtot + 3) & ~3;
+  const int n0 = a.dims[0], nL = a.dims[d->n_layers];
+  a.vec_x = (n0 % 4 == 0) && aligned16(a.x);
+  a.vec_y = (nL % 4 == 0) && aligned16(a.y);
+  a.vec_gy = (nL % 4 == 0) && aligned16(a.gy);
   return 0;
+}
+
+static size_t lds_fwd(const MlpArgs &a) { return ((size_t)a.w_total + (size_t)a.h_off[a.n_layers] * TP) * sizeof(float); }
+static size_t lds_bwd(const MlpArgs &a) {
+  return ((size_t)a.w_total + (size_t)(a.h_off[a.n_layers] + a.act_rows - a.h_off[1]) * TP) * sizeof(float) +
+         2 * MAX_SLOTS * WAVES * sizeof(int);
 }
 
 static void allow_big_lds() {
@@ -409,6 +510,12 @@ static inline int n_blocks(int64_t N) {
   return (int)(n_tiles < 256 ? (n_tiles < 1 ? 1 : n_tiles) : 256);   // persistent: one workgroup per CU
 }
 
+#ifdef P2C_MLP_TRACE
+extern "C" P2C_API int p2c_debug_mlp_trace(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_mlp::g_trace), sizeof(unsigned long long) * 80);
+}
+#endif
+
 extern "C" int64_t p2c_mlp_image_floats(const p2c_mlp_desc *d) {
   MlpArgs a;
   if (fill(a, d)) return 0;
@@ -418,7 +525,7 @@ extern "C" int64_t p2c_mlp_image_floats(const p2c_mlp_desc *d) {
 extern "C" int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *d) {
   MlpArgs a;
   if (fill(a, d)) return 0;
-  return (int64_t)n_blocks(a.N) * a.n_params;
+  return (int64_t)n_blocks(a.N) * a.n_tiles_w * 256;
 }
 
 extern "C" int p2c_mlp_fwd(const p2c_mlp_desc *d, void *stream_) {
@@ -427,7 +534,7 @@ extern "C" int p2c_mlp_fwd(const p2c_mlp_desc *d, void *stream_) {
   if (rc) return rc;
   if (!a.y || !a.w_image) return P2C_E_NULL;
   if (a.N == 0) return 0;
-  size_t lds = ((size_t)a.w_total + (size_t)a.act_rows * TS) * sizeof(float);
+  const size_t lds = lds_fwd(a);
   if (lds > 160 * 1024) return P2C_E_SHAPE;
   allow_big_lds();
   hipLaunchKernelGGL(mlp_pack_kernel, dim3((a.w_total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
@@ -444,12 +551,12 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   for (int l = 0; l < a.n_layers; ++l)
     if (!a.gW[l] || !a.gb[l]) return P2C_E_NULL;
   if (a.n_tiles_w > MAX_SLOTS * WAVES) return P2C_E_SHAPE;
-  size_t lds = ((size_t)a.w_total + 2 * (size_t)a.act_rows * TS) * sizeof(float);
+  const size_t lds = lds_bwd(a);
   if (lds > 160 * 1024) return P2C_E_SHAPE;
   const int blocks = n_blocks(a.N);
   allow_big_lds();
   hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
-  hipLaunchKernelGGL(mlp_reduce_kernel, dim3((a.n_params + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a, blocks);
+  hipLaunchKernelGGL(mlp_reduce_kernel, dim3(a.n_tiles_w), dim3(64 * RG), 0, (hipStream_t)stream_, a, blocks);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
