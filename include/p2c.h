@@ -114,11 +114,12 @@ P2C_API int64_t p2c_pose_head_workspace_floats(int32_t B);
  * (pose head + deterministic reduction of the per-wave partial sums). */
 P2C_API int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream);
 
-/* Backward (recompute): grad_y has the layout of desc->y. `grad_losses` (3 floats, device) = upstream gradients
- * of (loc_2d, loc_3d, loc_2d_3d); desc->loss_sums and desc->final_rel_rot must hold the values written by the forward.
+/* Backward (recompute): grad_y has the layout of desc->y. `grad_losses` = host array of three device pointers (each
+ * NULL = no gradient, or one float): the upstream gradients of (loc_2d, loc_3d, loc_2d_3d) -- for a 3-vector gradient g
+ * pass {g, g+1, g+2}; NULL array = all zero. desc->loss_sums and desc->final_rel_rot must hold the forward's values.
  * Optional upstream gradients of materialised outputs (NULL = none): grad_absolute_pose_loc (B,T,26,3),
  * grad_projection_2d_transformed (B,T,26,3) [channel 2 ignored]. One launch. */
-P2C_API int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *grad_losses,
+P2C_API int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *const grad_losses[3],
                       const float *grad_absolute_pose_loc, const float *grad_projection_2d_transformed,
                       float *grad_y, void *stream);
 
@@ -171,6 +172,22 @@ P2C_API int64_t p2c_mlp_image_floats(const p2c_mlp_desc *desc);
 P2C_API int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *desc);
 P2C_API int p2c_mlp_fwd(const p2c_mlp_desc *desc, void *stream);
 P2C_API int p2c_mlp_bwd(const p2c_mlp_desc *desc, void *stream);
+
+/* ---- fused AdamW / Adam over one flat fp32 buffer ------------------------------------------------------------------
+ * Replaces torch.optim.AdamW.step() as configured by the reference (modules/flow/base_model.py:156-158) when all
+ * trainable parameters live in one flat buffer. Update rule = torch/optim/adamw.py (amsgrad=False, maximize=False):
+ *   g *= grad_scale;  p -= lr*wd*p (adamw) | g += wd*p (adam);  m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2;
+ *   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = *step + 1;  *step = t. One launch, graph-capturable. */
+typedef struct p2c_adamw_desc {
+  int64_t n;                 /* parameters */
+  float *param, *grad, *exp_avg, *exp_avg_sq;   /* device, n floats each, 16-byte aligned */
+  float *step;               /* device scalar: steps taken so far; incremented by the call */
+  int32_t *ticket;           /* device int, zero-initialised once by the caller (workgroup completion counter) */
+  const float *hyper;        /* device, 6 floats: lr, beta1, beta2, eps, weight_decay, grad_scale */
+  int32_t adamw;             /* 1 = decoupled weight decay (AdamW), 0 = L2 penalty (Adam) */
+  int32_t zero_grad;         /* 1 = leave grad zeroed (replaces the next step's zero_grad memset) */
+} p2c_adamw_desc;
+P2C_API int p2c_adamw_step(const p2c_adamw_desc *desc, void *stream);
 
 #ifdef __cplusplus
 }

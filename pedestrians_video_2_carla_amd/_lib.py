@@ -52,11 +52,18 @@ class MlpDesc(ctypes.Structure):
 
 # every symbol include/p2c.h declares: (restype, argtypes)
 _vp, _i64, _ip = ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)
+class AdamWDesc(ctypes.Structure):
+    """p2c_adamw_desc (include/p2c.h)."""
+    _fields_ = [('n', ctypes.c_int64), ('param', _f32p), ('grad', _f32p), ('exp_avg', _f32p), ('exp_avg_sq', _f32p),
+                ('step', _f32p), ('ticket', _f32p), ('hyper', _f32p), ('adamw', ctypes.c_int32),
+                ('zero_grad', ctypes.c_int32)]
+
+
 SYMBOLS = {
     'p2c_version': (ctypes.c_char_p, []),
     'p2c_pose_head_workspace_floats': (_i64, [_i32]),
     'p2c_pose_head_fwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp]),
-    'p2c_pose_head_bwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp, _vp, _vp, _vp, _vp]),
+    'p2c_pose_head_bwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.POINTER(_vp * 3), _vp, _vp, _vp, _vp]),
     'p2c_normalize_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _i32, _ip,
                                          ctypes.c_float, _vp]),
     'p2c_normalize_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _i32, _ip,
@@ -69,6 +76,7 @@ SYMBOLS = {
     'p2c_remap_nodes': (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _ip, _ip, _vp]),
     'p2c_mlp_workspace_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
     'p2c_mlp_image_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
+    'p2c_adamw_step': (ctypes.c_int, [ctypes.POINTER(AdamWDesc), _vp]),
     'p2c_mlp_fwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
     'p2c_mlp_bwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
 }
@@ -78,6 +86,14 @@ _lib = None
 
 class P2CError(RuntimeError):
     pass
+
+
+def grad_loss_pointers(g0=None, g1=None, g2=None, vector=None):
+    """The ``grad_losses`` argument of p2c_pose_head_bwd: three nullable device pointers (data_ptr ints or None);
+    ``vector`` = data_ptr of a contiguous 3-float gradient."""
+    if vector is not None:
+        g0, g1, g2 = vector, vector + 4, vector + 8
+    return ctypes.byref((_vp * 3)(g0, g1, g2))
 
 
 def build(verbose: bool = False) -> str:

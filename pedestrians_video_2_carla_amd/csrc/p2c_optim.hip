@@ -1,0 +1,99 @@
+// p2c_optim.hip -- fused AdamW / Adam step over ONE flat fp32 parameter buffer (gfx950).
+//
+// The reference optimises with torch.optim.AdamW (modules/flow/base_model.py:156-158 configure_optimizers). The trainer
+// here keeps every trainable parameter as a view of one flat buffer (parallel/flat.py), so the whole optimizer step is
+// one element-wise pass: 4 reads + 3 writes (+1 when it also leaves the gradient zeroed) per parameter, one launch.
+// Everything that varies between steps lives in device memory (step counter, hyper-parameters), so the launch can sit in
+// a HIP graph and still follow a learning-rate scheduler.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/p2c.h"
+
+namespace p2c_optim {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Coefs {
+  float lr_wd, beta1, one_m_beta1, beta2, one_m_beta2, step_size, inv_bc2_sqrt, eps, wd, grad_scale;
+};
+
+// torch/optim/adamw.py (_single_tensor_adamw) / ATen fused_adam_utils.cuh: bias corrections in double, update in fp32
+__device__ __forceinline__ Coefs coefs(const p2c_adamw_desc &d, float step) {
+  const float lr = d.hyper[0], b1 = d.hyper[1], b2 = d.hyper[2], eps = d.hyper[3], wd = d.hyper[4], gs = d.hyper[5];
+  const double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  Coefs c;
+  c.lr_wd = lr * wd, c.beta1 = b1, c.one_m_beta1 = 1.f - b1, c.beta2 = b2, c.one_m_beta2 = 1.f - b2;
+  c.step_size = (float)((double)lr / bc1), c.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)), c.eps = eps, c.wd = wd;
+  c.grad_scale = gs;
+  return c;
+}
+
+template <bool ADAMW>
+__device__ __forceinline__ void update(const Coefs &c, float &p, float g, float &m, float &v) {
+  g *= c.grad_scale;
+  if (ADAMW) p -= c.lr_wd * p;          // decoupled weight decay
+  else g += c.wd * p;                   // L2 penalty (Adam)
+  m += c.one_m_beta1 * (g - m);         // lerp(exp_avg, grad, 1 - beta1)
+  v = c.beta2 * v + c.one_m_beta2 * g * g;
+  const float denom = sqrtf(v) * c.inv_bc2_sqrt + c.eps;
+  p -= c.step_size * m / denom;
+}
+
+template <bool ADAMW>
+__global__ __launch_bounds__(256) void adamw_kernel(const p2c_adamw_desc d) {
+  const float step = *d.step + 1.f;      // every workgroup reads the counter before it takes its completion ticket
+  const Coefs c = coefs(d, step);
+  const int64_t n4 = d.n >> 2;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  f32x4 *P = reinterpret_cast<f32x4 *>(d.param), *G = reinterpret_cast<f32x4 *>(d.grad);
+  f32x4 *M = reinterpret_cast<f32x4 *>(d.exp_avg), *V = reinterpret_cast<f32x4 *>(d.exp_avg_sq);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 p = P[i], g = G[i], m = M[i], v = V[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float pk = p[k], mk = m[k], vk = v[k];
+      update<ADAMW>(c, pk, g[k], mk, vk);
+      p[k] = pk, m[k] = mk, v[k] = vk;
+    }
+    P[i] = p, M[i] = m, V[i] = v;
+    if (d.zero_grad) G[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
+    float p = d.param[i], m = d.exp_avg[i], v = d.exp_avg_sq[i];
+    update<ADAMW>(c, p, d.grad[i], m, v);
+    d.param[i] = p, d.exp_avg[i] = m, d.exp_avg_sq[i] = v;
+    if (d.zero_grad) d.grad[i] = 0.f;
+  }
+  // the last workgroup to finish publishes the new step count (all others have read the old one already)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(d.ticket, 1) == (int)gridDim.x - 1) {
+      *d.step = step;
+      *d.ticket = 0;
+    }
+  }
+}
+
+}  // namespace p2c_optim
+
+extern "C" int p2c_adamw_step(const p2c_adamw_desc *desc, void *stream_) {
+  if (!desc || !desc->param || !desc->grad || !desc->exp_avg || !desc->exp_avg_sq || !desc->step || !desc->ticket ||
+      !desc->hyper)
+    return P2C_E_NULL;
+  if (desc->n < 0) return P2C_E_SHAPE;
+  if (desc->n == 0) return 0;
+  for (const void *p : {(const void *)desc->param, (const void *)desc->grad, (const void *)desc->exp_avg,
+                        (const void *)desc->exp_avg_sq})
+    if (reinterpret_cast<uintptr_t>(p) & 15) return P2C_E_SHAPE;       // flat buffers are 16-byte aligned
+  const int64_t n4 = (desc->n + 3) >> 2;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (desc->adamw)
+    hipLaunchKernelGGL(p2c_optim::adamw_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, *desc);
+  else
+    hipLaunchKernelGGL(p2c_optim::adamw_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, *desc);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

@@ -515,11 +515,16 @@ __device__ __forceinline__ void world_store(const p2c_pose_head_desc &d, const L
 
 // loss scaling: loc_2d = S2 / (2 N2) -> d/dn = (n - g) / N2 ;  loc_3d = S3 / N3 -> d/dx = 2 (x - g) / N3.
 // grad_losses = upstream gradients of (loc_2d, loc_3d, loc_2d_3d); loc_2d_3d = loc_2d + loc_3d (loss/loc_2d_3d.py:15).
-__device__ __forceinline__ void loss_coefs(const p2c_pose_head_desc &d, const float *grad_losses, float &coef2,
-                                           float &coef3) {
-  if (!grad_losses) return;
+// Each upstream gradient is its own (nullable) device scalar: autograd hands the gradient of the one loss that was
+// used straight through, without a scatter into a 3-vector.
+struct GradLosses {
+  const float *p[3];
+};
+__device__ __forceinline__ void loss_coefs(const p2c_pose_head_desc &d, const GradLosses &gl, float &coef2, float &coef3) {
+  if (!gl.p[0] && !gl.p[1] && !gl.p[2]) return;
   float n2 = d.loss_sums[1], n3 = d.loss_sums[3];
-  float g2 = grad_losses[0] + grad_losses[2], g3 = grad_losses[1] + grad_losses[2];
+  const float u0 = gl.p[0] ? *gl.p[0] : 0.f, u1 = gl.p[1] ? *gl.p[1] : 0.f, u2 = gl.p[2] ? *gl.p[2] : 0.f;
+  float g2 = u0 + u2, g3 = u1 + u2;
   coef2 = (d.gt2d && n2 > 0.f) ? g2 / n2 : 0.f;
   coef3 = (d.gt3d && n3 > 0.f) ? 2.f * g3 / n3 : 0.f;
 }
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
 // backward, rotation kinds: frames in reverse, forward recomputed per frame
 // =====================================================================================================================
 template <int KIND>
-__global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_desc d, const float *grad_losses,
+__global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_desc d, const GradLosses grad_losses,
                                                          const float *g_abs_ext, const float *g_projt_ext,
                                                          float *grad_y) {
   using K = KindTraits<KIND>;
@@ -797,7 +802,7 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
 #define P2C_BWD_WAVES 1
 #endif
 template <int KIND>
-__global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(const p2c_pose_head_desc d, const float *grad_losses,
+__global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(const p2c_pose_head_desc d, const GradLosses grad_losses,
                                                                  const float *g_abs_ext, const float *g_projt_ext,
                                                                  float *grad_y) {
   using K = KindTraits<KIND>;
@@ -908,7 +913,7 @@ __global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(
 //   x^ = nan_to_zero((y - y[hips]) / |y[neck] - y[hips]|) ;  abs_loc = x^ * s_ref + h_ref
 // =====================================================================================================================
 template <int MODE>
-__global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc d, const float *grad_losses,
+__global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc d, const GradLosses grad_losses,
                                                         const float *g_abs_ext, const float *g_projt_ext,
                                                         float *grad_y) {
   constexpr bool BWD = (MODE == MODE_BWD);
@@ -1082,10 +1087,10 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
     case P2C_KIND_RELATIVE_ROT_MAT: P2C_LAUNCH_ROT_FWD(P2C_KIND_RELATIVE_ROT_MAT); break;
     default:
       if (mat)
-        hipLaunchKernelGGL((pose_head_absloc<MODE_FWD_MATERIALIZE>), grid, block, 0, stream, d, (const float *)nullptr,
+        hipLaunchKernelGGL((pose_head_absloc<MODE_FWD_MATERIALIZE>), grid, block, 0, stream, d, GradLosses{{nullptr, nullptr, nullptr}},
                            (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
       else
-        hipLaunchKernelGGL((pose_head_absloc<MODE_FWD>), grid, block, 0, stream, d, (const float *)nullptr,
+        hipLaunchKernelGGL((pose_head_absloc<MODE_FWD>), grid, block, 0, stream, d, GradLosses{{nullptr, nullptr, nullptr}},
                            (const float *)nullptr, (const float *)nullptr, (float *)nullptr);
   }
 #undef P2C_LAUNCH_ROT_FWD
@@ -1099,7 +1104,7 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
   return e == hipSuccess ? 0 : (int)e;
 }
 
-extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *grad_losses,
+extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *const grad_losses_[3],
                                  const float *grad_absolute_pose_loc, const float *grad_projection_2d_transformed,
                                  float *grad_y, void *stream_) {
   int rc = validate(desc);
@@ -1108,6 +1113,9 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *gr
   const p2c_pose_head_desc d = *desc;
   hipStream_t stream = (hipStream_t)stream_;
   dim3 grid(grid_for(d.B)), block(kBlock);
+  GradLosses grad_losses{{nullptr, nullptr, nullptr}};
+  if (grad_losses_)
+    for (int i = 0; i < 3; ++i) grad_losses.p[i] = grad_losses_[i];
   const float *ga = grad_absolute_pose_loc, *gp = grad_projection_2d_transformed;
   switch (d.kind) {
     case P2C_KIND_POSE_CHANGES_6D:

@@ -158,8 +158,34 @@ def available_outputs(spec: PoseHeadSpec, world: bool) -> Tuple[str, ...]:
     return tuple(keys)
 
 
+class PoseLosses:
+    """(loc_2d, loc_3d, loc_2d_3d) of one fused pose-head call.
+
+    ``losses[i]`` / ``losses.loc_2d_3d`` are 0-dim tensors that are outputs of the autograd node themselves: calling
+    ``backward`` on one of them reaches the HIP backward without any select/scatter kernel in between. ``losses.vector``
+    is the same three numbers as one (3,) tensor (also differentiable)."""
+    names = ('loc_2d', 'loc_3d', 'loc_2d_3d')
+
+    def __init__(self, vector: Tensor, scalars: Sequence[Tensor]):
+        self.vector = vector
+        self.scalars = tuple(scalars)
+
+    def __getitem__(self, i):
+        return self.scalars[self.names.index(i)] if isinstance(i, str) else self.scalars[i]
+
+    def __len__(self):
+        return 3
+
+    def __iter__(self):
+        return iter(self.scalars)
+
+    loc_2d = property(lambda self: self.scalars[0])
+    loc_3d = property(lambda self: self.scalars[1])
+    loc_2d_3d = property(lambda self: self.scalars[2])
+
+
 class PoseHeadFunction(torch.autograd.Function):
-    """losses (3,) = (loc_2d, loc_3d, loc_2d_3d) [+ materialised tensors] = f(model output y)."""
+    """(losses (3,), loc_2d, loc_3d, loc_2d_3d [, materialised tensors]) = f(model output y)."""
 
     @staticmethod
     def forward(ctx, y, spec: PoseHeadSpec, skel_type, dloc, drot, gt2d, gt3d, want: Tuple[str, ...]):
@@ -196,10 +222,12 @@ class PoseHeadFunction(torch.autograd.Function):
         nondiff = [outs[k] for k in want if k not in ('absolute_pose_loc', 'projection_2d_transformed')
                    and not (k == 'projection_2d' and spec.transform == 'none')]
         ctx.mark_non_differentiable(*nondiff)
-        return (bufs['losses'], *result)
+        ctx.set_materialize_grads(False)
+        vec = bufs['losses']
+        return (vec, vec[0], vec[1], vec[2], *result)       # the scalars are views of the vector: no device work
 
     @staticmethod
-    def backward(ctx, g_losses, *g_outs):
+    def backward(ctx, g_losses, g0, g1, g2, *g_outs):
         lib = _lib.lib()
         spec = ctx.spec
         y, skel_type, dloc, drot, gt2d, gt3d, loss_sums, final_rel_rot = ctx.saved_tensors
@@ -215,22 +243,29 @@ class PoseHeadFunction(torch.autograd.Function):
                 g_abs = _require_device(g, 'grad absolute_pose_loc')
             elif k == 'projection_2d_transformed' or (k == 'projection_2d' and spec.transform == 'none'):
                 g_projt = _require_device(g, 'grad ' + k)
-        g_losses = None if g_losses is None else _require_device(g_losses, 'grad losses')
+        scalars = [None if g is None else _require_device(g, 'grad loss') for g in (g0, g1, g2)]
+        if g_losses is not None:                      # gradient w.r.t. the (3,) vector output
+            g_losses = _require_device(g_losses, 'grad losses')
+            if any(g is not None for g in scalars):   # both forms used at once (rare): fold the scalars into the vector
+                g_losses = g_losses + torch.stack([torch.zeros_like(g_losses[0]) if g is None else g for g in scalars])
+            gl = _lib.grad_loss_pointers(vector=g_losses.data_ptr())
+        else:
+            gl = _lib.grad_loss_pointers(*[_ptr(g) for g in scalars])
         desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, {})
         grad_y = torch.empty_like(y)
         with torch.cuda.device(y.device):
-            _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), _ptr(g_losses), _ptr(g_abs), _ptr(g_projt),
-                                             grad_y.data_ptr(), _stream()), 'p2c_pose_head_bwd')
+            _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), gl, _ptr(g_abs), _ptr(g_projt), grad_y.data_ptr(),
+                                             _stream()), 'p2c_pose_head_bwd')
         return grad_y, None, None, None, None, None, None, None
 
 
 def pose_head(y: Tensor, spec: PoseHeadSpec, skel_type: Tensor, dloc: Optional[Tensor] = None,
               drot: Optional[Tensor] = None, gt2d: Optional[Tensor] = None, gt3d: Optional[Tensor] = None,
               want: Sequence[str] = ()) -> Tuple[Tensor, Dict[str, Tensor]]:
-    """Fused pose head. Returns (losses (3,), {name: materialised tensor for name in want})."""
+    """Fused pose head. Returns (PoseLosses, {name: materialised tensor for name in want})."""
     want = tuple(want)
     res = PoseHeadFunction.apply(y, spec, skel_type, dloc, drot, gt2d, gt3d, want)
-    return res[0], dict(zip(want, res[1:]))
+    return PoseLosses(res[0], res[1:4]), dict(zip(want, res[4:]))
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -47,6 +47,15 @@ class FlatParameters:
         """Same optimizer class / hyper-parameters, but over the single flat parameter."""
         if len(optimizer.param_groups) != 1:
             raise ValueError('flat optimizer needs a single param group (the reference configures exactly one)')
+        g0 = optimizer.param_groups[0]
+        if (type(optimizer) in (torch.optim.AdamW, torch.optim.Adam) and self.flat_param.is_cuda
+                and not g0.get('amsgrad', False) and not g0.get('maximize', False) and overrides.pop('native', True)):
+            from pedestrians_video_2_carla_amd.parallel.optim import FlatAdamW      # one HIP launch, graph-safe
+            overrides.pop('fused', None), overrides.pop('capturable', None)
+            decoupled = type(optimizer) is torch.optim.AdamW or bool(g0.get('decoupled_weight_decay', False))
+            return FlatAdamW([self.flat_param], lr=g0['lr'], betas=g0['betas'], eps=g0['eps'],
+                             weight_decay=g0['weight_decay'], decoupled=decoupled)
+        overrides.pop('native', None)
         import inspect
         accepted = set(inspect.signature(type(optimizer).__init__).parameters)
         group = {k: v for k, v in optimizer.param_groups[0].items() if k != 'params' and k in accepted}
@@ -60,6 +69,7 @@ class GradientExchange:
     def __init__(self, flat: FlatParameters, process_group: Optional[dist.ProcessGroup] = None):
         self.flat = flat
         self.group = process_group
+        self.average_here = True        # False: the optimizer kernel applies the 1/world factor (FlatAdamW.grad_scale)
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
         self.world = dist.get_world_size(process_group) if self.enabled else 1
 
@@ -70,7 +80,8 @@ class GradientExchange:
     def all_reduce_gradients(self):
         if self.enabled:
             dist.all_reduce(self.flat.flat_grad, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.flat_grad.mul_(1.0 / self.world)
+            if self.average_here:
+                self.flat.flat_grad.mul_(1.0 / self.world)
 
 
 def all_reduce_loss_sums(sum_and_count: torch.Tensor, group=None) -> torch.Tensor:

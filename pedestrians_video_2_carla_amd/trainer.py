@@ -59,6 +59,7 @@ class Trainer:
         self.optimizers: List[torch.optim.Optimizer] = []
         self._graphs = None
         self._static_loss = None
+        self._unit = None
 
     # ------------------------------------------------------------------------------------------------------------
     def setup(self, flow, datamodule):
@@ -83,12 +84,18 @@ class Trainer:
             if len(configs) != 1:
                 raise ValueError('exactly one trainable plugin expected (ZeroTrajectory has no optimizer)')
             self.optimizers = [self.flat.rebuild_optimizer(configs[0]['optimizer'], **extra)]
+            opt = self.optimizers[0]
+            if hasattr(opt, 'grad_scale') and self.exchange.enabled:    # FlatAdamW folds the DP averaging into its pass
+                opt.grad_scale = 1.0 / self.exchange.world
+                self.exchange.average_here = False
         else:
             self.optimizers = [c['optimizer'] for c in configs]
         return self
 
     def _zero_grad(self):
         if self.flat is not None:
+            if getattr(self.optimizers[0], 'zero_grad_in_step', False):
+                return                  # the flat gradient starts zeroed and FlatAdamW leaves it zeroed after each step
             self.flat.zero_grad()
         else:
             for o in self.optimizers:
@@ -98,8 +105,11 @@ class Trainer:
         self._zero_grad()
         flow.on_train_batch_start(batch, batch_idx)
         out = flow.training_step(batch, batch_idx)
-        out['loss'].backward()
-        return out['loss'].detach()
+        loss = out['loss']
+        if self._unit is None or self._unit.shape != loss.shape or self._unit.device != loss.device:
+            self._unit = torch.ones_like(loss)       # root gradient, made once (backward() would fill one per step)
+        loss.backward(gradient=self._unit)
+        return loss.detach()
 
     def _optimizer_step(self):
         for o in self.optimizers:
@@ -117,6 +127,9 @@ class Trainer:
             if self._graphs is None:
                 self._capture(flow, batch, batch_idx)
             g_fb, g_opt = self._graphs
+            for o in self.optimizers:
+                if hasattr(o, 'sync_hyper'):
+                    o.sync_hyper()               # LR-scheduler changes reach the captured optimizer launch
             g_fb.replay()
             if g_opt is not None:
                 self.exchange.all_reduce_gradients()

@@ -28,20 +28,21 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 def test_descriptor_layout_matches_the_header(tmp_path):
-    """ctypes mirror vs the C struct: same size and same offset for every field."""
-    from pedestrians_video_2_carla_amd._lib import PoseHeadDesc
-    fields = [f[0] for f in PoseHeadDesc._fields_]
-    src = tmp_path / 'layout.c'
-    body = '\n'.join(f'  printf("{f} %zu\\n", offsetof(p2c_pose_head_desc, {f}));' for f in fields)
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "p2c.h"\nint main(void) {\n'
-                   '  printf("sizeof %zu\\n", sizeof(p2c_pose_head_desc));\n' + body + '\n  return 0;\n}\n')
-    exe = tmp_path / 'layout'
-    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
-    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True)
-               .stdout.strip().splitlines())
-    assert int(out['sizeof']) == ctypes.sizeof(PoseHeadDesc)
-    for f in fields:
-        assert int(out[f]) == getattr(PoseHeadDesc, f).offset, f
+    """ctypes mirrors vs the C structs: same size and same offset for every field."""
+    from pedestrians_video_2_carla_amd._lib import AdamWDesc, MlpDesc, PoseHeadDesc
+    for cname, ctype in (('p2c_pose_head_desc', PoseHeadDesc), ('p2c_mlp_desc', MlpDesc), ('p2c_adamw_desc', AdamWDesc)):
+        fields = [f[0] for f in ctype._fields_]
+        src = tmp_path / f'{cname}.c'
+        body = '\n'.join(f'  printf("{f} %zu\\n", offsetof({cname}, {f}));' for f in fields)
+        src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "p2c.h"\nint main(void) {\n'
+                       f'  printf("sizeof %zu\\n", sizeof({cname}));\n' + body + '\n  return 0;\n}\n')
+        exe = tmp_path / cname
+        subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+        out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True)
+                   .stdout.strip().splitlines())
+        assert int(out['sizeof']) == ctypes.sizeof(ctype), cname
+        for f in fields:
+            assert int(out[f]) == getattr(ctype, f).offset, (cname, f)
 
 
 def test_ops_refuse_host_tensors():

@@ -43,9 +43,12 @@ def run_hip(y, spec, skel_type, dloc=None, drot=None, gt2d=None, gt3d=None, want
     losses, outs = ops.pose_head(yd, spec, skel_type.to(d).int(), mv(dloc), mv(drot), mv(gt2d), mv(gt3d), want)
     g = None
     if grad:
-        w = torch.tensor(upstream, device=d)
-        total = (losses * w)[torch.tensor([u != 0 for u in upstream])].sum()
-        total.backward()
+        used = [i for i, u in enumerate(upstream) if u != 0]
+        if len(used) == 1 and upstream[used[0]] == 1.0:
+            losses[used[0]].backward()                 # scalar output: its gradient reaches the kernel as one pointer
+        else:                                          # (3,) vector output with arbitrary upstream weights
+            w = torch.tensor(upstream, device=d)
+            (losses.vector * w)[torch.tensor([u != 0 for u in upstream])].sum().backward()
         g = yd.grad
     return losses, outs, g
 
@@ -272,8 +275,8 @@ def test_full_size_properties():
         l1, _ = ops.pose_head(yr, spec, st, gt2d=gt2, gt3d=gt3)
         l1[2].backward()
         l2, _ = ops.pose_head(y, spec, st, gt2d=gt2, gt3d=gt3)
-        assert torch.isfinite(l1).all() and torch.isfinite(yr.grad).all()
-        assert torch.equal(l1, l2), 'forward must be bitwise deterministic'
+        assert torch.isfinite(l1.vector).all() and torch.isfinite(yr.grad).all()
+        assert torch.equal(l1.vector, l2.vector), 'forward must be bitwise deterministic'
         h = B // 2
         la, _ = ops.pose_head(y[:h], spec, st[:h], gt2d=gt2[:h], gt3d=gt3[:h])
         lb, _ = ops.pose_head(y[h:], spec, st[h:], gt2d=gt2[h:], gt3d=gt3[h:])
