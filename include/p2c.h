@@ -110,6 +110,12 @@ P2C_API const char *p2c_version(void);
 /* number of floats `partials` must hold for a batch of B clips */
 P2C_API int64_t p2c_pose_head_workspace_floats(int32_t B);
 
+/* Kernel selection for the 6-D kinds with lean outputs: batches of at most `max_b` clips (default 2048, or the
+ * environment variable P2C_TP_MAX_B) run the time-parallel kernels (one workgroup per clip, one 32-lane group per frame,
+ * T <= 32), larger ones the clip-sequential kernels. Both compute the same function (fp32 rounding order differs in the
+ * cumulative rotation product). max_b < 0 only queries. Returns the previous value. */
+P2C_API int p2c_pose_head_set_time_parallel_max_batch(int32_t max_b);
+
 /* Forward: fills loss_sums, losses, final_rel_rot and any non-NULL out_* tensor. Two launches on `stream`
  * (pose head + deterministic reduction of the per-wave partial sums). */
 P2C_API int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream);

@@ -16,6 +16,7 @@
 //
 // Reference semantics restated here are cited per function (paths relative to src/pedestrians_video_2_carla/).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <math.h>
 
@@ -210,14 +211,7 @@ struct LaneCtx {
   bool has2, has3;  // this lane's joint takes part in loc_2d / loc_3d
 };
 
-__device__ __forceinline__ LaneCtx make_lane(const p2c_pose_head_desc &d) {
-  LaneCtx L;
-  L.lane = threadIdx.x & 63;
-  L.j = L.lane & 31;
-  L.base = L.lane & 32;
-  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  L.clip = wave * 2 + (L.lane >> 5);
-  L.active = (L.j < J) && (L.clip < d.B);
+__device__ __forceinline__ void fill_lane(LaneCtx &L, const p2c_pose_head_desc &d) {
   L.anc0 = c_parent[L.j];
   L.anc1 = c_anc_r2[L.j];
   L.anc2 = c_anc_r3[L.j];
@@ -228,6 +222,31 @@ __device__ __forceinline__ LaneCtx make_lane(const p2c_pose_head_desc &d) {
   L.never_masked = (L.j == d.hips_lane);
   L.has2 = L.active && d.gt2d && L.gm2 >= 0;
   L.has3 = L.active && d.gt3d && L.gm3 >= 0;
+}
+
+// clip-sequential kernels: a wavefront owns two clips (one per 32-lane group) and walks their frames in order
+__device__ __forceinline__ LaneCtx make_lane(const p2c_pose_head_desc &d) {
+  LaneCtx L;
+  L.lane = threadIdx.x & 63;
+  L.j = L.lane & 31;
+  L.base = L.lane & 32;
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  L.clip = wave * 2 + (L.lane >> 5);
+  L.active = (L.j < J) && (L.clip < d.B);
+  fill_lane(L, d);
+  return L;
+}
+
+// time-parallel kernels: a workgroup owns ONE clip, every 32-lane group one of its frames (t = 2 * wave + group)
+__device__ __forceinline__ LaneCtx make_lane_tp(const p2c_pose_head_desc &d, int &t) {
+  LaneCtx L;
+  L.lane = threadIdx.x & 63;
+  L.j = L.lane & 31;
+  L.base = L.lane & 32;
+  t = (int)(threadIdx.x >> 6) * 2 + (L.lane >> 5);
+  L.clip = blockIdx.x;
+  L.active = (L.j < J) && (t < d.T);
+  fill_lane(L, d);
   return L;
 }
 
@@ -909,6 +928,192 @@ __global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(
 }
 
 // =====================================================================================================================
+// time-parallel variants for small batches (6-D kinds, lean outputs)
+// ---------------------------------------------------------------------------------------------------------------------
+// The clip-sequential kernels above give a whole clip to half a wavefront: with B = 256 that is 128 wavefronts on a
+// 1024-SIMD chip, each walking T frames one after the other. Here a workgroup takes ONE clip and every 32-lane group one
+// frame; the only coupling between frames -- rel_rot[t] = change[t] @ rel_rot[t-1] (p3d_pose.py:98-114) -- becomes a
+// log2(T)-round inclusive scan of 3x3 products through LDS, and the backward's suffix sum of torques a second pass
+// through LDS. B * T / 2 wavefronts, each doing one frame's work.
+// =====================================================================================================================
+__device__ __forceinline__ World world_at(const p2c_pose_head_desc &d, const LaneCtx &L, int t) {
+  World W;
+  W.on = (d.dloc != nullptr) || (d.drot != nullptr);
+  W.rot = identity();
+  W.loc = v3(0.f, 0.f, 0.f);
+  if (W.on) {
+    const int tt = t < d.T ? t : d.T - 1;
+    if (d.world_absolute) world_step(d, L, tt, W);
+    else
+      for (int i = 0; i <= tt; ++i) world_step(d, L, i, W);
+  }
+  return W;
+}
+
+// inclusive scan over the frames of the clip: returns P_t = c_t c_{t-1} ... c_0 (planes: 2 x [frames][32][9] floats)
+__device__ __forceinline__ M3 scan_time(M3 P, int t, int j, int T, float *planes, int plane_floats) {
+  int cur = 0;
+  for (int off = 1; off < T; off <<= 1) {
+    float *mine = planes + cur * plane_floats + (t * GROUP + j) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) mine[i] = P.m[i];
+    __syncthreads();
+    if (t >= off) {
+      const float *q = planes + cur * plane_floats + ((t - off) * GROUP + j) * 9;
+      M3 Q;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Q.m[i] = q[i];
+      P = mul(P, Q);
+    }
+    cur ^= 1;
+  }
+  return P;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void pose_head_rot_fwd_tp(const p2c_pose_head_desc d) {
+  using K = KindTraits<KIND>;
+  extern __shared__ float tp_lds[];
+  int t;
+  const LaneCtx L = make_lane_tp(d, t);
+  const int T = d.T, n_waves = blockDim.x >> 6, wave = threadIdx.x >> 6;
+  const int plane = n_waves * 2 * GROUP * 9;
+
+  V3 l = v3(0.f, 0.f, 0.f);
+  M3 Rref = identity();
+  if (L.j < J) {
+    int st = d.skel_type[L.clip];
+    const float *pl = d.ref_rel_loc + ((size_t)st * J + L.j) * 3;
+    l = v3(pl[0], pl[1], pl[2]);
+    if (K::SCAN) {
+      const float *pr = d.ref_rel_rot + ((size_t)st * J + L.j) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rref.m[i] = pr[i];
+    }
+  }
+  FrameIn<K::NY> cur;
+  FramePtrs ptrs = frame_ptrs<K::NY>(d, L, t);
+  load_frame<K::NY, 1>(L, ptrs, cur);
+  M3 c;
+  if (K::SIXD) {
+    SixD s;
+    c = rot6d_fwd(cur.y, s);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.m[i] = cur.y[i];
+  }
+  M3 R = c;
+  if (K::SCAN) R = mul(scan_time(c, t, L.j, T, tp_lds, plane), Rref);
+  if (L.active && K::SCAN && d.final_rel_rot && t == T - 1) store_m3(d.final_rel_rot, (size_t)L.clip * J + L.j, R);
+  M3 A = R;
+  V3 x = l;
+  fk_doubling(L, A, x);
+  const World W = world_at(d, L, t);
+  HeadAcc acc{0.f, 0.f, 0.f};
+  frame_head<MODE_FWD>(d, L, t, x, W, acc, 0.f, 0.f, nullptr, nullptr, cur.g2, cur.g3);
+
+  // one partial per clip, waves added in frame order
+  float s2 = wave_sum(acc.sum2), c2 = wave_sum(acc.cnt2), s3 = wave_sum(acc.sum3);
+  float *red = tp_lds + 2 * plane;
+  __syncthreads();
+  if (L.lane == 0) red[wave * 3 + 0] = s2, red[wave * 3 + 1] = c2, red[wave * 3 + 2] = s3;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f, cc = 0.f;
+    for (int w = 0; w < n_waves; ++w) a += red[w * 3], b += red[w * 3 + 1], cc += red[w * 3 + 2];
+    float *p = d.partials + (size_t)L.clip * 4;
+    p[0] = a, p[1] = b, p[2] = cc, p[3] = 0.f;
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_pose_head_desc d, const GradLosses grad_losses,
+                                                                     const float *g_abs_ext, const float *g_projt_ext,
+                                                                     float *grad_y) {
+  using K = KindTraits<KIND>;
+  static_assert(K::SIXD, "tangent-space backward is for the 6-D kinds");
+  extern __shared__ float tp_lds[];
+  int t;
+  const LaneCtx L = make_lane_tp(d, t);
+  const int T = d.T, n_waves = blockDim.x >> 6;
+  const int plane = n_waves * 2 * GROUP * 9;
+
+  V3 l = v3(0.f, 0.f, 0.f);
+  M3 Rref = identity();
+  if (L.j < J) {
+    int st = d.skel_type[L.clip];
+    const float *pl = d.ref_rel_loc + ((size_t)st * J + L.j) * 3;
+    l = v3(pl[0], pl[1], pl[2]);
+    if (K::SCAN) {
+      const float *pr = d.ref_rel_rot + ((size_t)st * J + L.j) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rref.m[i] = pr[i];
+    }
+  }
+  float coef2 = 0.f, coef3 = 0.f;
+  loss_coefs(d, grad_losses, coef2, coef3);
+
+  FrameIn<6> cur;
+  FramePtrs ptrs = frame_ptrs<6>(d, L, t);
+  load_frame<6, 1>(L, ptrs, cur);
+  SixD s;
+  const M3 c = rot6d_fwd(cur.y, s);
+  M3 R = c;
+  if (K::SCAN) R = mul(scan_time(c, t, L.j, T, tp_lds, plane), Rref);
+  M3 A = R;
+  V3 x = l;
+  fk_doubling(L, A, x);
+  const World W = world_at(d, L, t);
+  HeadAcc acc{0.f, 0.f, 0.f};
+  V3 F = frame_head<MODE_BWD>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
+  // subtree sums of F and F x x through prefix sums over the DFS-ordered lanes
+  V3 FX = cross(F, x);
+  V3 PF = v3(group_prefix(F.x), group_prefix(F.y), group_prefix(F.z));
+  V3 PX = v3(group_prefix(FX.x), group_prefix(FX.y), group_prefix(FX.z));
+  V3 SubF = shfl(PF, L.base + L.sub_end) - (PF - F);
+  V3 SubX = shfl(PX, L.base + L.sub_end) - (PX - FX);
+  V3 tau = SubX - cross(SubF, x);
+  V3 taup = vmul(vmulT(tau, A), R);  // tau A^T R
+  V3 g = taup;
+  if (K::SCAN) {
+    // S_t = sum over t' >= t of the parent-frame torques, added from the last frame down (the clip-sequential order)
+    float *sb = tp_lds;
+    __syncthreads();   // every group is done reading the scan planes
+    sb[(t * GROUP + L.j) * 3 + 0] = taup.x, sb[(t * GROUP + L.j) * 3 + 1] = taup.y, sb[(t * GROUP + L.j) * 3 + 2] = taup.z;
+    __syncthreads();
+    V3 S = v3(0.f, 0.f, 0.f);
+    for (int tt = T - 1; tt >= t; --tt) {
+      const float *q = sb + (tt * GROUP + L.j) * 3;
+      S = S + v3(q[0], q[1], q[2]);
+    }
+    const M3 Rprev = (t > 0) ? mulTN(c, R) : Rref;  // change is a rotation: rel_rot[t-1] = change^T rel_rot[t]
+    g = vmulT(S, Rprev);
+  }
+  if (L.active) {
+    float gy6[6];
+    if (s.c1 && s.c2) {
+      V3 b3 = v3(c.m[6], c.m[7], c.m[8]);
+      float al = dot(g, s.b1), be = dot(g, s.b2), ga = dot(g, b3);
+      float r1 = frcp(s.n1), r2 = frcp(s.n2);
+      float k3 = (be + al * s.d * r2) * r1, k2 = -ga * r1, k5 = -al * r2;
+      gy6[0] = fmaf(k3, b3.x, k2 * s.b2.x), gy6[1] = fmaf(k3, b3.y, k2 * s.b2.y), gy6[2] = fmaf(k3, b3.z, k2 * s.b2.z);
+      gy6[3] = k5 * b3.x, gy6[4] = k5 * b3.y, gy6[5] = k5 * b3.z;
+    } else {  // a norm sits on the 1e-12 clamp: generic chain rule through the Gram-Schmidt steps
+      M3 G;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        V3 ci = v3(c.m[i * 3], c.m[i * 3 + 1], c.m[i * 3 + 2]);
+        V3 h = cross(ci, g) * 0.5f;
+        G.m[i * 3] = h.x, G.m[i * 3 + 1] = h.y, G.m[i * 3 + 2] = h.z;
+      }
+      rot6d_bwd(s, G, gy6);
+    }
+    float2 *q = reinterpret_cast<float2 *>(grad_y + (((size_t)L.clip * T + t) * J + L.j) * 6);
+    q[0] = make_float2(gy6[0], gy6[1]), q[1] = make_float2(gy6[2], gy6[3]), q[2] = make_float2(gy6[4], gy6[5]);
+  }
+}
+
+// =====================================================================================================================
 // absolute_loc kind (projection.py:125-136 + reference_skeletons_denormalizer.py:67-91)
 //   x^ = nan_to_zero((y - y[hips]) / |y[neck] - y[hips]|) ;  abs_loc = x^ * s_ref + h_ref
 // =====================================================================================================================
@@ -1062,9 +1267,34 @@ static inline unsigned grid_for(int B) {
 
 extern "C" const char *p2c_version(void) { return "p2c-hip 0.1.0 gfx950"; }
 
+// Batches up to this many clips take the time-parallel kernels (6-D kinds, lean outputs, T <= 32); larger ones have
+// enough clips to fill the chip with the cheaper clip-sequential walk. P2C_TP_MAX_B overrides (tuning / tests).
+static int g_tp_max_b = -1;
+static int tp_max_b() {
+  if (g_tp_max_b < 0) {
+    const char *e = getenv("P2C_TP_MAX_B");
+    g_tp_max_b = e ? atoi(e) : 2048;
+  }
+  return g_tp_max_b;
+}
+extern "C" int p2c_pose_head_set_time_parallel_max_batch(int32_t max_b) {
+  const int prev = tp_max_b();
+  if (max_b >= 0) g_tp_max_b = max_b;
+  return prev;
+}
+static inline bool use_tp(const p2c_pose_head_desc &d) {
+  return (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D) && d.T <= 32 && d.B <= tp_max_b();
+}
+static inline unsigned tp_threads(int T) { return 64u * (unsigned)((T + 1) / 2); }
+static inline size_t tp_lds_bytes(int T) {
+  const size_t waves = (size_t)(T + 1) / 2;
+  return (2 * waves * 2 * GROUP * 9 + waves * 3) * sizeof(float);
+}
+
 extern "C" int64_t p2c_pose_head_workspace_floats(int32_t B) {
   if (B <= 0) return 0;
-  return (int64_t)grid_for(B) * (kBlock / 64) * 4;
+  const int64_t seq = (int64_t)grid_for(B) * (kBlock / 64) * 4, tp = (int64_t)B * 4;   // per-wave / per-clip partials
+  return seq > tp ? seq : tp;
 }
 
 extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) {
@@ -1077,8 +1307,11 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
                    d.out_scale || d.out_relative_pose_loc || d.out_relative_pose_rot || d.out_absolute_pose_loc ||
                    d.out_absolute_pose_rot || d.out_world_loc || d.out_world_rot;
   if ((d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_POSE_CHANGES_MAT) && !d.final_rel_rot) return P2C_E_NULL;
-#define P2C_LAUNCH_ROT_FWD(KIND)                                                                  \
-  if (mat) hipLaunchKernelGGL((pose_head_rot_fwd<KIND, true>), grid, block, 0, stream, d);        \
+  const bool tp = !mat && use_tp(d);
+  const dim3 tp_grid((unsigned)d.B), tp_block(tp_threads(d.T));
+#define P2C_LAUNCH_ROT_FWD(KIND)                                                                                \
+  if (mat) hipLaunchKernelGGL((pose_head_rot_fwd<KIND, true>), grid, block, 0, stream, d);                      \
+  else if (tp) hipLaunchKernelGGL((pose_head_rot_fwd_tp<KIND>), tp_grid, tp_block, tp_lds_bytes(d.T), stream, d); \
   else hipLaunchKernelGGL((pose_head_rot_fwd<KIND, false>), grid, block, 0, stream, d)
   switch (d.kind) {
     case P2C_KIND_POSE_CHANGES_6D: P2C_LAUNCH_ROT_FWD(P2C_KIND_POSE_CHANGES_6D); break;
@@ -1096,7 +1329,7 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
 #undef P2C_LAUNCH_ROT_FWD
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  int n_waves = (int)(grid.x * (kBlock / 64));
+  int n_waves = tp ? d.B : (int)(grid.x * (kBlock / 64));
   float n3 = (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
   hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, n_waves, n3,
                      d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
@@ -1120,14 +1353,22 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
   switch (d.kind) {
     case P2C_KIND_POSE_CHANGES_6D:
       if (!d.final_rel_rot) return P2C_E_NULL;
-      hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_POSE_CHANGES_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+      if (use_tp(d))
+        hipLaunchKernelGGL(pose_head_rot_bwd_tangent_tp<P2C_KIND_POSE_CHANGES_6D>, dim3((unsigned)d.B), dim3(tp_threads(d.T)),
+                           tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, grad_y);
+      else
+        hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_POSE_CHANGES_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
       break;
     case P2C_KIND_POSE_CHANGES_MAT:
       if (!d.final_rel_rot) return P2C_E_NULL;
       hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_POSE_CHANGES_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
       break;
     case P2C_KIND_RELATIVE_ROT_6D:
-      hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_RELATIVE_ROT_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+      if (use_tp(d))
+        hipLaunchKernelGGL(pose_head_rot_bwd_tangent_tp<P2C_KIND_RELATIVE_ROT_6D>, dim3((unsigned)d.B), dim3(tp_threads(d.T)),
+                           tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, grad_y);
+      else
+        hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_RELATIVE_ROT_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
       break;
     case P2C_KIND_RELATIVE_ROT_MAT:
       hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_RELATIVE_ROT_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);

@@ -21,6 +21,18 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(autouse=True, params=['time_parallel', 'clip_sequential'])
+def kernel_variant(request):
+    """Every case runs twice: with the time-parallel kernels (small batches, the default choice below 2048 clips) and
+    with the clip-sequential ones (what large batches get). Only lean 6-D calls have two variants; for the rest the
+    setting is a no-op."""
+    from pedestrians_video_2_carla_amd import _lib
+    lib = _lib.lib()
+    prev = lib.p2c_pose_head_set_time_parallel_max_batch(1 << 30 if request.param == 'time_parallel' else 0)
+    yield request.param
+    lib.p2c_pose_head_set_time_parallel_max_batch(prev)
+
+
 def close(a, b, what, rtol=RTOL, fp32_ref=None):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     assert a.shape == b.shape, (what, a.shape, b.shape)
