@@ -11,8 +11,10 @@ batch that is resident in HBM before the timed region. Workload at N=1: BASELINE
 (B=256 clips per GPU, T=16, J=26, pose_changes output, loss loc_2d_3d); weak scaling: every rank gets its own B clips.
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  roofline     dominant HIP kernel of the step: algorithmic bytes per launch / measured launch duration vs 8 TB/s
-  roofline_sweep  the same kernel(s) at B = 256, 1024, 8192, 65536 (the step at B=256 is launch-bound by construction)
+  step_breakdown  device time of every launch group of the step at the benchmark batch (graph-timed, HIP events)
+  roofline     the launch group that takes the most time in the step: algorithmic bytes (pose head, vs 8 TB/s HBM) or
+               flops (fused MLP, vs the 157.3 TFLOP/s fp32 MFMA peak) per launch / measured duration; `other` = the rest
+  roofline_sweep  the pose-head kernels at B = 256, 1024, 8192, 65536 (the step at B=256 is latency-bound by construction)
   cpu_baseline the op-for-op CPU port of the reference step (oracle/reference_port.py) timed on this host's cores.
 """
 import argparse
@@ -29,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD (= the fp32 vector peak)
 T_FRAMES, JOINTS = 16, 26
 # SURVEY.md §8d algorithmic bytes per clip (T=16, J=26), pose_changes: fwd reads y6d(6)+gt2d(2)+gt3d(3) floats per
 # joint-frame; bwd reads the same and writes grad_y(6); + the skeleton-type index.
@@ -117,6 +120,69 @@ def kernel_times(device, B, reps=20):
             e1.synchronize()
             out[name] = e0.elapsed_time(e1) * 1e3 / (reps * rounds)      # us per launch (fwd: head + 1-block reduce)
     return out
+
+
+def _graph_us(fn, stream, reps=20, rounds=5):
+    fn()
+    stream.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=stream):
+        for _ in range(reps):
+            fn()
+    graph.replay()
+    stream.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(rounds):
+        graph.replay()
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * rounds)
+
+
+def mlp_times(device, model, B):
+    """Device time of the fused LinearAE launches (pack + forward; backward + partial reduction) and of the fused AdamW
+    at N = B * T frames, through the C ABI, graph-timed like kernel_times(). Returns (times_us, macs_per_frame)."""
+    import ctypes
+    from pedestrians_video_2_carla_amd import _lib, ops
+    from pedestrians_video_2_carla_amd.parallel.optim import FlatAdamW
+    lib = _lib.lib()
+    linears = model._linears()
+    Ws = [l.weight.detach().clone() for l in linears]
+    bs = [l.bias.detach().clone() for l in linears]
+    N = B * T_FRAMES
+    x = torch.randn(N, Ws[0].shape[1], device=device)
+    gy = torch.randn(N, Ws[-1].shape[0], device=device)
+    desc = ops._mlp_desc(x, Ws, bs)
+    f32 = dict(dtype=torch.float32, device=device)
+    y = torch.empty(N, Ws[-1].shape[0], **f32)
+    image = torch.empty(lib.p2c_mlp_image_floats(ctypes.byref(desc)), **f32)
+    part = torch.empty(lib.p2c_mlp_workspace_floats(ctypes.byref(desc)), **f32)
+    gW, gb = [torch.empty_like(w) for w in Ws], [torch.empty_like(b) for b in bs]
+    desc.y, desc.w_image, desc.gy, desc.partials = y.data_ptr(), image.data_ptr(), gy.data_ptr(), part.data_ptr()
+    for i in range(len(Ws)):
+        desc.gW[i], desc.gb[i] = gW[i].data_ptr(), gb[i].data_ptr()
+    flat = torch.nn.Parameter(torch.randn(sum(w.numel() + b.numel() for w, b in zip(Ws, bs)), device=device))
+    flat.grad = torch.randn_like(flat)
+    opt = FlatAdamW([flat], lr=1e-4)
+    opt.sync_hyper()
+    out = {}
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        s = stream.cuda_stream
+        out['mlp_fwd(+pack)'] = _graph_us(lambda: _lib.check(lib.p2c_mlp_fwd(ctypes.byref(desc), s), 'mlp fwd'), stream)
+        out['mlp_bwd(+reduce)'] = _graph_us(lambda: _lib.check(lib.p2c_mlp_bwd(ctypes.byref(desc), s), 'mlp bwd'), stream)
+        out['adamw'] = _graph_us(opt.step, stream)
+    macs = sum(w.shape[0] * w.shape[1] for w in Ws)
+    macs_bwd = macs + sum(w.shape[0] * w.shape[1] for w in Ws[1:])        # wgrad of every layer + dgrad of layers 1..L-1
+    return out, {'mlp_fwd(+pack)': 2 * macs * N, 'mlp_bwd(+reduce)': 2 * macs_bwd * N}
+
+
+def mfma_entry(name, B, us, flops):
+    achieved = flops / (us * 1e-6) / 1e12
+    return {'kernel': name, 'B': B, 'us_per_launch': round(us, 2), 'bound': 'mfma', 'achieved': round(achieved, 3),
+            'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+            'algorithmic_flops_per_launch': flops, 'traffic': None}
 
 
 def roofline_entry(name, B, us, nbytes_per_clip, traffic=None):
@@ -225,20 +291,28 @@ def main():
     }
     traffic = load_traffic()
     kt = kernel_times(device, args.batch_size)
-    dominant = max(kt, key=kt.get)
     names = {'fwd': 'pose_head_rot_fwd<6D>(+loss_finalize)', 'bwd': 'pose_head_rot_bwd<6D>'}
     per_clip = {'fwd': BYTES_FWD, 'bwd': BYTES_BWD}
-    result['roofline'] = roofline_entry(names[dominant], args.batch_size, kt[dominant], per_clip[dominant],
-                                        traffic.get(f'{dominant}_B{args.batch_size}'))
-    result['roofline']['other'] = roofline_entry(names['fwd' if dominant == 'bwd' else 'bwd'], args.batch_size,
-                                                 kt['fwd' if dominant == 'bwd' else 'bwd'],
-                                                 per_clip['fwd' if dominant == 'bwd' else 'bwd'])
+    entries = {names[w]: roofline_entry(names[w], args.batch_size, kt[w], per_clip[w],
+                                        (traffic.get(f'{names[w]}@B{args.batch_size}') or {}).get('bytes')) for w in ('fwd', 'bwd')}
+    breakdown = {names[w]: round(kt[w], 2) for w in ('fwd', 'bwd')}
+    if getattr(flow.movements_model, 'fused_mlp', False):
+        mt, flops = mlp_times(device, flow.movements_model, args.batch_size)
+        breakdown.update({k: round(v, 2) for k, v in mt.items()})
+        for k, fl in flops.items():
+            entries[k] = mfma_entry(k, args.batch_size, mt[k], fl)
+            entries[k]['traffic'] = (traffic.get(f'{k}@B{args.batch_size}') or {}).get('bytes')
+    result['step_breakdown_us'] = breakdown
+    dominant = max(entries, key=lambda k: entries[k]['us_per_launch'])
+    result['roofline'] = entries.pop(dominant)
+    result['roofline']['other'] = list(entries.values())
     if not args.no_sweep and world == 1:
         sweep = []
         for B in (256, 1024, 8192, 65536):
             k = kernel_times(device, B, reps=10 if B > 8192 else 20)
             for which in ('fwd', 'bwd'):
-                sweep.append(roofline_entry(names[which], B, k[which], per_clip[which], traffic.get(f'{which}_B{B}')))
+                sweep.append(roofline_entry(names[which], B, k[which], per_clip[which],
+                                            (traffic.get(f'{names[which]}@B{B}') or {}).get('bytes')))
         result['roofline_sweep'] = sweep
     if not args.no_cpu_baseline and world == 1:
         result['cpu_baseline'] = cpu_baseline(args.batch_size, args.cpu_seconds)

@@ -1,54 +1,59 @@
-"""Kernel micro-benchmark: pose head fwd / bwd device time at several batch sizes (HIP events on the launch stream)."""
+"""Kernel micro-benchmark: pose head fwd / bwd device time per launch (HIP graph of 20 launches, events on the launch
+stream) for both kernel variants at several batch sizes.   python tools/kbench.py [B ...]"""
 import sys, os, ctypes, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pedestrians_video_2_carla_amd import ops, _lib
 
 FWD_B, BWD_B = 18308, 28292   # algorithmic bytes per clip at T=16
+T, J = 16, 26
 
 
-def time_it(fn, iters=50, warm=5):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
+def graph_time(fn, stream, reps=20, rounds=5):
+    fn(); stream.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        for _ in range(reps):
+            fn()
+    g.replay(); stream.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3  # us
+    e0.record(stream)
+    for _ in range(rounds):
+        g.replay()
+    e1.record(stream); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * rounds)
 
 
 def main():
     d = torch.device('cuda:0')
-    kind = sys.argv[1] if len(sys.argv) > 1 else 'pose_changes_6d'
-    spec = ops.PoseHeadSpec(kind=kind)
-    for B in (256, 1024, 8192, 65536):
-        T = 16
+    lib = _lib.lib()
+    Bs = [int(a) for a in sys.argv[1:]] or [256, 1024, 2048, 4096, 8192]
+    stream = torch.cuda.Stream()
+    f32 = dict(dtype=torch.float32, device=d)
+    for B in Bs:
         g = torch.Generator(device=d).manual_seed(1)
-        ny = {'pose_changes_6d': (6,), 'pose_changes': (3, 3), 'absolute_loc': (3,)}[kind]
-        y = torch.randn((B, T, 26) + ny, device=d, generator=g)
+        y = torch.randn(B, T, J, 6, device=d, generator=g)
+        y[..., 0] += 1.5; y[..., 4] += 1.5
         st = torch.randint(0, 4, (B,), device=d, generator=g).int()
-        gt2 = torch.randn(B, T, 26, 2, device=d, generator=g)
-        gt3 = torch.randn(B, T, 26, 3, device=d, generator=g)
-        yr = y.clone().requires_grad_(True)
-        losses, _ = ops.pose_head(yr, spec, st, gt2d=gt2, gt3d=gt3)
-        gl = torch.tensor([0., 0., 1.], device=d)
-
-        def fwd():
-            ops.pose_head(y, spec, st, gt2d=gt2, gt3d=gt3)
-
-        def fb():
-            l, _ = ops.pose_head(yr, spec, st, gt2d=gt2, gt3d=gt3)
-            torch.autograd.backward(l, gl)
-
-        tf = time_it(fwd)
-        tfb = time_it(fb)
-        tb = tfb - tf
-        print(json.dumps(dict(kind=kind, B=B, fwd_us=round(tf, 1), fwd_bwd_us=round(tfb, 1),
-                              fwd_GBps=round(FWD_B * B / tf / 1e3, 1), bwd_GBps=round(BWD_B * B / max(tb, 1e-3) / 1e3, 1),
-                              clips_per_s=round(B / tfb * 1e6))))
+        gt2 = torch.randn(B, T, J, 2, device=d, generator=g)
+        gt3 = torch.randn(B, T, J, 3, device=d, generator=g)
+        spec = ops.PoseHeadSpec(kind='pose_changes_6d')
+        bufs = {'partials': torch.empty(lib.p2c_pose_head_workspace_floats(B), **f32), 'loss_sums': torch.empty(4, **f32),
+                'losses': torch.empty(3, **f32), 'final_rel_rot': torch.empty(B, J, 3, 3, **f32)}
+        desc = ops._fill_desc(spec, y, st, None, None, gt2, gt3, bufs, {})
+        gl = torch.tensor([0.0, 0.0, 1.0], **f32)
+        gy = torch.empty_like(y)
+        for variant, max_b in (('time_parallel', 1 << 30), ('clip_sequential', 0)):
+            prev = lib.p2c_pose_head_set_time_parallel_max_batch(max_b)
+            with torch.cuda.stream(stream):
+                s = stream.cuda_stream
+                tf = graph_time(lambda: _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), s), 'fwd'), stream)
+                tb = graph_time(lambda: _lib.check(lib.p2c_pose_head_bwd(
+                    ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, gy.data_ptr(), s), 'bwd'),
+                    stream)
+            lib.p2c_pose_head_set_time_parallel_max_batch(prev)
+            print(json.dumps(dict(B=B, variant=variant, fwd_us=round(tf, 2), bwd_us=round(tb, 2),
+                                  fwd_GBps=round(FWD_B * B / tf / 1e3, 1), bwd_GBps=round(BWD_B * B / tb / 1e3, 1))))
 
 
 if __name__ == '__main__':
