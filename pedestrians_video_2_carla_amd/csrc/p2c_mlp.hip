@@ -82,35 +82,60 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpArgs a) {
   a.w_image[i] = v;
 }
 
-// Workgroup copy of the packed image HBM -> LDS: 16-byte loads, several in flight per thread; every workgroup starts at
-// a different offset so that the 256 CUs do not ask the L2 for the same line at the same moment.
-__device__ __forceinline__ void stage_image(const MlpArgs &a, float *dst) {
+// Workgroup copy of the packed image HBM -> LDS, split into ISSUE (all global loads of the thread in flight at once:
+// the image was written by another XCD's pack kernel, so every load is an L2 miss of a few thousand cycles -- one such
+// latency is paid, not one per batch) and COMMIT (LDS stores). Every workgroup starts at a different offset so that the
+// 256 CUs do not ask for the same line at the same moment.
+constexpr int STAGE_U = 12;   // float4 per thread and round (one round covers 96 KB with 512 threads)
+struct ImageRegs {
+  f32x4 v[STAGE_U];
+};
+__device__ __forceinline__ int stage_index(int i0, int u, int total4, int rot, int nth, bool &ok) {
+  int i = i0 + u * nth;
+  ok = i < total4;
+  i += rot;
+  i -= (i >= total4) ? total4 : 0;
+  return ok ? i : 0;
+}
+__device__ __forceinline__ void stage_issue(const MlpArgs &a, ImageRegs &r, int base = 0) {
   const int total4 = a.w_total >> 2, nth = blockDim.x;
   const f32x4 *src = reinterpret_cast<const f32x4 *>(a.w_image);
+  const int rot = (int)((blockIdx.x * 2654435761u) % (unsigned)total4);
+#pragma unroll
+  for (int u = 0; u < STAGE_U; ++u) {
+    bool ok;
+    const int i = stage_index(base + threadIdx.x, u, total4, rot, nth, ok);
+    r.v[u] = src[i];
+  }
+}
+__device__ __forceinline__ void stage_commit(const MlpArgs &a, const ImageRegs &r, float *dst, int base = 0) {
+  const int total4 = a.w_total >> 2, nth = blockDim.x;
   f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
   const int rot = (int)((blockIdx.x * 2654435761u) % (unsigned)total4);
-  constexpr int U = 6;
-  for (int i0 = threadIdx.x; i0 < total4; i0 += U * nth) {
-    f32x4 v[U];
-    int idx[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int i = i0 + u * nth + rot;
-      i -= (i >= total4) ? total4 : 0;
-      idx[u] = (i0 + u * nth < total4) ? i : 0;
-      v[u] = src[idx[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (i0 + u * nth < total4) d4[idx[u]] = v[u];
+  for (int u = 0; u < STAGE_U; ++u) {
+    bool ok;
+    const int i = stage_index(base + threadIdx.x, u, total4, rot, nth, ok);
+    if (ok) d4[i] = r.v[u];
+  }
+}
+// images larger than one round (wide custom MLPs): the remaining rounds
+__device__ __forceinline__ void stage_rest(const MlpArgs &a, ImageRegs &r, float *dst) {
+  const int total4 = a.w_total >> 2, per_round = STAGE_U * blockDim.x;
+  for (int base = per_round; base < total4; base += per_round) {
+    stage_issue(a, r, base);
+    stage_commit(a, r, dst, base);
   }
 }
 
 #ifdef P2C_MLP_TRACE   // developer build only (tools/mlptrace.py): shader-clock stamps of workgroup 0
 __device__ unsigned long long g_trace[2][40];
+#ifndef P2C_MLP_TRACE_BLOCK
+#define P2C_MLP_TRACE_BLOCK 0
+#endif
 #define TR(k, i)                                                                      \
   do {                                                                                \
-    if (blockIdx.x == 0 && threadIdx.x == 0) {                                        \
+    if (blockIdx.x == P2C_MLP_TRACE_BLOCK && threadIdx.x == 0) {                                        \
       g_trace[k][i] = __builtin_readcyclecounter();                                   \
       if ((i) == 0 || (i) == 39) g_trace[k][(i) == 0 ? 38 : 37] = wall_clock64();    \
     }                                                                                 \
@@ -124,50 +149,55 @@ struct Lane {
 };
 
 // 16 consecutive rows of a row-major [N][n] HBM matrix (one contiguous span) -> LDS transposed dst[k * TP + sample];
-// rows beyond N read as zero. All loads of a thread are issued before the first LDS store.
-__device__ __forceinline__ void load_tile_T(const float *src, int64_t row0, int64_t N, int n, float *dst, bool vec) {
+// rows beyond N read as zero. ISSUE puts every load of the thread in flight, COMMIT (later, after other work) stores to
+// LDS: the HBM latency of the next tile hides behind the current tile's phases.
+constexpr int TILE_UV = (TS * MAXW / 4 + 64 * WAVES - 1) / (64 * WAVES);   // float4 per thread (vector path)
+constexpr int TILE_US = (TS * MAXW + 64 * WAVES - 1) / (64 * WAVES);       // floats per thread (scalar path)
+static_assert(TILE_US <= 4 * TILE_UV, "scalar path must fit the vector path's registers");
+struct TileRegs {
+  f32x4 v[TILE_UV];   // the scalar path keeps its floats in the same registers (v[u / 4][u % 4])
+};
+__device__ __forceinline__ void tile_issue(const float *src, int64_t row0, int64_t N, int n, bool vec, TileRegs &r) {
   const int64_t left = N - row0;
-  const int valid = (int)(left < TS ? left : TS) * n;      // floats of this tile that exist
+  const int valid = left <= 0 ? 0 : (int)(left < TS ? left : TS) * n;      // floats of this tile that exist
   const float *p = src + row0 * n;
   const int nth = blockDim.x;
   if (vec) {                                               // n % 4 == 0: a float4 never straddles two rows
-    const int total4 = (TS * n) >> 2;
     const f32x4 *p4 = reinterpret_cast<const f32x4 *>(p);
-    constexpr int U = 2;
-    for (int i0 = threadIdx.x; i0 < total4; i0 += U * nth) {
-      f32x4 v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + u * nth;
-        v[u] = (i < total4 && 4 * i < valid) ? p4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+    for (int u = 0; u < TILE_UV; ++u) {
+      const int i = threadIdx.x + u * nth;
+      r.v[u] = (4 * i < valid) ? p4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + u * nth;
-        if (i < total4) {
-          const int e = 4 * i, sidx = e / n, k = e - sidx * n;
+    for (int u = 0; u < TILE_US; ++u) {
+      const int i = threadIdx.x + u * nth;
+      r.v[u >> 2][u & 3] = (i < valid) ? p[i] : 0.f;
+    }
+  }
+}
+__device__ __forceinline__ void tile_commit(int n, bool vec, const TileRegs &r, float *dst) {
+  const int nth = blockDim.x;
+  if (vec) {
+    const int total4 = (TS * n) >> 2;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) dst[(k + j) * TP + sidx] = v[u][j];
-        }
+    for (int u = 0; u < TILE_UV; ++u) {
+      const int i = threadIdx.x + u * nth;
+      if (i < total4) {
+        const int e = 4 * i, sidx = e / n, k = e - sidx * n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(k + j) * TP + sidx] = r.v[u][j];
       }
     }
   } else {
     const int total = TS * n;
-    constexpr int U = 8;
-    for (int i0 = threadIdx.x; i0 < total; i0 += U * nth) {
-      float v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + u * nth;
-        v[u] = (i < valid) ? p[i] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int i = i0 + u * nth;
-        if (i < total) {
-          const int sidx = i / n, k = i - sidx * n;
-          dst[k * TP + sidx] = v[u];
-        }
+    for (int u = 0; u < TILE_US; ++u) {
+      const int i = threadIdx.x + u * nth;
+      if (i < total) {
+        const int sidx = i / n, k = i - sidx * n;
+        dst[k * TP + sidx] = r.v[u >> 2][u & 3];
       }
     }
   }
@@ -191,19 +221,36 @@ __device__ __forceinline__ void layer_forward_nt(const Lane &L, const float *wl,
     ap[h] = wl + ((nt0 + h * WAVES) * 16 + L.c) * ld + L.g;
   }
   const float *bp = in + L.g * TP + L.c;
-  for (int s = 0; s < ksteps; s += 4) {
-    float bv[4], av[NT][4];
+  // Ping-pong software pipeline: the operands of k-group s+1 are in flight while the MFMAs of group s run (ksteps is a
+  // multiple of 4, >= 4). The sched_barriers keep the compiler from sinking the loads below the MFMAs they overlap.
+  float b0[4], a0[NT][4], b1[4], a1[NT][4];
+  auto load = [&](float (&bv)[4], float (&av)[NT][4], int s) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       bv[u] = bp[(s + u) * 4 * TP];
 #pragma unroll
       for (int h = 0; h < NT; ++h) av[h][u] = ap[h][(s + u) * 4];
     }
+  };
+  auto fma4 = [&](const float (&bv)[4], const float (&av)[NT][4]) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
 #pragma unroll
       for (int h = 0; h < NT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][u], bv[u], acc[h], 0, 0, 0);
     }
+  };
+  load(b0, a0, 0);
+  for (int s = 4;; s += 8) {
+    if (s < ksteps) load(b1, a1, s);
+    __builtin_amdgcn_sched_barrier(0);
+    fma4(b0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s >= ksteps) break;
+    if (s + 4 < ksteps) load(b0, a0, s + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    fma4(b1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 4 >= ksteps) break;
   }
 #pragma unroll
   for (int h = 0; h < NT; ++h) {
@@ -250,15 +297,27 @@ __device__ __forceinline__ void layer_dgrad(const Lane &L, const float *wl, int 
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
     const float *a0p = wl + L.g * ld + mt * 16 + L.c;
     const float *bp = gin + L.g * TP + L.c;
-    for (int s = 0; s < ksteps; s += 4) {
-      float bv[4], a0[4];
+    float b0[4], a0[4], b1[4], a1[4];
+    auto load = [&](float (&bv)[4], float (&av)[4], int s) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        bv[u] = bp[(s + u) * 4 * TP];
-        a0[u] = a0p[(s + u) * 4 * ld];
-      }
+      for (int u = 0; u < 4; ++u) bv[u] = bp[(s + u) * 4 * TP], av[u] = a0p[(s + u) * 4 * ld];
+    };
+    auto fma4 = [&](const float (&bv)[4], const float (&av)[4]) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bv[u], c0, 0, 0, 0);
+      for (int u = 0; u < 4; ++u) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], c0, 0, 0, 0);
+    };
+    load(b0, a0, 0);
+    for (int s = 4;; s += 8) {   // same ping-pong pipeline as layer_forward_nt
+      if (s < ksteps) load(b1, a1, s);
+      __builtin_amdgcn_sched_barrier(0);
+      fma4(b0, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s >= ksteps) break;
+      if (s + 4 < ksteps) load(b0, a0, s + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      fma4(b1, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (s + 4 >= ksteps) break;
     }
     const int mb = mt * 16 + 4 * L.g;
 #pragma unroll
@@ -297,20 +356,27 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
   const int nl = a.n_layers;
   TR(0, 0);
   float *H = lds + a.w_total;
-  init_activations(H, a.h_off[nl]);
-  stage_image(a, lds);
+  const int64_t n_tiles = (a.N + TS - 1) / TS;
+  TileRegs xr;
+  {
+    ImageRegs wr;
+    stage_issue(a, wr);
+    tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, a.dims[0], a.vec_x != 0, xr);   // first tile: in flight with the image
+    init_activations(H, a.h_off[nl]);
+    stage_commit(a, wr, lds);
+    stage_rest(a, wr, lds);
+  }
   __syncthreads();
   if (threadIdx.x < TS) H[(a.h_off[0] + a.dims[0]) * TP + threadIdx.x] = 1.f;
   TR(0, 1);
-  const int64_t n_tiles = (a.N + TS - 1) / TS;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * TS, row = row0 + L.c;
     const bool row_ok = row < a.N;
     TR(0, 2);
-    load_tile_T(a.x, row0, a.N, a.dims[0], H + a.h_off[0] * TP, a.vec_x != 0);
-#pragma unroll
-    for (int l = 0; l < NL; ++l) {
-      if (l >= nl) break;
+    tile_commit(a.dims[0], a.vec_x != 0, xr, H + a.h_off[0] * TP);
+    tile_issue(a.x, (tile + gridDim.x) * TS, a.N, a.dims[0], a.vec_x != 0, xr);    // prefetch the next tile of this block
+#pragma unroll 1
+    for (int l = 0; l < nl; ++l) {
       __syncthreads();
       TR(0, 3 + l);
       const bool last = (l == nl - 1);
@@ -337,6 +403,11 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   float *H = lds + a.w_total;
   float *G = H + (a.h_off[nl] - a.h_off[1]) * TP;          // G_l lives at row h_off[l] of this base (l = 1..L)
   int *tab = reinterpret_cast<int *>(H + (a.h_off[nl] + a.act_rows - a.h_off[1]) * TP);
+  TileRegs xr, gr;
+  ImageRegs wr;
+  stage_issue(a, wr);
+  tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, a.dims[0], a.vec_x != 0, xr);
+  tile_issue(a.gy, (int64_t)blockIdx.x * TS, a.N, a.dims[nl], a.vec_gy != 0, gr);
   init_activations(H, a.h_off[nl] + a.act_rows - a.h_off[1]);
   if (threadIdx.x < MAX_SLOTS * WAVES) {   // LDS float offsets of the A (G rows) and B (H rows) fragments of dW tile t
     const int t = threadIdx.x < a.n_tiles_w ? threadIdx.x : 0;
@@ -344,16 +415,11 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
     tab[2 * threadIdx.x] = (a.h_off[nl] - a.h_off[1] + a.h_off[tr.l + 1] + tr.ntile * 16) * TP;   // G rows, H-relative
     tab[2 * threadIdx.x + 1] = (a.h_off[tr.l] + tr.mtile * 16) * TP;
   }
-  stage_image(a, lds);
+  stage_commit(a, wr, lds);
+  stage_rest(a, wr, lds);
   __syncthreads();
   if (threadIdx.x < TS) H[(a.h_off[0] + a.dims[0]) * TP + threadIdx.x] = 1.f;
-  int goff[MAX_SLOTS], hoff[MAX_SLOTS];
-#pragma unroll
-  for (int slot = 0; slot < MAX_SLOTS; ++slot) {
-    const int t = slot * WAVES + L.wave;
-    goff[slot] = tab[2 * t] + L.c * TP + L.g;
-    hoff[slot] = tab[2 * t + 1] + L.c * TP + L.g;
-  }
+  const int lane_off = L.c * TP + L.g;
   TR(1, 1);
 
   f32x4 acc[MAX_SLOTS];
@@ -364,22 +430,22 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * TS;
     __syncthreads();                       // previous tile's dW phase has consumed H and G
-    load_tile_T(a.x, row0, a.N, a.dims[0], H + a.h_off[0] * TP, a.vec_x != 0);
-    load_tile_T(a.gy, row0, a.N, a.dims[nl], G + a.h_off[nl] * TP, a.vec_gy != 0);
+      tile_commit(a.dims[0], a.vec_x != 0, xr, H + a.h_off[0] * TP);
+    tile_commit(a.dims[nl], a.vec_gy != 0, gr, G + a.h_off[nl] * TP);
+      tile_issue(a.x, row0 + (int64_t)gridDim.x * TS, a.N, a.dims[0], a.vec_x != 0, xr);   // prefetch this block's next tile
+    tile_issue(a.gy, row0 + (int64_t)gridDim.x * TS, a.N, a.dims[nl], a.vec_gy != 0, gr);
     // ---- phase F: activations H_1 .. H_{L-1}
     TR(1, 2);
-#pragma unroll
-    for (int l = 0; l < NL - 1; ++l) {
-      if (l >= nl - 1) break;
+#pragma unroll 1
+    for (int l = 0; l < nl - 1; ++l) {
       __syncthreads();
       TR(1, 3 + l);
       layer_forward(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], true, H + a.h_off[l] * TP,
                     H + a.h_off[l + 1] * TP, nullptr, false, false);
     }
     // ---- phase D: G_l = relu'(H_l) .* (W_l^T G_{l+1}), l = L-1 .. 1
-#pragma unroll
-    for (int l = NL - 1; l >= 1; --l) {
-      if (l > nl - 1) continue;
+#pragma unroll 1
+    for (int l = nl - 1; l >= 1; --l) {
       __syncthreads();
       TR(1, 12 + l);
       layer_dgrad(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], G + a.h_off[l + 1] * TP, H + a.h_off[l] * TP,
@@ -391,8 +457,9 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
     // Branch-free: slots past the last tile alias tile 0 and are never written out. Samples beyond N carry G = 0.
 #pragma unroll
     for (int slot = 0; slot < MAX_SLOTS; ++slot) {
-      const float *gp = H + goff[slot];   // A[n][k = sample]   (offsets are relative to H)
-      const float *hp = H + hoff[slot];   // B[k = sample][m]
+      const int t = slot * WAVES + L.wave;
+      const float *gp = H + tab[2 * t] + lane_off;       // A[n][k = sample]   (table offsets are relative to H)
+      const float *hp = H + tab[2 * t + 1] + lane_off;   // B[k = sample][m]
       float av[4], bv[4];
 #pragma unroll
       for (int s = 0; s < TS / 4; ++s) av[s] = gp[4 * s], bv[s] = hp[4 * s];
@@ -422,10 +489,12 @@ __global__ __launch_bounds__(64 * RG) void mlp_reduce_kernel(const MlpArgs a, in
   const f32x4 *p = reinterpret_cast<const f32x4 *>(a.partials) + (size_t)t * 64 + lane;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   int w = q;
-  for (; w + 3 * RG < n_blocks; w += 4 * RG) {
-    const f32x4 v0 = p[(size_t)w * stride], v1 = p[(size_t)(w + RG) * stride], v2 = p[(size_t)(w + 2 * RG) * stride],
-                v3 = p[(size_t)(w + 3 * RG) * stride];
-    s += v0, s += v1, s += v2, s += v3;
+  for (; w + 7 * RG < n_blocks; w += 8 * RG) {     // eight loads in flight, added in workgroup order
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(w + u * RG) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
   }
   for (; w < n_blocks; w += RG) s += p[(size_t)w * stride];
   red[q][lane] = s;

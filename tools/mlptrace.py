@@ -23,8 +23,8 @@ for N in [int(a) for a in sys.argv[1:]] or [16, 4096]:
         t = list(buf[40 * k:40 * k + 40])
         cyc, wall = t[39] - t[0], (t[37] - t[38]) * 10.0       # wall clock: 100 MHz -> ns
         print(f'N={N} {name}: {cyc} cycles, {wall:.0f} ns, {cyc / max(wall, 1):.2f} GHz')
+        order = sorted((v, i) for i, v in enumerate(t[:37]) if v >= t[0] and i > 0) + [(t[39], 39)]
         prev = t[0]
-        for i in list(range(1, 37)) + [39]:
-            if t[i] > prev:
-                print(f'   [{i:2d}] +{t[i] - prev:6d}')
-                prev = t[i]
+        for v, i in order:
+            print(f'   [{i:2d}] +{v - prev:6d}')
+            prev = v
