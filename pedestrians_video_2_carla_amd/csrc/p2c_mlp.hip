@@ -57,6 +57,7 @@ struct MlpArgs {
   int32_t act_rows;              // rows of H_0 .. H_L
   int32_t vec_x, vec_y, vec_gy;  // 16-byte row loads/stores are legal (row length % 4 == 0 and base aligned)
   float *w_image;                // packed, zero-padded weight images in HBM (w_total floats), written by mlp_pack_kernel
+  int32_t tab[2 * MAX_SLOTS * WAVES];   // dW tile t: LDS float offsets (relative to H) of its G rows and its H rows
 };
 
 __device__ __forceinline__ int pad16(int n) { return (n + 15) & ~15; }
@@ -203,10 +204,13 @@ __device__ __forceinline__ void tile_commit(int n, bool vec, const TileRegs &r, 
   }
 }
 
-// zero `rows` activation rows and set the constant-one row of H_0
-__device__ __forceinline__ void init_activations(float *area, int rows) {
-  for (int i = threadIdx.x; i < rows * TP; i += blockDim.x) area[i] = 0.f;
+// Rows of the activation area that are READ but never written by a tile load or a layer epilogue must be finite (they
+// meet zero weights): the padding rows of H_0 behind the x tile (row n0 = the constant one) and, in the backward, the
+// padding rows of the gy tile. Everything else is rewritten for every tile before it is read.
+__device__ __forceinline__ void init_rows(float *area, int row0, int row1, int one_row) {
+  for (int i = row0 * TP + threadIdx.x; i < row1 * TP; i += blockDim.x) area[i] = (i / TP == one_row) ? 1.f : 0.f;
 }
+__device__ __forceinline__ int k_rows(int n_in) { return ((((n_in + 1 + 3) >> 2) + 3) & ~3) * 4; }   // rows the k loop reads
 
 // out^T[n][s] = act( sum_k Waug[n][k] in^T_aug[k][s] ) for NT output tiles of this wave (nt0, nt0 + WAVES)
 template <int NT>
@@ -352,7 +356,7 @@ __device__ __forceinline__ TileRef locate_tile(const int32_t *dims, int t) {
 __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
   Lane L;
-  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = threadIdx.x >> 6;
+  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: tile offsets run on the scalar unit
   const int nl = a.n_layers;
   TR(0, 0);
   float *H = lds + a.w_total;
@@ -362,12 +366,10 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
     ImageRegs wr;
     stage_issue(a, wr);
     tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, a.dims[0], a.vec_x != 0, xr);   // first tile: in flight with the image
-    init_activations(H, a.h_off[nl]);
+    init_rows(H, a.h_off[0] + a.dims[0], a.h_off[0] + k_rows(a.dims[0]), a.h_off[0] + a.dims[0]);
     stage_commit(a, wr, lds);
     stage_rest(a, wr, lds);
   }
-  __syncthreads();
-  if (threadIdx.x < TS) H[(a.h_off[0] + a.dims[0]) * TP + threadIdx.x] = 1.f;
   TR(0, 1);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * TS, row = row0 + L.c;
@@ -397,28 +399,20 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
 __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
   Lane L;
-  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = threadIdx.x >> 6;
+  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: tile offsets run on the scalar unit
   const int nl = a.n_layers;
   TR(1, 0);
   float *H = lds + a.w_total;
   float *G = H + (a.h_off[nl] - a.h_off[1]) * TP;          // G_l lives at row h_off[l] of this base (l = 1..L)
-  int *tab = reinterpret_cast<int *>(H + (a.h_off[nl] + a.act_rows - a.h_off[1]) * TP);
   TileRegs xr, gr;
   ImageRegs wr;
   stage_issue(a, wr);
   tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, a.dims[0], a.vec_x != 0, xr);
   tile_issue(a.gy, (int64_t)blockIdx.x * TS, a.N, a.dims[nl], a.vec_gy != 0, gr);
-  init_activations(H, a.h_off[nl] + a.act_rows - a.h_off[1]);
-  if (threadIdx.x < MAX_SLOTS * WAVES) {   // LDS float offsets of the A (G rows) and B (H rows) fragments of dW tile t
-    const int t = threadIdx.x < a.n_tiles_w ? threadIdx.x : 0;
-    const TileRef tr = locate_tile(a.dims, t);
-    tab[2 * threadIdx.x] = (a.h_off[nl] - a.h_off[1] + a.h_off[tr.l + 1] + tr.ntile * 16) * TP;   // G rows, H-relative
-    tab[2 * threadIdx.x + 1] = (a.h_off[tr.l] + tr.mtile * 16) * TP;
-  }
+  init_rows(H, a.h_off[0] + a.dims[0], a.h_off[0] + k_rows(a.dims[0]), a.h_off[0] + a.dims[0]);
+  init_rows(G, a.h_off[nl] + a.dims[nl], a.h_off[nl] + pad16(a.dims[nl]), -1);
   stage_commit(a, wr, lds);
   stage_rest(a, wr, lds);
-  __syncthreads();
-  if (threadIdx.x < TS) H[(a.h_off[0] + a.dims[0]) * TP + threadIdx.x] = 1.f;
   const int lane_off = L.c * TP + L.g;
   TR(1, 1);
 
@@ -458,8 +452,8 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
 #pragma unroll
     for (int slot = 0; slot < MAX_SLOTS; ++slot) {
       const int t = slot * WAVES + L.wave;
-      const float *gp = H + tab[2 * t] + lane_off;       // A[n][k = sample]   (table offsets are relative to H)
-      const float *hp = H + tab[2 * t + 1] + lane_off;   // B[k = sample][m]
+      const float *gp = H + a.tab[2 * t] + lane_off;       // A[n][k = sample]   (scalar loads from the kernel arguments)
+      const float *hp = H + a.tab[2 * t + 1] + lane_off;   // B[k = sample][m]
       float av[4], bv[4];
 #pragma unroll
       for (int s = 0; s < TS / 4; ++s) av[s] = gp[4 * s], bv[s] = hp[4 * s];
@@ -553,6 +547,19 @@ static int fill(MlpArgs &a, const p2c_mlp_desc *d) {
   a.n_tiles_w = tiles;
   a.n_params = params;
   a.w_total = (wtot + 3) & ~3;
+  if (tiles <= MAX_SLOTS * WAVES) {   // slots past the last tile alias tile 0 (computed, never written out)
+    const int nl = d->n_layers;
+    int t = 0;
+    for (int l = 0; l < nl; ++l) {
+      const int ntl = (a.dims[l + 1] + 15) / 16, mtl = (a.dims[l] + 1 + 15) / 16;
+      for (int nt = 0; nt < ntl; ++nt)
+        for (int mt = 0; mt < mtl; ++mt, ++t) {
+          a.tab[2 * t] = (a.h_off[nl] - a.h_off[1] + a.h_off[l + 1] + nt * 16) * TP;   // G rows live behind the H area
+          a.tab[2 * t + 1] = (a.h_off[l] + mt * 16) * TP;
+        }
+    }
+    for (; t < MAX_SLOTS * WAVES; ++t) a.tab[2 * t] = a.tab[0], a.tab[2 * t + 1] = a.tab[1];
+  }
   const int n0 = a.dims[0], nL = a.dims[d->n_layers];
   a.vec_x = (n0 % 4 == 0) && aligned16(a.x);
   a.vec_y = (nL % 4 == 0) && aligned16(a.y);
@@ -562,8 +569,7 @@ static int fill(MlpArgs &a, const p2c_mlp_desc *d) {
 
 static size_t lds_fwd(const MlpArgs &a) { return ((size_t)a.w_total + (size_t)a.h_off[a.n_layers] * TP) * sizeof(float); }
 static size_t lds_bwd(const MlpArgs &a) {
-  return ((size_t)a.w_total + (size_t)(a.h_off[a.n_layers] + a.act_rows - a.h_off[1]) * TP) * sizeof(float) +
-         2 * MAX_SLOTS * WAVES * sizeof(int);
+  return ((size_t)a.w_total + (size_t)(a.h_off[a.n_layers] + a.act_rows - a.h_off[1]) * TP) * sizeof(float);
 }
 
 static void allow_big_lds() {
