@@ -11,6 +11,7 @@ on ~12-100 small tensors, parameter broadcast at wrap time (SURVEY.md §2 rows 2
   * the optimizer runs on the flat parameter as a single tensor (AdamW is element-wise, so the update is identical),
     i.e. one fused kernel instead of a multi-tensor loop.
 """
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -70,7 +71,11 @@ class GradientExchange:
         self.flat = flat
         self.group = process_group
         self.average_here = True        # False: the optimizer kernel applies the 1/world factor (FlatAdamW.grad_scale)
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        initialised = dist.is_available() and dist.is_initialized()
+        # P2C_FORCE_EXCHANGE=1 keeps the collective (and the two-graph step) with a single rank: lets the one-GPU box
+        # exercise exactly the code path the multi-GPU runs take
+        forced = initialised and os.environ.get('P2C_FORCE_EXCHANGE', '0') == '1'
+        self.enabled = initialised and (dist.get_world_size(process_group) > 1 or forced)
         self.world = dist.get_world_size(process_group) if self.enabled else 1
 
     def broadcast_parameters(self, src: int = 0):

@@ -33,7 +33,8 @@ def init_distributed(backend: Optional[str] = None) -> Dict[str, int]:
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    forced = os.environ.get('P2C_FORCE_EXCHANGE', '0') == '1' and 'RANK' in os.environ   # one-rank rehearsal of the DP path
+    if (world > 1 or forced) and not dist.is_initialized():
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # "nccl" IS RCCL on ROCm
         if backend == 'nccl':

@@ -1,0 +1,42 @@
+"""The multi-GPU step on the one-GPU box: RCCL process group of ONE rank with the gradient exchange forced on, so the
+two-graph step (graph A: forward + backward -> eager RCCL all-reduce of the flat gradient buffer -> graph B: FlatAdamW with
+the 1/world factor folded in) runs exactly as it does with 2..8 ranks. With one rank the all-reduce is the identity, so the
+loss curve must equal the single-graph trainer's."""
+import os
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_graph_step_with_rccl_matches_single_graph_step(monkeypatch):
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    from test_flow_gpu import make
+    from pedestrians_video_2_carla_amd.trainer import Trainer
+    d = torch.device('cuda:0')
+    torch.cuda.set_device(d)
+    steps = 12
+    flow_a, dm = make(B=16, missing=0.0)
+    flow_b, _ = make(B=16, missing=0.0)
+    batch = dm.generate_batch(d)
+    ta = Trainer(device=d, use_graph=True).setup(flow_a, dm)
+    single = torch.stack([ta.train_step(flow_a, batch, i).clone() for i in range(steps)]).cpu()
+
+    monkeypatch.setenv('P2C_FORCE_EXCHANGE', '1')
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', '29533')
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        tb = Trainer(device=d, use_graph=True).setup(flow_b, dm)
+        assert tb.exchange.enabled and tb.exchange.world == 1 and not tb.exchange.average_here
+        multi = torch.stack([tb.train_step(flow_b, batch, i).clone() for i in range(steps)]).cpu()
+        assert tb._graphs[1] is not None, 'distributed step = two graphs with the collective between them'
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(single, multi), (single, multi)
+    pa = torch.cat([p.detach().reshape(-1) for p in flow_a.parameters()])
+    pb = torch.cat([p.detach().reshape(-1) for p in flow_b.parameters()])
+    assert torch.equal(pa, pb)
