@@ -22,6 +22,7 @@
 //     tiles of dW_aug = G^T [H | 1] and keep them in MFMA accumulators across the persistent tile loop; per-workgroup
 //     partials are reduced in fixed order (bitwise reproducible, no atomics).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "../../include/p2c.h"
@@ -33,8 +34,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MAXW = 160;        // widest layer (padded to 16)
 constexpr int TS = 16;           // samples per tile
 constexpr int TP = 17;           // LDS pitch of an activation row (odd: the dW phase reads [row = lane&15][sample])
-constexpr int WAVES = 8;         // waves per workgroup
-constexpr int MAX_SLOTS = 12;    // dW tiles per wave held in accumulators
+#ifndef P2C_MLP_WAVES
+#define P2C_MLP_WAVES 8
+#endif
+constexpr int WAVES = P2C_MLP_WAVES;     // waves per workgroup
+constexpr int MAX_SLOTS = 96 / WAVES;    // dW tiles per wave held in accumulators (96 tiles in all)
 constexpr int NL = P2C_MLP_MAX_LAYERS;
 
 struct MlpArgs {
@@ -60,7 +64,92 @@ struct MlpArgs {
   int32_t tab[2 * MAX_SLOTS * WAVES];   // dW tile t: LDS float offsets (relative to H) of its G rows and its H rows
 };
 
-__device__ __forceinline__ int pad16(int n) { return (n + 15) & ~15; }
+__host__ __device__ constexpr int pad16(int n) { return (n + 15) & ~15; }
+// layout rules shared by the host (fill) and by the compile-time shapes below
+__host__ __device__ constexpr int ld_of(int n_in) {          // LDS pitch of the image of a layer with n_in inputs
+  int ld = ((((n_in + 1 + 3) >> 2) + 3) & ~3) * 4;          // k extent incl. the bias column, in 4-step blocks
+  if (ld < pad16(n_in)) ld = pad16(n_in);                    // dgrad reads columns up to pad16(n_in)
+  while ((ld & 3) != 2) ++ld;                                // pitch == 2 (mod 4)
+  return ld;
+}
+__host__ __device__ constexpr int img_rows_of(int n_out) { return (n_out + 16) & ~15; }   // rows 0..n_out (unit row), padded
+__host__ __device__ constexpr int act_rows_of(int n) { return pad16(n) + 16; }            // ones row / k rounding past pad16
+
+// Shape providers. DynShape reads the layer geometry from the kernel arguments (any MLP the ABI accepts); StaticShape
+// carries it in the type, so that with the layer loops unrolled every pitch, offset and trip count is an immediate:
+// the integer address arithmetic that otherwise dominates these latency-bound kernels disappears.
+struct DynShape {
+  static constexpr bool kStatic = false;
+  const MlpArgs &a;
+  __device__ explicit DynShape(const MlpArgs &args) : a(args) {}
+  __device__ int n_layers() const { return a.n_layers; }
+  __device__ int dims(int l) const { return a.dims[l]; }
+  __device__ int ld(int l) const { return a.ld[l]; }
+  __device__ int w_off(int l) const { return a.w_off[l]; }
+  __device__ int w_total() const { return a.w_total; }
+  __device__ int h_off(int l) const { return a.h_off[l]; }
+  __device__ int act_rows() const { return a.act_rows; }
+};
+template <int... D>
+struct StaticShape {
+  static constexpr bool kStatic = true;
+  static constexpr int NLAY = (int)sizeof...(D) - 1;
+  __device__ explicit StaticShape(const MlpArgs &) {}
+  __host__ __device__ static constexpr int dim_at(int l) {
+    constexpr int d[] = {D...};
+    return d[l];
+  }
+  __host__ __device__ static constexpr int n_layers() { return NLAY; }
+  __host__ __device__ static constexpr int dims(int l) { return dim_at(l); }
+  __host__ __device__ static constexpr int ld(int l) { return ld_of(dim_at(l)); }
+  __host__ __device__ static constexpr int w_off(int l) {
+    int o = 0;
+    for (int i = 0; i < l; ++i) o += img_rows_of(dim_at(i + 1)) * ld_of(dim_at(i));
+    return o;
+  }
+  __host__ __device__ static constexpr int w_total() { return (w_off(NLAY) + 3) & ~3; }
+  __host__ __device__ static constexpr int h_off(int l) {
+    int r = 0;
+    for (int i = 0; i < l; ++i) r += act_rows_of(dim_at(i));
+    return r;
+  }
+  __host__ __device__ static constexpr int act_rows() { return h_off(NLAY + 1); }
+  static bool matches(const MlpArgs &a) {
+    if (a.n_layers != NLAY) return false;
+    for (int l = 0; l <= NLAY; ++l)
+      if (a.dims[l] != dim_at(l)) return false;
+    return true;
+  }
+};
+// the LinearAE of the reference (linear_ae.py:25-59): 26 joints x 2 in; 26 x {6, 3, 2} out (pose_changes 6-D, absolute_loc,
+// pose_2d)
+using LinearAE156 = StaticShape<52, 26, 13, 6, 39, 78, 156>;
+using LinearAE78 = StaticShape<52, 26, 13, 6, 19, 39, 78>;
+using LinearAE52 = StaticShape<52, 26, 13, 6, 13, 26, 52>;
+
+// layer loop: fully unrolled for a static shape, a plain loop otherwise
+template <class S, class F>
+__device__ __forceinline__ void for_layers(const S &shape, int first, int last_exclusive, F &&f) {
+  if constexpr (S::kStatic) {
+#pragma unroll
+    for (int l = 0; l < S::NLAY; ++l)
+      if (l >= first && l < last_exclusive) f(l);
+  } else {
+#pragma unroll 1
+    for (int l = first; l < last_exclusive; ++l) f(l);
+  }
+}
+template <class S, class F>
+__device__ __forceinline__ void for_layers_down(const S &shape, int first, int last_inclusive, F &&f) {   // first >= last
+  if constexpr (S::kStatic) {
+#pragma unroll
+    for (int l = S::NLAY - 1; l >= 0; --l)
+      if (l <= first && l >= last_inclusive) f(l);
+  } else {
+#pragma unroll 1
+    for (int l = first; l >= last_inclusive; --l) f(l);
+  }
+}
 
 // Pack kernel (once per forward): the zero-padded image of every [W_l | b_l] -- rows 0..rows_l-1, pitch ld_l, bias in
 // column n_in, and a unit row n_out that copies the constant-one input row to the output (so that the next layer finds
@@ -98,8 +187,8 @@ __device__ __forceinline__ int stage_index(int i0, int u, int total4, int rot, i
   i -= (i >= total4) ? total4 : 0;
   return ok ? i : 0;
 }
-__device__ __forceinline__ void stage_issue(const MlpArgs &a, ImageRegs &r, int base = 0) {
-  const int total4 = a.w_total >> 2, nth = blockDim.x;
+__device__ __forceinline__ void stage_issue(const MlpArgs &a, int total4, ImageRegs &r, int base = 0) {
+  const int nth = blockDim.x;
   const f32x4 *src = reinterpret_cast<const f32x4 *>(a.w_image);
   const int rot = (int)((blockIdx.x * 2654435761u) % (unsigned)total4);
 #pragma unroll
@@ -109,8 +198,8 @@ __device__ __forceinline__ void stage_issue(const MlpArgs &a, ImageRegs &r, int 
     r.v[u] = src[i];
   }
 }
-__device__ __forceinline__ void stage_commit(const MlpArgs &a, const ImageRegs &r, float *dst, int base = 0) {
-  const int total4 = a.w_total >> 2, nth = blockDim.x;
+__device__ __forceinline__ void stage_commit(int total4, const ImageRegs &r, float *dst, int base = 0) {
+  const int nth = blockDim.x;
   f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
   const int rot = (int)((blockIdx.x * 2654435761u) % (unsigned)total4);
 #pragma unroll
@@ -121,11 +210,11 @@ __device__ __forceinline__ void stage_commit(const MlpArgs &a, const ImageRegs &
   }
 }
 // images larger than one round (wide custom MLPs): the remaining rounds
-__device__ __forceinline__ void stage_rest(const MlpArgs &a, ImageRegs &r, float *dst) {
-  const int total4 = a.w_total >> 2, per_round = STAGE_U * blockDim.x;
+__device__ __forceinline__ void stage_rest(const MlpArgs &a, int total4, ImageRegs &r, float *dst) {
+  const int per_round = STAGE_U * blockDim.x;
   for (int base = per_round; base < total4; base += per_round) {
-    stage_issue(a, r, base);
-    stage_commit(a, r, dst, base);
+    stage_issue(a, total4, r, base);
+    stage_commit(total4, r, dst, base);
   }
 }
 
@@ -353,39 +442,42 @@ __device__ __forceinline__ TileRef locate_tile(const int32_t *dims, int t) {
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
 // LDS: [weight images | H_0 .. H_{L-1}]   (the input rows of layer l are H_l, its output H_{l+1})
+template <class S>
 __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
+  const S sh(a);
   Lane L;
-  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: tile offsets run on the scalar unit
-  const int nl = a.n_layers;
+  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4;
+  L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: tile offsets run on the scalar unit
+  const int nl = sh.n_layers();
+  const int total4 = sh.w_total() >> 2;
   TR(0, 0);
-  float *H = lds + a.w_total;
+  float *H = lds + sh.w_total();
   const int64_t n_tiles = (a.N + TS - 1) / TS;
   TileRegs xr;
   {
     ImageRegs wr;
-    stage_issue(a, wr);
-    tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, a.dims[0], a.vec_x != 0, xr);   // first tile: in flight with the image
-    init_rows(H, a.h_off[0] + a.dims[0], a.h_off[0] + k_rows(a.dims[0]), a.h_off[0] + a.dims[0]);
-    stage_commit(a, wr, lds);
-    stage_rest(a, wr, lds);
+    stage_issue(a, total4, wr);
+    tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // first tile: in flight with the image
+    init_rows(H, sh.h_off(0) + sh.dims(0), sh.h_off(0) + k_rows(sh.dims(0)), sh.h_off(0) + sh.dims(0));
+    stage_commit(total4, wr, lds);
+    stage_rest(a, total4, wr, lds);
   }
   TR(0, 1);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * TS, row = row0 + L.c;
     const bool row_ok = row < a.N;
     TR(0, 2);
-    tile_commit(a.dims[0], a.vec_x != 0, xr, H + a.h_off[0] * TP);
-    tile_issue(a.x, (tile + gridDim.x) * TS, a.N, a.dims[0], a.vec_x != 0, xr);    // prefetch the next tile of this block
-#pragma unroll 1
-    for (int l = 0; l < nl; ++l) {
+    tile_commit(sh.dims(0), a.vec_x != 0, xr, H + sh.h_off(0) * TP);
+    tile_issue(a.x, (tile + gridDim.x) * TS, a.N, sh.dims(0), a.vec_x != 0, xr);    // prefetch the next tile of this block
+    for_layers(sh, 0, nl, [&](int l) {
       __syncthreads();
       TR(0, 3 + l);
       const bool last = (l == nl - 1);
-      layer_forward(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], !last, H + a.h_off[l] * TP,
-                    last ? nullptr : H + a.h_off[l + 1] * TP, last ? a.y + row * a.dims[l + 1] : nullptr, row_ok,
+      layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), !last, H + sh.h_off(l) * TP,
+                    last ? nullptr : H + sh.h_off(l + 1) * TP, last ? a.y + row * sh.dims(l + 1) : nullptr, row_ok,
                     a.vec_y != 0);
-    }
+    });
     TR(0, 12);
     // the next tile's x rows overwrite H_0 only after every wave has passed layer 0's barrier chain: the barrier of
     // layer 1 (or, for a single layer, the one below) orders them
@@ -395,24 +487,30 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
-// LDS: [weight images | H_0 .. H_{L-1} | G_1 .. G_L (G_L = gy tile) | dW tile table]
+// LDS: [weight images | H_0 .. H_{L-1} | G_1 .. G_L (G_L = gy tile)]
+template <class S>
 __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
+  const S sh(a);
   Lane L;
-  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: tile offsets run on the scalar unit
-  const int nl = a.n_layers;
+  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4;
+  L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // in an SGPR: tile offsets run on the scalar unit
+  const int nl = sh.n_layers();
+  const int total4 = sh.w_total() >> 2;
   TR(1, 0);
-  float *H = lds + a.w_total;
-  float *G = H + (a.h_off[nl] - a.h_off[1]) * TP;          // G_l lives at row h_off[l] of this base (l = 1..L)
+  float *H = lds + sh.w_total();
+  float *G = H + (sh.h_off(nl) - sh.h_off(1)) * TP;          // G_l lives at row h_off(l) of this base (l = 1..L)
   TileRegs xr, gr;
-  ImageRegs wr;
-  stage_issue(a, wr);
-  tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, a.dims[0], a.vec_x != 0, xr);
-  tile_issue(a.gy, (int64_t)blockIdx.x * TS, a.N, a.dims[nl], a.vec_gy != 0, gr);
-  init_rows(H, a.h_off[0] + a.dims[0], a.h_off[0] + k_rows(a.dims[0]), a.h_off[0] + a.dims[0]);
-  init_rows(G, a.h_off[nl] + a.dims[nl], a.h_off[nl] + pad16(a.dims[nl]), -1);
-  stage_commit(a, wr, lds);
-  stage_rest(a, wr, lds);
+  {
+    ImageRegs wr;
+    stage_issue(a, total4, wr);
+    tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);
+    tile_issue(a.gy, (int64_t)blockIdx.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr);
+    init_rows(H, sh.h_off(0) + sh.dims(0), sh.h_off(0) + k_rows(sh.dims(0)), sh.h_off(0) + sh.dims(0));
+    init_rows(G, sh.h_off(nl) + sh.dims(nl), sh.h_off(nl) + pad16(sh.dims(nl)), -1);
+    stage_commit(total4, wr, lds);
+    stage_rest(a, total4, wr, lds);
+  }
   const int lane_off = L.c * TP + L.g;
   TR(1, 1);
 
@@ -424,27 +522,25 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * TS;
     __syncthreads();                       // previous tile's dW phase has consumed H and G
-      tile_commit(a.dims[0], a.vec_x != 0, xr, H + a.h_off[0] * TP);
-    tile_commit(a.dims[nl], a.vec_gy != 0, gr, G + a.h_off[nl] * TP);
-      tile_issue(a.x, row0 + (int64_t)gridDim.x * TS, a.N, a.dims[0], a.vec_x != 0, xr);   // prefetch this block's next tile
-    tile_issue(a.gy, row0 + (int64_t)gridDim.x * TS, a.N, a.dims[nl], a.vec_gy != 0, gr);
+    tile_commit(sh.dims(0), a.vec_x != 0, xr, H + sh.h_off(0) * TP);
+    tile_commit(sh.dims(nl), a.vec_gy != 0, gr, G + sh.h_off(nl) * TP);
+    tile_issue(a.x, row0 + (int64_t)gridDim.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // prefetch this block's next tile
+    tile_issue(a.gy, row0 + (int64_t)gridDim.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr);
     // ---- phase F: activations H_1 .. H_{L-1}
     TR(1, 2);
-#pragma unroll 1
-    for (int l = 0; l < nl - 1; ++l) {
+    for_layers(sh, 0, nl - 1, [&](int l) {
       __syncthreads();
       TR(1, 3 + l);
-      layer_forward(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], true, H + a.h_off[l] * TP,
-                    H + a.h_off[l + 1] * TP, nullptr, false, false);
-    }
+      layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), true, H + sh.h_off(l) * TP,
+                    H + sh.h_off(l + 1) * TP, nullptr, false, false);
+    });
     // ---- phase D: G_l = relu'(H_l) .* (W_l^T G_{l+1}), l = L-1 .. 1
-#pragma unroll 1
-    for (int l = nl - 1; l >= 1; --l) {
+    for_layers_down(sh, nl - 1, 1, [&](int l) {
       __syncthreads();
       TR(1, 12 + l);
-      layer_dgrad(L, lds + a.w_off[l], a.ld[l], a.dims[l], a.dims[l + 1], G + a.h_off[l + 1] * TP, H + a.h_off[l] * TP,
-                  G + a.h_off[l] * TP);
-    }
+      layer_dgrad(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), G + sh.h_off(l + 1) * TP, H + sh.h_off(l) * TP,
+                  G + sh.h_off(l) * TP);
+    });
     __syncthreads();
     TR(1, 22);
     // ---- phase W: dW_aug_l[n][m] += sum_s G_{l+1}^T[n][s] * H_l^T_aug[m][s]; tile t = slot * WAVES + wave.
@@ -468,7 +564,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
 #pragma unroll
   for (int slot = 0; slot < MAX_SLOTS; ++slot) {
     const int t = slot * WAVES + L.wave;
-    if (t < a.n_tiles_w) part[t * 64 + L.lane] = acc[slot];
+    if (t < a.n_tiles_w) __builtin_nontemporal_store(acc[slot], &part[t * 64 + L.lane]);   // streamed: read once, by another kernel
   }
   TR(1, 39);
 }
@@ -527,21 +623,17 @@ static int fill(MlpArgs &a, const p2c_mlp_desc *d) {
     if (d->dims[l] < 1 || d->dims[l] > MAXW - 1) return P2C_E_SHAPE;
     a.dims[l] = d->dims[l];
     a.h_off[l] = rows;
-    rows += ((a.dims[l] + 15) & ~15) + 16;     // room for the ones row / the 4-step k rounding past pad16
+    rows += act_rows_of(a.dims[l]);            // room for the ones row / the 4-step k rounding past pad16
   }
   for (int l = 0; l < d->n_layers; ++l) {
     if (!d->W[l] || !d->b[l]) return P2C_E_NULL;
     a.W[l] = d->W[l], a.b[l] = d->b[l], a.gW[l] = d->gW[l], a.gb[l] = d->gb[l];
     tiles += ((a.dims[l + 1] + 15) / 16) * ((a.dims[l] + 1 + 15) / 16);
     params += a.dims[l + 1] * (a.dims[l] + 1);
-    int ld = ((((a.dims[l] + 1 + 3) >> 2) + 3) & ~3) * 4;      // k extent incl. the bias column, in 4-step blocks
-    int p16 = (a.dims[l] + 15) & ~15;                          // dgrad reads columns up to pad16(n_in)
-    if (ld < p16) ld = p16;
-    while ((ld & 3) != 2) ++ld;                                // pitch == 2 (mod 4)
-    a.ld[l] = ld;
+    a.ld[l] = ld_of(a.dims[l]);
     a.w_off[l] = wtot;
     // rows: forward tiles cover 0..n_out (unit row), dgrad k-steps cover up to pad16(n_out)
-    wtot += (((a.dims[l + 1] + 16) & ~15)) * ld;
+    wtot += img_rows_of(a.dims[l + 1]) * a.ld[l];
   }
   a.act_rows = rows;
   a.n_tiles_w = tiles;
@@ -572,17 +664,52 @@ static size_t lds_bwd(const MlpArgs &a) {
   return ((size_t)a.w_total + (size_t)(a.h_off[a.n_layers] + a.act_rows - a.h_off[1]) * TP) * sizeof(float);
 }
 
+// Kernel selection: the LinearAE shapes of the reference get the instantiations with compile-time geometry; every other
+// MLP (and P2C_MLP_GENERIC=1, for tests) the generic ones. Same algorithm, same arithmetic order, same results.
+typedef void (*mlp_kernel_t)(const MlpArgs);
+static bool force_generic() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("P2C_MLP_GENERIC");
+    v = (e && atoi(e)) ? 1 : 0;
+  }
+  return v == 1;
+}
+template <class S>
+static void allow_big_lds_for() {
+  (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 static void allow_big_lds() {
   static bool done = false;
   if (done) return;
-  (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  allow_big_lds_for<DynShape>();
+  allow_big_lds_for<LinearAE156>();
+  allow_big_lds_for<LinearAE78>();
+  allow_big_lds_for<LinearAE52>();
   done = true;
 }
+static mlp_kernel_t pick(const MlpArgs &a, bool bwd) {
+  if (!force_generic()) {
+    if (LinearAE156::matches(a)) return bwd ? mlp_bwd_kernel<LinearAE156> : mlp_fwd_kernel<LinearAE156>;
+    if (LinearAE78::matches(a)) return bwd ? mlp_bwd_kernel<LinearAE78> : mlp_fwd_kernel<LinearAE78>;
+    if (LinearAE52::matches(a)) return bwd ? mlp_bwd_kernel<LinearAE52> : mlp_fwd_kernel<LinearAE52>;
+  }
+  return bwd ? mlp_bwd_kernel<DynShape> : mlp_fwd_kernel<DynShape>;
+}
 
+static int max_blocks() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("P2C_MLP_MAX_BLOCKS");
+    v = e ? atoi(e) : 256;
+  }
+  return v;
+}
 static inline int n_blocks(int64_t N) {
   int64_t n_tiles = (N + TS - 1) / TS;
-  return (int)(n_tiles < 256 ? (n_tiles < 1 ? 1 : n_tiles) : 256);   // persistent: one workgroup per CU
+  const int cap = max_blocks();
+  return (int)(n_tiles < cap ? (n_tiles < 1 ? 1 : n_tiles) : cap);   // persistent: one workgroup per CU
 }
 
 #ifdef P2C_MLP_TRACE
@@ -613,7 +740,7 @@ extern "C" int p2c_mlp_fwd(const p2c_mlp_desc *d, void *stream_) {
   if (lds > 160 * 1024) return P2C_E_SHAPE;
   allow_big_lds();
   hipLaunchKernelGGL(mlp_pack_kernel, dim3((a.w_total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
-  hipLaunchKernelGGL(mlp_fwd_kernel, dim3(n_blocks(a.N)), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+  hipLaunchKernelGGL(pick(a, false), dim3(n_blocks(a.N)), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -630,7 +757,7 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   if (lds > 160 * 1024) return P2C_E_SHAPE;
   const int blocks = n_blocks(a.N);
   allow_big_lds();
-  hipLaunchKernelGGL(mlp_bwd_kernel, dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+  hipLaunchKernelGGL(pick(a, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
   hipLaunchKernelGGL(mlp_reduce_kernel, dim3(a.n_tiles_w), dim3(64 * RG), 0, (hipStream_t)stream_, a, blocks);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

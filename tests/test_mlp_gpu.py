@@ -72,3 +72,29 @@ def test_fused_mlp_other_widths():
         for p, q in zip(seq.parameters(), ref.parameters()):
             close(p.grad, q.grad, f'grad {dims}')
     assert not ops.mlp_supported([52, 200, 10])
+
+
+def test_static_and_generic_kernels_agree_on_the_linear_ae_shape():
+    """The LinearAE shapes run instantiations with compile-time geometry; P2C_MLP_GENERIC=1 (read once per process, so a
+    child process) forces the generic kernels. Same algorithm, same arithmetic order: results must be bit-identical."""
+    import os, subprocess, sys
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from pedestrians_video_2_carla_amd import ops\n"
+        "d = torch.device('cuda:0'); torch.manual_seed(5)\n"
+        "dims = [52, 26, 13, 6, 39, 78, 156]\n"
+        "Ws = [(torch.randn(o, i, device=d) * 0.2).requires_grad_(True) for i, o in zip(dims[:-1], dims[1:])]\n"
+        "bs = [(torch.randn(o, device=d) * 0.2).requires_grad_(True) for o in dims[1:]]\n"
+        "x = torch.randn(1000, 52, device=d)\n"
+        "y = ops.fused_mlp(x, Ws, bs); y.square().sum().backward()\n"
+        "out = torch.cat([y.detach().reshape(-1)] + [p.grad.reshape(-1) for p in Ws + bs])\n"
+        "torch.save(out.cpu(), sys.argv[1])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = []
+    for generic in ('0', '1'):
+        with tempfile.NamedTemporaryFile(suffix='.pt') as f:
+            env = dict(os.environ, P2C_MLP_GENERIC=generic)
+            subprocess.run([sys.executable, '-c', code, f.name], check=True, env=env, timeout=300)
+            outs.append(torch.load(f.name))
+    assert torch.equal(outs[0], outs[1])
