@@ -115,6 +115,10 @@ P2C_API int64_t p2c_pose_head_workspace_floats(int32_t B);
  * T <= 32), larger ones the clip-sequential kernels. Both compute the same function (fp32 rounding order differs in the
  * cumulative rotation product). max_b < 0 only queries. Returns the previous value. */
 P2C_API int p2c_pose_head_set_time_parallel_max_batch(int32_t max_b);
+/* Experimental, off by default (min_b = 2^30; env P2C_PK_MIN_B): batches of at least `min_b` clips of the same
+ * configuration without world motion run the packed-fp32 clip-sequential kernels (two clips per lane, v_pk_fma_f32) --
+ * parity-tested, currently slower than the scalar kernels. min_b < 0 only queries. */
+P2C_API int p2c_pose_head_set_packed_min_batch(int32_t min_b);
 
 /* Forward: fills loss_sums, losses, final_rel_rot and any non-NULL out_* tensor. Two launches on `stream`
  * (pose head + deterministic reduction of the per-wave partial sums). */

@@ -1113,6 +1113,8 @@ __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_p
   }
 }
 
+#include "p2c_pose_head_pk.inc"
+
 // =====================================================================================================================
 // absolute_loc kind (projection.py:125-136 + reference_skeletons_denormalizer.py:67-91)
 //   x^ = nan_to_zero((y - y[hips]) / |y[neck] - y[hips]|) ;  abs_loc = x^ * s_ref + h_ref
@@ -1285,6 +1287,32 @@ extern "C" int p2c_pose_head_set_time_parallel_max_batch(int32_t max_b) {
 static inline bool use_tp(const p2c_pose_head_desc &d) {
   return (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D) && d.T <= 32 && d.B <= tp_max_b();
 }
+// EXPERIMENTAL, off by default: the packed-fp32 kernels (two clips per lane, p2c_pose_head_pk.inc) for large batches of the
+// training configuration (6-D kinds, lean outputs, no world motion, no external gradients). They halve the FP instruction
+// count but not the cross-lane / register-pairing moves and run at 2-3 waves per SIMD: measured 370 vs 324 us (forward)
+// and 667 vs 538 us (backward) at B = 65 536, i.e. slower than the scalar kernels. P2C_PK_MIN_B /
+// p2c_pose_head_set_packed_min_batch enable them from a batch size on (parity-tested in tests/test_pose_head_gpu.py).
+static int g_pk_min_b = -1;
+static int pk_min_b() {
+  if (g_pk_min_b < 0) {
+    const char *e = getenv("P2C_PK_MIN_B");
+    g_pk_min_b = e ? atoi(e) : (1 << 30);
+  }
+  return g_pk_min_b;
+}
+extern "C" int p2c_pose_head_set_packed_min_batch(int32_t min_b) {
+  const int prev = pk_min_b();
+  if (min_b >= 0) g_pk_min_b = min_b;
+  return prev;
+}
+static inline bool use_pk(const p2c_pose_head_desc &d) {
+  return (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D) && !d.dloc && !d.drot &&
+         d.B >= pk_min_b() && !use_tp(d);
+}
+static inline unsigned grid_pk(int B) {
+  const int waves = (B + 3) / 4;
+  return (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
+}
 static inline unsigned tp_threads(int T) { return 64u * (unsigned)((T + 1) / 2); }
 static inline size_t tp_lds_bytes(int T) {
   const size_t waves = (size_t)(T + 1) / 2;
@@ -1308,15 +1336,22 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
                    d.out_absolute_pose_rot || d.out_world_loc || d.out_world_rot;
   if ((d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_POSE_CHANGES_MAT) && !d.final_rel_rot) return P2C_E_NULL;
   const bool tp = !mat && use_tp(d);
-  const dim3 tp_grid((unsigned)d.B), tp_block(tp_threads(d.T));
+  const bool pkd = !mat && use_pk(d);
+  const dim3 tp_grid((unsigned)d.B), tp_block(tp_threads(d.T)), pk_grid(grid_pk(d.B));
 #define P2C_LAUNCH_ROT_FWD(KIND)                                                                                \
   if (mat) hipLaunchKernelGGL((pose_head_rot_fwd<KIND, true>), grid, block, 0, stream, d);                      \
   else if (tp) hipLaunchKernelGGL((pose_head_rot_fwd_tp<KIND>), tp_grid, tp_block, tp_lds_bytes(d.T), stream, d); \
   else hipLaunchKernelGGL((pose_head_rot_fwd<KIND, false>), grid, block, 0, stream, d)
   switch (d.kind) {
-    case P2C_KIND_POSE_CHANGES_6D: P2C_LAUNCH_ROT_FWD(P2C_KIND_POSE_CHANGES_6D); break;
+    case P2C_KIND_POSE_CHANGES_6D:
+      if (pkd) hipLaunchKernelGGL((pk::pose_head_rot_fwd_pk<P2C_KIND_POSE_CHANGES_6D>), pk_grid, block, 0, stream, d);
+      else { P2C_LAUNCH_ROT_FWD(P2C_KIND_POSE_CHANGES_6D); }
+      break;
     case P2C_KIND_POSE_CHANGES_MAT: P2C_LAUNCH_ROT_FWD(P2C_KIND_POSE_CHANGES_MAT); break;
-    case P2C_KIND_RELATIVE_ROT_6D: P2C_LAUNCH_ROT_FWD(P2C_KIND_RELATIVE_ROT_6D); break;
+    case P2C_KIND_RELATIVE_ROT_6D:
+      if (pkd) hipLaunchKernelGGL((pk::pose_head_rot_fwd_pk<P2C_KIND_RELATIVE_ROT_6D>), pk_grid, block, 0, stream, d);
+      else { P2C_LAUNCH_ROT_FWD(P2C_KIND_RELATIVE_ROT_6D); }
+      break;
     case P2C_KIND_RELATIVE_ROT_MAT: P2C_LAUNCH_ROT_FWD(P2C_KIND_RELATIVE_ROT_MAT); break;
     default:
       if (mat)
@@ -1329,7 +1364,7 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
 #undef P2C_LAUNCH_ROT_FWD
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  int n_waves = tp ? d.B : (int)(grid.x * (kBlock / 64));
+  int n_waves = tp ? d.B : (int)((pkd ? pk_grid.x : grid.x) * (kBlock / 64));
   float n3 = (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
   hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, n_waves, n3,
                      d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
@@ -1353,7 +1388,10 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
   switch (d.kind) {
     case P2C_KIND_POSE_CHANGES_6D:
       if (!d.final_rel_rot) return P2C_E_NULL;
-      if (use_tp(d))
+      if (use_pk(d) && !ga && !gp)
+        hipLaunchKernelGGL(pk::pose_head_rot_bwd_tangent_pk<P2C_KIND_POSE_CHANGES_6D>, dim3(grid_pk(d.B)), block, 0, stream, d,
+                           grad_losses, grad_y);
+      else if (use_tp(d))
         hipLaunchKernelGGL(pose_head_rot_bwd_tangent_tp<P2C_KIND_POSE_CHANGES_6D>, dim3((unsigned)d.B), dim3(tp_threads(d.T)),
                            tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, grad_y);
       else
@@ -1364,7 +1402,10 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
       hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_POSE_CHANGES_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
       break;
     case P2C_KIND_RELATIVE_ROT_6D:
-      if (use_tp(d))
+      if (use_pk(d) && !ga && !gp)
+        hipLaunchKernelGGL(pk::pose_head_rot_bwd_tangent_pk<P2C_KIND_RELATIVE_ROT_6D>, dim3(grid_pk(d.B)), block, 0, stream, d,
+                           grad_losses, grad_y);
+      else if (use_tp(d))
         hipLaunchKernelGGL(pose_head_rot_bwd_tangent_tp<P2C_KIND_RELATIVE_ROT_6D>, dim3((unsigned)d.B), dim3(tp_threads(d.T)),
                            tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, grad_y);
       else

@@ -21,16 +21,19 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.fixture(autouse=True, params=['time_parallel', 'clip_sequential'])
+@pytest.fixture(autouse=True, params=['time_parallel', 'clip_sequential', 'packed'])
 def kernel_variant(request):
-    """Every case runs twice: with the time-parallel kernels (small batches, the default choice below 2048 clips) and
-    with the clip-sequential ones (what large batches get). Only lean 6-D calls have two variants; for the rest the
-    setting is a no-op."""
+    """Every case runs three times: with the time-parallel kernels (small batches, the default choice below 2048 clips),
+    with the clip-sequential scalar ones (mid-size batches, and every configuration the others do not cover) and with the
+    packed-fp32 clip-sequential ones (large batches). Only lean 6-D calls have variants; for the rest the setting is a
+    no-op."""
     from pedestrians_video_2_carla_amd import _lib
     lib = _lib.lib()
-    prev = lib.p2c_pose_head_set_time_parallel_max_batch(1 << 30 if request.param == 'time_parallel' else 0)
+    prev_tp = lib.p2c_pose_head_set_time_parallel_max_batch(1 << 30 if request.param == 'time_parallel' else 0)
+    prev_pk = lib.p2c_pose_head_set_packed_min_batch(0 if request.param == 'packed' else 1 << 30)
     yield request.param
-    lib.p2c_pose_head_set_time_parallel_max_batch(prev)
+    lib.p2c_pose_head_set_time_parallel_max_batch(prev_tp)
+    lib.p2c_pose_head_set_packed_min_batch(prev_pk)
 
 
 def close(a, b, what, rtol=RTOL, fp32_ref=None):

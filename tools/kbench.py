@@ -43,8 +43,9 @@ def main():
         desc = ops._fill_desc(spec, y, st, None, None, gt2, gt3, bufs, {})
         gl = torch.tensor([0.0, 0.0, 1.0], **f32)
         gy = torch.empty_like(y)
-        for variant, max_b in (('time_parallel', 1 << 30), ('clip_sequential', 0)):
+        for variant, max_b, min_pk in (('time_parallel', 1 << 30, 1 << 30), ('clip_sequential', 0, 1 << 30), ('packed', 0, 0)):
             prev = lib.p2c_pose_head_set_time_parallel_max_batch(max_b)
+            prev_pk = lib.p2c_pose_head_set_packed_min_batch(min_pk)
             with torch.cuda.stream(stream):
                 s = stream.cuda_stream
                 tf = graph_time(lambda: _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), s), 'fwd'), stream)
@@ -52,6 +53,7 @@ def main():
                     ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, gy.data_ptr(), s), 'bwd'),
                     stream)
             lib.p2c_pose_head_set_time_parallel_max_batch(prev)
+            lib.p2c_pose_head_set_packed_min_batch(prev_pk)
             print(json.dumps(dict(B=B, variant=variant, fwd_us=round(tf, 2), bwd_us=round(tb, 2),
                                   fwd_GBps=round(FWD_B * B / tf / 1e3, 1), bwd_GBps=round(BWD_B * B / tb / 1e3, 1))))
 
