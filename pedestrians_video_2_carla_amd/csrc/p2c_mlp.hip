@@ -571,10 +571,12 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
 
 // grad = sum over workgroups of their partial tiles, in a fixed order (bitwise reproducible), scattered to the per-layer
 // gradient tensors. One workgroup per dW tile: 64 lanes x 16 groups; group q adds workgroups q, q+16, ...
-constexpr int RG = 16;
-__global__ __launch_bounds__(64 * RG) void mlp_reduce_kernel(const MlpArgs a, int n_blocks) {
-  __shared__ f32x4 red[RG][64];
-  const int t = blockIdx.x, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+constexpr int RG = 16;    // groups of workgroup partials added in parallel
+constexpr int RL = 16;    // lanes of a tile per reducing workgroup: 4 workgroups per tile -> every CU pulls partials
+__global__ __launch_bounds__(RL * RG) void mlp_reduce_kernel(const MlpArgs a, int n_blocks) {
+  __shared__ f32x4 red[RG][RL];
+  const int t = blockIdx.x / (64 / RL), li = threadIdx.x % RL, q = threadIdx.x / RL;
+  const int lane = (blockIdx.x % (64 / RL)) * RL + li;        // lane of the MFMA C tile this thread reduces
   const size_t stride = (size_t)a.n_tiles_w * 64;
   const f32x4 *p = reinterpret_cast<const f32x4 *>(a.partials) + (size_t)t * 64 + lane;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -582,16 +584,16 @@ __global__ __launch_bounds__(64 * RG) void mlp_reduce_kernel(const MlpArgs a, in
   for (; w + 7 * RG < n_blocks; w += 8 * RG) {     // eight loads in flight, added in workgroup order
     f32x4 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(w + u * RG) * stride];
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(&p[(size_t)(w + u * RG) * stride]);
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v[u];
   }
-  for (; w < n_blocks; w += RG) s += p[(size_t)w * stride];
-  red[q][lane] = s;
+  for (; w < n_blocks; w += RG) s += __builtin_nontemporal_load(&p[(size_t)w * stride]);
+  red[q][li] = s;
   __syncthreads();
   if (q != 0) return;
 #pragma unroll
-  for (int i = 1; i < RG; ++i) s += red[i][lane];
+  for (int i = 1; i < RG; ++i) s += red[i][li];
   const TileRef tr = locate_tile(a.dims, t);
   const int n_in = a.dims[tr.l], n_out = a.dims[tr.l + 1];
   const int m = tr.mtile * 16 + (lane & 15);
@@ -758,7 +760,7 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   const int blocks = n_blocks(a.N);
   allow_big_lds();
   hipLaunchKernelGGL(pick(a, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
-  hipLaunchKernelGGL(mlp_reduce_kernel, dim3(a.n_tiles_w), dim3(64 * RG), 0, (hipStream_t)stream_, a, blocks);
+  hipLaunchKernelGGL(mlp_reduce_kernel, dim3(a.n_tiles_w * (64 / RL)), dim3(RL * RG), 0, (hipStream_t)stream_, a, blocks);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

@@ -252,6 +252,8 @@ __device__ __forceinline__ LaneCtx make_lane_tp(const p2c_pose_head_desc &d, int
 
 // Forward kinematics by pointer doubling over the group (walker_control/p3d_pose.py:116-184):
 //   abs_rot[j] = rel_rot[j] @ abs_rot[parent], abs_loc[j] = rel_loc[j] @ abs_rot[parent] + abs_loc[parent].
+template <bool NEED_ROT = true>   // NEED_ROT = false: only the absolute locations are wanted (lean forward): the last
+                                 // round's 3x3 product is skipped
 __device__ __forceinline__ void fk_doubling(const LaneCtx &L, M3 &R, V3 &l) {
   {
     // round 1 without LDS: DPP row_shr:1 hands every lane the transform of lane-1
@@ -276,7 +278,7 @@ __device__ __forceinline__ void fk_doubling(const LaneCtx &L, M3 &R, V3 &l) {
     M3 Ra = shfl(R, L.base + L.anc2);
     V3 la = shfl(l, L.base + L.anc2);
     l = vmul(l, Ra) + la;
-    R = mul(R, Ra);
+    if (NEED_ROT) R = mul(R, Ra);
   }
 }
 
@@ -646,12 +648,12 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
   W.loc = v3(0.f, 0.f, 0.f);
   HeadAcc acc{0.f, 0.f, 0.f};
 
-  FrameIn<K::NY> cur, nxt;
+  // two register sets for the frame inputs, used alternately: the loads of frame t+1 are in flight while frame t is
+  // computed, and no register-to-register copies are needed at the end of an iteration
+  FrameIn<K::NY> fa, fb;
   FramePtrs ptrs = frame_ptrs<K::NY>(d, L, 0);
-  load_frame<K::NY, 1>(L, ptrs, cur);
-  for (int t = 0; t < T; ++t) {
+  auto step = [&](const FrameIn<K::NY> &cur, int t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
-    if (t + 1 < T) load_frame<K::NY, 1>(L, ptrs, nxt);
     M3 c;
     if (K::SIXD) {
       SixD s;
@@ -671,12 +673,20 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
     }
     M3 A = R;
     V3 x = l;
-    fk_doubling(L, A, x);
+    fk_doubling<MAT>(L, A, x);
     if (MAT && L.active && d.out_absolute_pose_rot) store_m3(d.out_absolute_pose_rot, jf, A);
     world_step(d, L, t, W);
     if (MAT && W.on) world_store(d, L, t, W);
     frame_head<MAT ? MODE_FWD_MATERIALIZE : MODE_FWD>(d, L, t, x, W, acc, 0.f, 0.f, nullptr, nullptr, cur.g2, cur.g3);
-    cur = nxt;
+  };
+  load_frame<K::NY, 1>(L, ptrs, fa);
+  for (int t = 0; t < T; t += 2) {
+    if (t + 1 < T) load_frame<K::NY, 1>(L, ptrs, fb);
+    step(fa, t);
+    if (t + 1 < T) {
+      if (t + 2 < T) load_frame<K::NY, 1>(L, ptrs, fa);
+      step(fb, t + 1);
+    }
   }
   if (L.active && K::SCAN && d.final_rel_rot) store_m3(d.final_rel_rot, (size_t)L.clip * J + L.j, R);
 
