@@ -65,10 +65,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const p2c_adamw_desc d) {
     d.param[i] = p, d.exp_avg[i] = m, d.exp_avg_sq[i] = v;
     if (d.zero_grad) d.grad[i] = 0.f;
   }
-  // the last workgroup to finish publishes the new step count (all others have read the old one already)
+  // The last workgroup to finish publishes the new step count. No fence: the counter is independent of the parameter
+  // stores, every workgroup has consumed its (start-of-kernel) read of the old value before it draws a ticket, and a
+  // device-scope release fence (cross-XCD L2 write-back) would cost ~4 us -- as much as the whole kernel.
   __syncthreads();
   if (threadIdx.x == 0) {
-    __threadfence();
     if (atomicAdd(d.ticket, 1) == (int)gridDim.x - 1) {
       *d.step = step;
       *d.ticket = 0;
