@@ -183,6 +183,19 @@ P2C_API int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *desc);
 P2C_API int p2c_mlp_fwd(const p2c_mlp_desc *desc, void *stream);
 P2C_API int p2c_mlp_bwd(const p2c_mlp_desc *desc, void *stream);
 
+/* ---- grouped per-joint embeddings (K7a) --------------------------------------------------------------------------------
+ * Replaces the loop over 26 nn.Linear(2, 64) of Seq2SeqEmbeddings._format_input (modules/movements/seq2seq/
+ * seq2seq_embeddings.py:53-78): y[(t', b), j, :] = W_j x[b, t, j, :] + b_j with t' = t (or T-1-t when `flip`, the
+ * reference's invert_sequence), written sequence-first as the LSTM wants it. x (B,T,J,C), C <= 4; y (T,B,J,E), E % 4 == 0.
+ * Joint j's weight (E,C) starts at W + j*w_stride, its bias at b + j*b_stride (floats): stacked tensors and views of a
+ * flat parameter buffer are both addressed without a copy. Backward: gW / gb with the same strides (x gets no gradient:
+ * it is data); partials = p2c_embed_workspace_floats floats; fixed-order two-stage reduction (bitwise reproducible). */
+P2C_API int64_t p2c_embed_workspace_floats(int32_t B, int32_t T, int32_t J, int32_t C, int32_t E);
+P2C_API int p2c_embed_fwd(const float *x, const float *W, const float *b, int64_t w_stride, int64_t b_stride, float *y,
+                  int32_t B, int32_t T, int32_t J, int32_t C, int32_t E, int32_t flip, void *stream);
+P2C_API int p2c_embed_bwd(const float *x, const float *gy, int64_t w_stride, int64_t b_stride, float *gW, float *gb,
+                  float *partials, int32_t B, int32_t T, int32_t J, int32_t C, int32_t E, int32_t flip, void *stream);
+
 /* ---- fused AdamW / Adam over one flat fp32 buffer ------------------------------------------------------------------
  * Replaces torch.optim.AdamW.step() as configured by the reference (modules/flow/base_model.py:156-158) when all
  * trainable parameters live in one flat buffer. Update rule = torch/optim/adamw.py (amsgrad=False, maximize=False):

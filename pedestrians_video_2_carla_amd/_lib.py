@@ -79,6 +79,9 @@ SYMBOLS = {
     'p2c_mlp_workspace_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
     'p2c_mlp_image_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
     'p2c_adamw_step': (ctypes.c_int, [ctypes.POINTER(AdamWDesc), _vp]),
+    'p2c_embed_workspace_floats': (_i64, [ctypes.c_int32] * 5),
+    'p2c_embed_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp] + [ctypes.c_int32] * 6 + [_vp]),
+    'p2c_embed_bwd': (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + [_vp]),
     'p2c_mlp_fwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
     'p2c_mlp_bwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
 }

@@ -457,3 +457,89 @@ class FusedMLPFunction(torch.autograd.Function):
 def fused_mlp(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor],
               sinks: Optional[Sequence[Tensor]] = None) -> Tensor:
     return FusedMLPFunction.apply(x, len(weights), None if sinks is None else list(sinks), *weights, *biases)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# grouped per-joint embeddings (K7a, Seq2SeqEmbeddings._format_input)
+# ----------------------------------------------------------------------------------------------------------------------
+def _uniform_stride(tensors: Sequence[Tensor]) -> Optional[int]:
+    """Element stride between consecutive tensors if they are equally spaced views of one buffer (e.g. the trainer's
+    flat parameter buffer), else None."""
+    if len(tensors) == 1:
+        return tensors[0].numel()
+    if any(not t.is_contiguous() for t in tensors):
+        return None
+    step = tensors[1].data_ptr() - tensors[0].data_ptr()
+    if step <= 0 or step % 4 or any(tensors[i + 1].data_ptr() - tensors[i].data_ptr() != step
+                                    for i in range(len(tensors) - 1)):
+        return None
+    return step // 4
+
+
+class JointEmbeddingsFunction(torch.autograd.Function):
+    """y (T,B,J,E) = per-joint Linear(C,E) of x (B,T,J,C), sequence-first (time-reversed when ``flip``), one launch.
+
+    ``params`` = (w_0, b_0, w_1, b_1, ...). When the weights (and the biases) are equally spaced views of one buffer they are
+    read in place; otherwise they are stacked first. ``sinks`` (optional) = the matching gradient tensors, equally spaced
+    too: the backward then writes the gradients there and returns none (same contract as FusedMLPFunction)."""
+
+    @staticmethod
+    def forward(ctx, x, flip: bool, sinks, *params):
+        lib = _lib.lib()
+        x = _require_device(x, 'x')
+        if x.ndim != 4:
+            raise RuntimeError(f'x should be (B, T, joints, channels), got {tuple(x.shape)}')
+        B, T, Jn, C = x.shape
+        ws = [_require_device(p, 'weight') for p in params[0::2]]
+        bs = [_require_device(p, 'bias') for p in params[1::2]]
+        if len(ws) != Jn or any(w.shape != ws[0].shape or w.shape[1] != C for w in ws):
+            raise RuntimeError('one (E, C) weight per joint expected')
+        E = ws[0].shape[0]
+        wst, bst = _uniform_stride(ws), _uniform_stride(bs)
+        if wst is None or bst is None:
+            W, bb = torch.stack(ws), torch.stack(bs)
+            wptr, bptr, wst, bst = W.data_ptr(), bb.data_ptr(), E * C, E
+        else:
+            wptr, bptr = ws[0].data_ptr(), bs[0].data_ptr()
+        y = torch.empty(T, B, Jn, E, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.p2c_embed_fwd(x.data_ptr(), wptr, bptr, wst, bst, y.data_ptr(), B, T, Jn, C, E, int(flip),
+                                         _stream()), 'p2c_embed_fwd')
+        ctx.save_for_backward(x)
+        ctx.cfg = (B, T, Jn, C, E, bool(flip))
+        ctx.sinks = sinks
+        ctx.n_params = len(params)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        (x,) = ctx.saved_tensors
+        B, T, Jn, C, E, flip = ctx.cfg
+        gy = _require_device(gy, 'grad')
+        f32 = dict(dtype=torch.float32, device=x.device)
+        part = torch.empty(lib.p2c_embed_workspace_floats(B, T, Jn, C, E), **f32)
+        sinks = ctx.sinks
+        direct = False
+        if sinks is not None:
+            gws, gbs = sinks[0::2], sinks[1::2]
+            wst, bst = _uniform_stride(gws), _uniform_stride(gbs)
+            direct = wst is not None and bst is not None
+        if direct:
+            gwptr, gbptr = gws[0].data_ptr(), gbs[0].data_ptr()
+        else:
+            gW, gb = torch.empty(Jn, E, C, **f32), torch.empty(Jn, E, **f32)
+            gwptr, gbptr, wst, bst = gW.data_ptr(), gb.data_ptr(), E * C, E
+        with torch.cuda.device(x.device):
+            _lib.check(lib.p2c_embed_bwd(x.data_ptr(), gy.data_ptr(), wst, bst, gwptr, gbptr, part.data_ptr(), B, T, Jn, C, E,
+                                         int(flip), _stream()), 'p2c_embed_bwd')
+        if direct:
+            return (None, None, None) + (None,) * ctx.n_params
+        grads = [g for j in range(Jn) for g in (gW[j], gb[j])]
+        return (None, None, None, *grads)
+
+
+def joint_embeddings(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor], flip: bool = False,
+                     sinks: Optional[Sequence[Tensor]] = None) -> Tensor:
+    params = [p for pair in zip(weights, biases) for p in pair]
+    return JointEmbeddingsFunction.apply(x, flip, sinks, *params)
