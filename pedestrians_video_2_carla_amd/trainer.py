@@ -157,6 +157,16 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g_fb = torch.cuda.CUDAGraph()
+        if distributed and os.environ.get('P2C_GRAPH_ALLREDUCE', '0') == '1':
+            # opt-in: the RCCL all-reduce is captured too, the whole step is ONE graph replay (needs an RCCL build that
+            # supports stream capture; verified with one rank only -- see DESIGN.md section 6)
+            with torch.cuda.graph(g_fb):
+                self._static_loss = self._forward_backward(flow, batch, batch_idx)
+                self.exchange.all_reduce_gradients()
+                self._optimizer_step()
+            self._graphs = (g_fb, None)
+            self._restore(flow, snapshot)
+            return
         if distributed:
             with torch.cuda.graph(g_fb):
                 self._static_loss = self._forward_backward(flow, batch, batch_idx)
