@@ -196,6 +196,30 @@ P2C_API int p2c_embed_fwd(const float *x, const float *W, const float *b, int64_
 P2C_API int p2c_embed_bwd(const float *x, const float *gy, int64_t w_stride, int64_t b_stride, float *gW, float *gb,
                   float *partials, int32_t B, int32_t T, int32_t J, int32_t C, int32_t E, int32_t flip, void *stream);
 
+/* ---- LSTM recurrence (K7b) ---------------------------------------------------------------------------------------------
+ * The time loop of one torch.nn.LSTM layer (gate order i, f, g, o; reference seq2seq.py:36-58 Encoder / Decoder):
+ *   gates[t] = gx[t] + h[t-1] W_hh^T ;  c[t] = f c[t-1] + i g ;  h[t] = o tanh(c[t])
+ * with gx[t] = x[t] W_ih^T + b_ih + b_hh computed by the caller (one dense library GEMM for all t). H in {16,32,48,64},
+ * all tensors fp32 row-major, 16-byte aligned. Forward fills out (T,B,H), optional hT/cT (B,H) and the saved activations
+ * acts (T,B,4H) / cs (T,B,H). Backward takes g_out / g_hT / g_cT (each optional), acts, cs, c0, w_hh and writes
+ * g_gx (T,B,4H) = d gates (from which the caller forms dW_hh = sum_t g_gx[t]^T h[t-1], dW_ih, db with library GEMMs)
+ * and optional g_h0 / g_c0. One launch each. */
+typedef struct p2c_lstm_desc {
+  int32_t T, B, H;
+  const float *gx;              /* (T,B,4H) */
+  const float *h0, *c0;         /* (B,H) or NULL = zeros */
+  const float *w_hh;            /* (4H,H) */
+  float *out;                   /* (T,B,H) */
+  float *hT, *cT;               /* (B,H) or NULL */
+  float *acts, *cs;             /* (T,B,4H), (T,B,H): written by fwd (may be NULL for inference), read by bwd */
+  const float *g_out;           /* (T,B,H) or NULL */
+  const float *g_hT, *g_cT;     /* (B,H) or NULL */
+  float *g_gx;                  /* (T,B,4H) */
+  float *g_h0, *g_c0;           /* (B,H) or NULL */
+} p2c_lstm_desc;
+P2C_API int p2c_lstm_rec_fwd(const p2c_lstm_desc *desc, void *stream);
+P2C_API int p2c_lstm_rec_bwd(const p2c_lstm_desc *desc, void *stream);
+
 /* ---- fused AdamW / Adam over one flat fp32 buffer ------------------------------------------------------------------
  * Replaces torch.optim.AdamW.step() as configured by the reference (modules/flow/base_model.py:156-158) when all
  * trainable parameters live in one flat buffer. Update rule = torch/optim/adamw.py (amsgrad=False, maximize=False):

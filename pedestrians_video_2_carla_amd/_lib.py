@@ -59,6 +59,14 @@ class AdamWDesc(ctypes.Structure):
                 ('zero_grad', ctypes.c_int32)]
 
 
+class LstmDesc(ctypes.Structure):
+    """p2c_lstm_desc (include/p2c.h)."""
+    _fields_ = [('T', ctypes.c_int32), ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('gx', _f32p), ('h0', _f32p),
+                ('c0', _f32p), ('w_hh', _f32p), ('out', _f32p), ('hT', _f32p), ('cT', _f32p), ('acts', _f32p),
+                ('cs', _f32p), ('g_out', _f32p), ('g_hT', _f32p), ('g_cT', _f32p), ('g_gx', _f32p), ('g_h0', _f32p),
+                ('g_c0', _f32p)]
+
+
 SYMBOLS = {
     'p2c_version': (ctypes.c_char_p, []),
     'p2c_pose_head_workspace_floats': (_i64, [_i32]),
@@ -79,6 +87,8 @@ SYMBOLS = {
     'p2c_mlp_workspace_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
     'p2c_mlp_image_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
     'p2c_adamw_step': (ctypes.c_int, [ctypes.POINTER(AdamWDesc), _vp]),
+    'p2c_lstm_rec_fwd': (ctypes.c_int, [ctypes.POINTER(LstmDesc), _vp]),
+    'p2c_lstm_rec_bwd': (ctypes.c_int, [ctypes.POINTER(LstmDesc), _vp]),
     'p2c_embed_workspace_floats': (_i64, [ctypes.c_int32] * 5),
     'p2c_embed_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp] + [ctypes.c_int32] * 6 + [_vp]),
     'p2c_embed_bwd': (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + [_vp]),

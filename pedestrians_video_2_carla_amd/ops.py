@@ -543,3 +543,69 @@ def joint_embeddings(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tens
                      sinks: Optional[Sequence[Tensor]] = None) -> Tensor:
     params = [p for pair in zip(weights, biases) for p in pair]
     return JointEmbeddingsFunction.apply(x, flip, sinks, *params)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# LSTM layer: library GEMM for the input projection + one HIP launch for the recurrence (K7b)
+# ----------------------------------------------------------------------------------------------------------------------
+def lstm_supported(hidden_size: int) -> bool:
+    return hidden_size in (16, 32, 48, 64)
+
+
+class LSTMRecurrenceFunction(torch.autograd.Function):
+    """(out (T,B,H), hT, cT) = recurrence(gx (T,B,4H), h0, c0, W_hh (4H,H)); gate order i, f, g, o (torch.nn.LSTM)."""
+
+    @staticmethod
+    def forward(ctx, gx, h0, c0, w_hh):
+        lib = _lib.lib()
+        gx, h0, c0, w_hh = (_require_device(t, n) for t, n in ((gx, 'gx'), (h0, 'h0'), (c0, 'c0'), (w_hh, 'weight_hh')))
+        T, B, G = gx.shape
+        H = w_hh.shape[1]
+        if G != 4 * H or w_hh.shape[0] != 4 * H or h0.shape != (B, H) or c0.shape != (B, H):
+            raise RuntimeError(f'inconsistent LSTM shapes: gx {tuple(gx.shape)}, w_hh {tuple(w_hh.shape)}, h0 {tuple(h0.shape)}')
+        if not lstm_supported(H):
+            raise RuntimeError(f'hidden size {H} is not supported by the HIP recurrence (16, 32, 48 or 64)')
+        f32 = dict(dtype=torch.float32, device=gx.device)
+        out, hT, cT = torch.empty(T, B, H, **f32), torch.empty(B, H, **f32), torch.empty(B, H, **f32)
+        acts, cs = torch.empty(T, B, 4 * H, **f32), torch.empty(T, B, H, **f32)
+        d = _lib.LstmDesc()
+        d.T, d.B, d.H = T, B, H
+        d.gx, d.h0, d.c0, d.w_hh = gx.data_ptr(), h0.data_ptr(), c0.data_ptr(), w_hh.data_ptr()
+        d.out, d.hT, d.cT, d.acts, d.cs = out.data_ptr(), hT.data_ptr(), cT.data_ptr(), acts.data_ptr(), cs.data_ptr()
+        with torch.cuda.device(gx.device):
+            _lib.check(lib.p2c_lstm_rec_fwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_fwd')
+        ctx.save_for_backward(h0, c0, w_hh, out, acts, cs)
+        return out, hT, cT
+
+    @staticmethod
+    def backward(ctx, g_out, g_hT, g_cT):
+        lib = _lib.lib()
+        h0, c0, w_hh, out, acts, cs = ctx.saved_tensors
+        T, B, H = out.shape
+        f32 = dict(dtype=torch.float32, device=out.device)
+        g_gx, g_h0, g_c0 = torch.empty(T, B, 4 * H, **f32), torch.empty(B, H, **f32), torch.empty(B, H, **f32)
+        d = _lib.LstmDesc()
+        d.T, d.B, d.H = T, B, H
+        d.c0, d.w_hh, d.acts, d.cs = c0.data_ptr(), w_hh.data_ptr(), acts.data_ptr(), cs.data_ptr()
+        d.g_out = _ptr(None if g_out is None else _require_device(g_out, 'grad out'))
+        d.g_hT = _ptr(None if g_hT is None else _require_device(g_hT, 'grad hT'))
+        d.g_cT = _ptr(None if g_cT is None else _require_device(g_cT, 'grad cT'))
+        d.g_gx, d.g_h0, d.g_c0 = g_gx.data_ptr(), g_h0.data_ptr(), g_c0.data_ptr()
+        with torch.cuda.device(out.device):
+            _lib.check(lib.p2c_lstm_rec_bwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_bwd')
+        g_w = None
+        if ctx.needs_input_grad[3]:       # dW_hh = sum_t dgates[t]^T h[t-1]: two dense library GEMMs over all (t, b)
+            g_w = g_gx[0].t() @ h0
+            if T > 1:
+                g_w = torch.addmm(g_w, g_gx[1:].reshape(-1, 4 * H).t(), out[:-1].reshape(-1, H))
+        return g_gx, g_h0, g_c0, g_w
+
+
+def lstm_layer(x: Tensor, h0: Tensor, c0: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Optional[Tensor],
+               b_hh: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
+    """One unidirectional torch.nn.LSTM layer: x (T,B,I) -> (out (T,B,H), hT (B,H), cT (B,H)). The input projection for
+    all time steps is one dense GEMM (library); the time loop is one HIP launch (p2c_lstm_rec_fwd)."""
+    T, B, I = x.shape
+    bias = None if b_ih is None else (b_ih + b_hh if b_hh is not None else b_ih)
+    gx = torch.nn.functional.linear(x.reshape(T * B, I), w_ih, bias).view(T, B, -1)
+    return LSTMRecurrenceFunction.apply(gx, h0, c0, w_hh)

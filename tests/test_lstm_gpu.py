@@ -1,0 +1,75 @@
+"""LSTM layer = library GEMM + HIP recurrence (K7b, p2c_lstm_rec_fwd/_bwd through the C ABI) against torch.nn.LSTM in
+fp64 on the CPU with the same weights: outputs, final states and every gradient within 1e-4 relative."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    return torch.device('cuda:0')
+
+
+def close(a, b, what, rtol=RTOL):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err, scale = (a - b).abs().max().item(), b.abs().max().item()
+    assert err <= rtol * scale + 1e-30, f'{what}: {err:.3e} vs scale {scale:.3e}'
+
+
+@pytest.mark.parametrize('T,B,I,H', [(1, 1, 5, 16), (16, 6, 52, 64), (7, 33, 20, 32), (16, 130, 64, 64), (3, 17, 9, 48)])
+@pytest.mark.parametrize('with_state', [False, True])
+def test_layer_matches_torch_lstm(T, B, I, H, with_state):
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    torch.manual_seed(T * 100 + B)
+    ref = torch.nn.LSTM(I, H).double()
+    x = torch.randn(T, B, I, dtype=torch.float64)
+    h0 = torch.randn(B, H, dtype=torch.float64) if with_state else torch.zeros(B, H, dtype=torch.float64)
+    c0 = torch.randn(B, H, dtype=torch.float64) if with_state else torch.zeros(B, H, dtype=torch.float64)
+    up, uh, uc = torch.randn(T, B, H, dtype=torch.float64), torch.randn(B, H, dtype=torch.float64), torch.randn(B, H, dtype=torch.float64)
+    xr, hr, cr = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+    out_r, (hT_r, cT_r) = ref(xr, (hr[None], cr[None]))
+    ((out_r * up).sum() + (hT_r[0] * uh).sum() + (cT_r[0] * uc).sum()).backward()
+
+    p = {n: v.detach().float().to(d).requires_grad_(True) for n, v in ref.named_parameters()}
+    xd, hd, cd = (t.float().to(d).requires_grad_(True) for t in (x, h0, c0))
+    out, hT, cT = ops.lstm_layer(xd, hd, cd, p['weight_ih_l0'], p['weight_hh_l0'], p['bias_ih_l0'], p['bias_hh_l0'])
+    ((out * up.float().to(d)).sum() + (hT * uh.float().to(d)).sum() + (cT * uc.float().to(d)).sum()).backward()
+    close(out, out_r, 'out'), close(hT, hT_r[0], 'hT'), close(cT, cT_r[0], 'cT')
+    close(xd.grad, xr.grad, 'grad x'), close(hd.grad, hr.grad, 'grad h0'), close(cd.grad, cr.grad, 'grad c0')
+    for n, v in ref.named_parameters():
+        close(p[n].grad, v.grad, 'grad ' + n)
+
+
+def test_seq2seq_model_uses_the_fused_stack_and_matches_cpu():
+    """Whole Seq2SeqEmbeddings model (encoder stack, T decoder steps, fc) on the GPU vs the same module in fp64 on the CPU
+    (nn.LSTM path): forward and all parameter gradients."""
+    import copy
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2SeqEmbeddings
+    d = dev()
+    torch.manual_seed(3)
+    model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d,
+                              p_dropout=0.0).train()
+    cpu = copy.deepcopy(model).double()
+    gpu = model.to(d)
+    x = torch.randn(9, 16, 26, 2)
+    up = torch.randn(9, 16, 26, 2)
+    yr = cpu(x.double())
+    (yr * up.double()).sum().backward()
+    y = gpu(x.to(d))
+    (y * up.to(d)).sum().backward()
+    close(y, yr, 'model output', rtol=2e-4)
+    for (n, pg), (_, pc) in zip(gpu.named_parameters(), cpu.named_parameters()):
+        close(pg.grad, pc.grad, 'grad ' + n, rtol=5e-4)
+
+
+def test_no_cpu_fallback():
+    from pedestrians_video_2_carla_amd import ops, _lib
+    with pytest.raises(_lib.P2CError):
+        ops.lstm_layer(torch.zeros(2, 3, 4), torch.zeros(3, 16), torch.zeros(3, 16), torch.zeros(64, 4), torch.zeros(64, 16),
+                       None, None)

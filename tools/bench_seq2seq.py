@@ -13,6 +13,8 @@ from pedestrians_video_2_carla_amd.trainer import Trainer, seed_everything
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 use_graph = len(sys.argv) > 3 and sys.argv[3] == 'graph'
+if os.environ.get('P2C_BLAS'):
+    torch.backends.cuda.preferred_blas_library(os.environ['P2C_BLAS'])
 d = torch.device('cuda:0')
 seed_everything(22742)
 dm = SyntheticCarlaRecordedDataModule(clip_length=16, batch_size=B)
