@@ -48,9 +48,25 @@ __device__ __forceinline__ f32x4 load4(const float *p, bool ok) {
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------------
+// W_hh (4H x H floats) -> LDS with coalesced 16-byte loads (a strided per-lane gather from global costs ~10 us per
+// launch, which is most of a single-step decoder call); pitch H + 1 keeps the fragment pick-up conflict-free
+template <int H>
+__device__ __forceinline__ void stage_w(const float *w_hh, float *wl) {
+  constexpr int N4 = 4 * H * H / 4;
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(w_hh);
+  for (int i = threadIdx.x; i < N4; i += blockDim.x) {
+    const f32x4 v = src[i];
+    const int e = i * 4, row = e / H, col = e - row * H;
+    float *p = wl + row * (H + 1) + col;
+    p[0] = v[0], p[1] = v[1], p[2] = v[2], p[3] = v[3];
+  }
+  __syncthreads();
+}
+
 template <int H>
 __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args a) {
   constexpr int KS = H / 4;                       // k-steps of the recurrent product
+  extern __shared__ float dyn_lds[];              // [4H][H+1] staging image of W_hh, then unused
   __shared__ float hbuf[2][H * TP];               // h[t-1]^T, double buffered
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -59,11 +75,12 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
   const int u0 = w * 16 + 4 * g;                  // first of this lane's four hidden units
   const int B = a.B, T = a.T;
 
+  stage_w<H>(a.w_hh, dyn_lds);
   float frag[4][KS];                              // A fragments: gate q, rows 16w + (lane & 15), k = 4 ks + g
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) frag[q][ks] = a.w_hh[(size_t)(q * H + w * 16 + c) * H + 4 * ks + g];
+    for (int ks = 0; ks < KS; ++ks) frag[q][ks] = dyn_lds[(q * H + w * 16 + c) * (H + 1) + 4 * ks + g];
 
   f32x4 cst = a.c0 ? load4(a.c0 + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
   {
@@ -126,7 +143,8 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
 template <int H>
 __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args a) {
   constexpr int KS = H;                           // 4H gate rows / 4
-  __shared__ float dg[2][4 * H * TP];             // d gates^T [gate row][sequence], double buffered
+  extern __shared__ float dyn_lds[];              // [4H][H+1] staging image of W_hh, then d gates^T, double buffered
+  float *dg0 = dyn_lds, *dg1 = dyn_lds + 4 * H * TP;   // (2 x 4H x TP <= 4H x (H+1) for H >= 33; sized on the host)
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.x * TS + c;
@@ -134,9 +152,11 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
   const int u0 = w * 16 + 4 * g;
   const int B = a.B, T = a.T;
 
+  stage_w<H>(a.w_hh, dyn_lds);
   float frag[KS];                                 // A fragments of W_hh^T: rows = units 16w + (lane & 15), k = gate row 4 ks + g
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) frag[ks] = a.w_hh[(size_t)(4 * ks + g) * H + w * 16 + c];
+  for (int ks = 0; ks < KS; ++ks) frag[ks] = dyn_lds[(4 * ks + g) * (H + 1) + w * 16 + c];
+  __syncthreads();                                // the staging image is dead: its space becomes the d-gates buffers
 
   f32x4 dh = a.g_hT ? load4(a.g_hT + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 dc = a.g_cT ? load4(a.g_cT + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
       *reinterpret_cast<f32x4 *>(p) = pi, *reinterpret_cast<f32x4 *>(p + H) = pf;
       *reinterpret_cast<f32x4 *>(p + 2 * H) = pg, *reinterpret_cast<f32x4 *>(p + 3 * H) = po;
     }
-    float *d = dg[cur];
+    float *d = cur ? dg1 : dg0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       d[(u0 + r) * TP + c] = pi[r], d[(H + u0 + r) * TP + c] = pf[r];
@@ -205,12 +225,24 @@ static int check(const p2c_lstm_desc *d, Args &a) {
   return 0;
 }
 
-#define P2C_LSTM_DISPATCH(KERNEL)                                                                                      \
-  switch (a.H) {                                                                                                       \
-    case 16: hipLaunchKernelGGL(KERNEL<16>, grid, dim3(64), 0, (hipStream_t)stream, a); break;                          \
-    case 32: hipLaunchKernelGGL(KERNEL<32>, grid, dim3(128), 0, (hipStream_t)stream, a); break;                         \
-    case 48: hipLaunchKernelGGL(KERNEL<48>, grid, dim3(192), 0, (hipStream_t)stream, a); break;                         \
-    default: hipLaunchKernelGGL(KERNEL<64>, grid, dim3(256), 0, (hipStream_t)stream, a);                                \
+static size_t lds_bytes(int H, bool bwd) {
+  size_t image = (size_t)4 * H * (H + 1), dgates = (size_t)2 * 4 * H * TP;
+  return sizeof(float) * ((bwd && dgates > image) ? dgates : image);
+}
+template <int H>
+static void allow_lds() {
+  static bool done = false;
+  if (done) return;
+  (void)hipFuncSetAttribute((const void *)lstm_rec_fwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)lstm_rec_bwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  done = true;
+}
+#define P2C_LSTM_DISPATCH(KERNEL, BWD)                                                                                     \
+  switch (a.H) {                                                                                                           \
+    case 16: allow_lds<16>(); hipLaunchKernelGGL(KERNEL<16>, grid, dim3(64), lds_bytes(16, BWD), (hipStream_t)stream, a); break;   \
+    case 32: allow_lds<32>(); hipLaunchKernelGGL(KERNEL<32>, grid, dim3(128), lds_bytes(32, BWD), (hipStream_t)stream, a); break;  \
+    case 48: allow_lds<48>(); hipLaunchKernelGGL(KERNEL<48>, grid, dim3(192), lds_bytes(48, BWD), (hipStream_t)stream, a); break;  \
+    default: allow_lds<64>(); hipLaunchKernelGGL(KERNEL<64>, grid, dim3(256), lds_bytes(64, BWD), (hipStream_t)stream, a);         \
   }
 
 extern "C" int p2c_lstm_rec_fwd(const p2c_lstm_desc *d, void *stream) {
@@ -220,7 +252,7 @@ extern "C" int p2c_lstm_rec_fwd(const p2c_lstm_desc *d, void *stream) {
   if (!a.gx || !a.out) return P2C_E_NULL;
   if (a.B == 0) return 0;
   const dim3 grid((unsigned)((a.B + TS - 1) / TS));
-  P2C_LSTM_DISPATCH(lstm_rec_fwd_kernel)
+  P2C_LSTM_DISPATCH(lstm_rec_fwd_kernel, false)
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -232,7 +264,7 @@ extern "C" int p2c_lstm_rec_bwd(const p2c_lstm_desc *d, void *stream) {
   if (!a.acts || !a.cs || !a.g_gx) return P2C_E_NULL;
   if (a.B == 0) return 0;
   const dim3 grid((unsigned)((a.B + TS - 1) / TS));
-  P2C_LSTM_DISPATCH(lstm_rec_bwd_kernel)
+  P2C_LSTM_DISPATCH(lstm_rec_bwd_kernel, true)
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
