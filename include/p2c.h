@@ -220,6 +220,31 @@ typedef struct p2c_lstm_desc {
 P2C_API int p2c_lstm_rec_fwd(const p2c_lstm_desc *desc, void *stream);
 P2C_API int p2c_lstm_rec_bwd(const p2c_lstm_desc *desc, void *stream);
 
+/* ---- Seq2Seq decoder loop (K7c) -----------------------------------------------------------------------------------------
+ * for t in range(T): out_t = fc(LSTM_2layers(x_t; encoder state)); x_{t+1} = out_t   (reference seq2seq.py:245-349; the
+ * decoder state is NOT carried between frames, 272-288). The caller provides the frame-invariant recurrent terms
+ * k_l = b_ih_l + b_hh_l + W_hh_l hidden_l (B,4H) and the encoder cell states c_l (B,H). H = 64, O <= 64. Forward writes
+ * out (T,B,O) and the saved activations; backward consumes g_out (T,B,O) and writes d gates0 / d gates1 (T,B,4H),
+ * d out_total (T,B,O) [= g_out + the gradient that flows back through the fed-back input], and d c_l (B,H): the weight
+ * gradients are dense reductions of those over all (t,b) (dW_ih0 = dgates0^T x_prev, dW_ih1 = dgates1^T h0d,
+ * dW_fc = dout_total^T h1, dk_l = sum_t dgates_l, db_fc = sum dout_total), left to library GEMMs. One launch each. */
+typedef struct p2c_decoder_desc {
+  int32_t T, B, H, O;
+  const float *k0, *c0, *k1, *c1;
+  const float *w_ih0, *w_ih1, *w_fc, *b_fc;   /* (4H,O), (4H,H), (O,H), (O) */
+  const float *x0;                /* (B,O) first input, NULL = zeros (<sos>) */
+  const float *drop;              /* (T,B,H) multiplicative dropout mask applied to the layer-0 output, or NULL */
+  float *out;                     /* (T,B,O) */
+  float *acts0, *acts1;           /* (T,B,4H) activated gates, written by fwd, read by bwd */
+  float *h0d, *h1;                /* (T,B,H) layer outputs (after dropout for layer 0), written by fwd */
+  const float *g_out;             /* (T,B,O) */
+  float *g_gates0, *g_gates1;     /* (T,B,4H) */
+  float *g_outtot;                /* (T,B,O) */
+  float *g_c0, *g_c1;             /* (B,H) */
+} p2c_decoder_desc;
+P2C_API int p2c_decoder_fwd(const p2c_decoder_desc *desc, void *stream);
+P2C_API int p2c_decoder_bwd(const p2c_decoder_desc *desc, void *stream);
+
 /* ---- fused AdamW / Adam over one flat fp32 buffer ------------------------------------------------------------------
  * Replaces torch.optim.AdamW.step() as configured by the reference (modules/flow/base_model.py:156-158) when all
  * trainable parameters live in one flat buffer. Update rule = torch/optim/adamw.py (amsgrad=False, maximize=False):

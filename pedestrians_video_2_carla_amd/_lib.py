@@ -67,6 +67,13 @@ class LstmDesc(ctypes.Structure):
                 ('g_c0', _f32p)]
 
 
+class DecoderDesc(ctypes.Structure):
+    """p2c_decoder_desc (include/p2c.h)."""
+    _fields_ = [('T', ctypes.c_int32), ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('O', ctypes.c_int32)] + [
+        (n, _f32p) for n in ('k0', 'c0', 'k1', 'c1', 'w_ih0', 'w_ih1', 'w_fc', 'b_fc', 'x0', 'drop', 'out', 'acts0', 'acts1',
+                             'h0d', 'h1', 'g_out', 'g_gates0', 'g_gates1', 'g_outtot', 'g_c0', 'g_c1')]
+
+
 SYMBOLS = {
     'p2c_version': (ctypes.c_char_p, []),
     'p2c_pose_head_workspace_floats': (_i64, [_i32]),
@@ -89,6 +96,8 @@ SYMBOLS = {
     'p2c_adamw_step': (ctypes.c_int, [ctypes.POINTER(AdamWDesc), _vp]),
     'p2c_lstm_rec_fwd': (ctypes.c_int, [ctypes.POINTER(LstmDesc), _vp]),
     'p2c_lstm_rec_bwd': (ctypes.c_int, [ctypes.POINTER(LstmDesc), _vp]),
+    'p2c_decoder_fwd': (ctypes.c_int, [ctypes.POINTER(DecoderDesc), _vp]),
+    'p2c_decoder_bwd': (ctypes.c_int, [ctypes.POINTER(DecoderDesc), _vp]),
     'p2c_embed_workspace_floats': (_i64, [ctypes.c_int32] * 5),
     'p2c_embed_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp] + [ctypes.c_int32] * 6 + [_vp]),
     'p2c_embed_bwd': (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + [_vp]),

@@ -1,0 +1,342 @@
+// p2c_s2s.hip -- K7c: the whole decoder loop of Seq2Seq(Embeddings) as ONE launch forward and ONE backward (gfx950).
+//
+// Reference: modules/movements/seq2seq/seq2seq.py:245-349 -- for t in range(T): out_t = fc(LSTM_2layers(step_in, (hidden,
+// cell))), step_in = out_t, where (hidden, cell) are the ENCODER's for every frame (the decoder state is not carried,
+// seq2seq.py:272-288). With the state frozen, the recurrent terms are per-clip constants
+//     k_l = b_ih_l + b_hh_l + W_hh_l hidden_l      (computed by the caller: two small library GEMMs, autograd on top)
+// and the decoder is the same 3-stage map applied T times to its own output:
+//     gates0 = x_t W_ih0^T + k0 ;  c = f c_enc0 + i g ;  h0 = o tanh(c)   [* dropout mask in training]
+//     gates1 = h0  W_ih1^T + k1 ;  c = f c_enc1 + i g ;  h1 = o tanh(c)
+//     x_{t+1} = out_t = h1 W_fc^T + b_fc
+// As framework ops that is T x (2 LSTM launches + projections + adds) forward and about twice that backward, with every
+// weight gradient accumulated T times. Here: a workgroup owns 16 clips, 4 waves; wave w owns hidden units / output
+// features [16w, 16w+16); W_ih0, W_ih1, W_fc live as MFMA A fragments IN REGISTERS for all T steps (O/4*4 + 64 + 16
+// VGPRs), k_l / c_enc_l / b_fc too; x_t, h0, h1 pass through LDS transposed (the B operands); three barriers per step.
+// Backward walks t = T-1..0 with the transposed fragments, carries d x_{t+1} in registers, and writes d gates0, d gates1
+// and d out_total once: the weight gradients are then six dense library GEMMs / reductions over all (t, b) at once
+// (dW_ih0 = dgates0^T x_prev, dW_ih1 = dgates1^T h0, dW_fc = dout^T h1, dk_l = sum_t dgates_l, db_fc = sum dout).
+// H = 64, two layers, O <= 64 (pose_2d: 52); everything else takes the per-step path (ops.lstm_layer).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/p2c.h"
+
+namespace p2c_s2s {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TS = 16, TP = 17, H = 64, G4 = 4 * H, OMAX = 64;
+
+struct Args {
+  const float *k0, *c0, *k1, *c1;        // (B,4H), (B,H), (B,4H), (B,H)
+  const float *w_ih0, *w_ih1, *w_fc, *b_fc;   // (4H,O), (4H,H), (O,H), (O)
+  const float *x0;                       // (B,O) or NULL = zeros (<sos>)
+  const float *drop;                     // (T,B,H) multiplicative dropout mask on the layer-0 output, or NULL
+  float *out;                            // (T,B,O)
+  float *acts0, *acts1, *h0d, *h1;       // saved for the backward: (T,B,4H) x2, (T,B,H) x2
+  const float *g_out;                    // (T,B,O)
+  float *g_gates0, *g_gates1, *g_outtot; // (T,B,4H) x2, (T,B,O)
+  float *g_c0, *g_c1;                    // (B,H) x2
+  int32_t T, B, O;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f / (1.f + __expf(-2.f * x)) - 1.f; }
+__device__ __forceinline__ f32x4 load4(const float *p, bool ok) {
+  return ok ? *reinterpret_cast<const f32x4 *>(p) : (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+// rows x cols row-major matrix -> LDS image [rows][cols + 1] (coalesced 16-byte loads when cols % 4 == 0)
+__device__ __forceinline__ void stage(const float *src, int rows, int cols, float *img) {
+  __syncthreads();                                   // previous users of the image region are done
+  const int n = rows * cols;
+  if ((cols & 3) == 0) {
+    const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
+    for (int i = threadIdx.x; i < (n >> 2); i += blockDim.x) {
+      const f32x4 v = s4[i];
+      const int e = i * 4, r = e / cols, cc = e - r * cols;
+      float *p = img + r * (cols + 1) + cc;
+      p[0] = v[0], p[1] = v[1], p[2] = v[2], p[3] = v[3];
+    }
+  } else {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const int r = i / cols, cc = i - r * cols;
+      img[r * (cols + 1) + cc] = src[i];
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void cell_fwd(const f32x4 (&acc)[4], const f32x4 &c_enc, f32x4 &ai, f32x4 &af, f32x4 &ag, f32x4 &ao,
+                                         f32x4 &h) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    ai[r] = sigmoidf_(acc[0][r]), af[r] = sigmoidf_(acc[1][r]), ag[r] = tanhf_(acc[2][r]), ao[r] = sigmoidf_(acc[3][r]);
+    h[r] = ao[r] * tanhf_(af[r] * c_enc[r] + ai[r] * ag[r]);
+  }
+}
+// gradient of the pre-activation gates given dh (the cell state is the frozen encoder state: nothing is carried in time)
+__device__ __forceinline__ void cell_bwd(const f32x4 &dh, const f32x4 &ai, const f32x4 &af, const f32x4 &ag, const f32x4 &ao,
+                                         const f32x4 &c_enc, f32x4 &pi, f32x4 &pf, f32x4 &pg, f32x4 &po, f32x4 &dc_acc) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float tc = tanhf_(af[r] * c_enc[r] + ai[r] * ag[r]);
+    const float dct = dh[r] * ao[r] * (1.f - tc * tc);
+    po[r] = dh[r] * tc * ao[r] * (1.f - ao[r]);
+    pi[r] = dct * ag[r] * ai[r] * (1.f - ai[r]);
+    pf[r] = dct * c_enc[r] * af[r] * (1.f - af[r]);
+    pg[r] = dct * ai[r] * (1.f - ag[r] * ag[r]);
+    dc_acc[r] += dct * af[r];
+  }
+}
+__device__ __forceinline__ void store_gates(float *base, size_t row, int u0, const f32x4 &a, const f32x4 &b, const f32x4 &c,
+                                            const f32x4 &d) {
+  float *p = base + row * G4 + u0;
+  *reinterpret_cast<f32x4 *>(p) = a, *reinterpret_cast<f32x4 *>(p + H) = b;
+  *reinterpret_cast<f32x4 *>(p + 2 * H) = c, *reinterpret_cast<f32x4 *>(p + 3 * H) = d;
+}
+
+// ---- forward -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
+  extern __shared__ float img[];                    // staging image of one weight matrix at a time
+  __shared__ float xT[OMAX * TP], h0T[H * TP], h1T[H * TP];
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * TS + c;
+  const bool ok = b < a.B;
+  const int u0 = w * 16 + 4 * g;
+  const int O = a.O, O4 = (O + 3) >> 2, B = a.B, T = a.T;
+
+  float fa0[4][OMAX / 4], fa1[4][H / 4], ffc[H / 4];
+  stage(a.w_ih0, G4, O, img);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int ks = 0; ks < OMAX / 4; ++ks) {
+      const int k = 4 * ks + g;
+      fa0[q][ks] = (k < O) ? img[(q * H + w * 16 + c) * (O + 1) + k] : 0.f;
+    }
+  stage(a.w_ih1, G4, H, img);
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int ks = 0; ks < H / 4; ++ks) fa1[q][ks] = img[(q * H + w * 16 + c) * (H + 1) + 4 * ks + g];
+  stage(a.w_fc, O, H, img);
+#pragma unroll
+  for (int ks = 0; ks < H / 4; ++ks) ffc[ks] = (w * 16 + c < O) ? img[(w * 16 + c) * (H + 1) + 4 * ks + g] : 0.f;
+
+  f32x4 k0r[4], k1r[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    k0r[q] = load4(a.k0 + (size_t)b * G4 + q * H + u0, ok);
+    k1r[q] = load4(a.k1 + (size_t)b * G4 + q * H + u0, ok);
+  }
+  const f32x4 c0r = load4(a.c0 + (size_t)b * H + u0, ok), c1r = load4(a.c1 + (size_t)b * H + u0, ok);
+  f32x4 bfc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bfc[r] = (u0 + r < O) ? a.b_fc[u0 + r] : 0.f;
+  {   // x_0 (rows >= O stay zero: they only ever meet zero weight fragments)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xT[(u0 + r) * TP + c] = (a.x0 && ok && u0 + r < O) ? a.x0[(size_t)b * O + u0 + r] : 0.f;
+  }
+  __syncthreads();
+
+  for (int t = 0; t < T; ++t) {
+    const size_t row = (size_t)t * B + b;
+    f32x4 acc[4], ai, af, ag, ao, h;
+    // ---- layer 0
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = k0r[q];
+#pragma unroll
+    for (int ks = 0; ks < OMAX / 4; ++ks) {          // unrolled with a uniform guard: the fragments must stay in registers
+      if (ks < O4) {
+        const float bv = xT[(4 * ks + g) * TP + c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[q][ks], bv, acc[q], 0, 0, 0);
+      }
+    }
+    cell_fwd(acc, c0r, ai, af, ag, ao, h);
+    if (a.drop) {
+      const f32x4 m = load4(a.drop + row * H + u0, ok);
+      h *= m;
+    }
+    if (ok) {
+      store_gates(a.acts0, row, u0, ai, af, ag, ao);
+      *reinterpret_cast<f32x4 *>(a.h0d + row * H + u0) = h;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h0T[(u0 + r) * TP + c] = h[r];
+    __syncthreads();
+    // ---- layer 1
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = k1r[q];
+#pragma unroll
+    for (int ks = 0; ks < H / 4; ++ks) {
+      const float bv = h0T[(4 * ks + g) * TP + c];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[q][ks], bv, acc[q], 0, 0, 0);
+    }
+    cell_fwd(acc, c1r, ai, af, ag, ao, h);
+    if (ok) {
+      store_gates(a.acts1, row, u0, ai, af, ag, ao);
+      *reinterpret_cast<f32x4 *>(a.h1 + row * H + u0) = h;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h1T[(u0 + r) * TP + c] = h[r];
+    __syncthreads();
+    // ---- fc: this wave's 16 output features
+    f32x4 o = bfc;
+#pragma unroll
+    for (int ks = 0; ks < H / 4; ++ks)
+      o = __builtin_amdgcn_mfma_f32_16x16x4f32(ffc[ks], h1T[(4 * ks + g) * TP + c], o, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (ok && u0 + r < O) a.out[row * O + u0 + r] = o[r];
+      xT[(u0 + r) * TP + c] = o[r];                // next step's input (features >= O are exactly zero)
+    }
+    __syncthreads();
+  }
+}
+
+// ---- backward ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
+  extern __shared__ float img[];
+  __shared__ float doT[OMAX * TP], dg1T[G4 * TP], dg0T[G4 * TP];
+  const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x * TS + c;
+  const bool ok = b < a.B;
+  const int u0 = w * 16 + 4 * g;
+  const int O = a.O, O4 = (O + 3) >> 2, B = a.B, T = a.T;
+
+  // transposed fragments: rows = this wave's 16 hidden units (or output features), k = the contracted index
+  float ffcT[OMAX / 4], f1T[G4 / 4], f0T[G4 / 4];
+  stage(a.w_fc, O, H, img);                          // dh1 = W_fc^T dout:  A[unit][k = o] = W_fc[o][unit]
+#pragma unroll
+  for (int ks = 0; ks < OMAX / 4; ++ks) {
+    const int k = 4 * ks + g;
+    ffcT[ks] = (k < O) ? img[k * (H + 1) + w * 16 + c] : 0.f;
+  }
+  stage(a.w_ih1, G4, H, img);                        // dh0 = W_ih1^T dgates1:  A[unit][k = gate row] = W_ih1[k][unit]
+#pragma unroll
+  for (int ks = 0; ks < G4 / 4; ++ks) f1T[ks] = img[(4 * ks + g) * (H + 1) + w * 16 + c];
+  stage(a.w_ih0, G4, O, img);                        // dx = W_ih0^T dgates0:  A[o][k = gate row] = W_ih0[k][o]
+#pragma unroll
+  for (int ks = 0; ks < G4 / 4; ++ks) f0T[ks] = (w * 16 + c < O) ? img[(4 * ks + g) * (O + 1) + w * 16 + c] : 0.f;
+
+  const f32x4 c0r = load4(a.c0 + (size_t)b * H + u0, ok), c1r = load4(a.c1 + (size_t)b * H + u0, ok);
+  f32x4 dc0 = zero4(), dc1 = zero4(), dx = zero4();
+
+  for (int t = T - 1; t >= 0; --t) {
+    const size_t row = (size_t)t * B + b;
+    // ---- d out_t (loss + the next step's input gradient), this wave's 16 output features
+    f32x4 dout = dx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (ok && u0 + r < O) dout[r] += a.g_out[row * O + u0 + r];
+      else dout[r] = 0.f;
+      if (ok && u0 + r < O) a.g_outtot[row * O + u0 + r] = dout[r];
+      doT[(u0 + r) * TP + c] = dout[r];
+    }
+    __syncthreads();
+    // ---- fc backward: dh1 for this wave's 16 hidden units
+    f32x4 dh = zero4();
+#pragma unroll
+    for (int ks = 0; ks < OMAX / 4; ++ks)
+      if (ks < O4) dh = __builtin_amdgcn_mfma_f32_16x16x4f32(ffcT[ks], doT[(4 * ks + g) * TP + c], dh, 0, 0, 0);
+    f32x4 pi, pf, pg, po;
+    {
+      const float *pa = a.acts1 + row * G4 + u0;
+      const f32x4 ai = load4(pa, ok), af = load4(pa + H, ok), ag = load4(pa + 2 * H, ok), ao = load4(pa + 3 * H, ok);
+      cell_bwd(dh, ai, af, ag, ao, c1r, pi, pf, pg, po, dc1);
+    }
+    if (ok) store_gates(a.g_gates1, row, u0, pi, pf, pg, po);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dg1T[(u0 + r) * TP + c] = pi[r], dg1T[(H + u0 + r) * TP + c] = pf[r];
+      dg1T[(2 * H + u0 + r) * TP + c] = pg[r], dg1T[(3 * H + u0 + r) * TP + c] = po[r];
+    }
+    __syncthreads();
+    // ---- layer-1 input gradient: dh0 (two accumulators halve the dependent chain)
+    f32x4 e0 = zero4(), e1 = zero4();
+#pragma unroll
+    for (int ks = 0; ks < G4 / 4; ks += 2) {
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1T[ks], dg1T[(4 * ks + g) * TP + c], e0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1T[ks + 1], dg1T[(4 * ks + 4 + g) * TP + c], e1, 0, 0, 0);
+    }
+    dh = e0 + e1;
+    if (a.drop) dh *= load4(a.drop + row * H + u0, ok);
+    {
+      const float *pa = a.acts0 + row * G4 + u0;
+      const f32x4 ai = load4(pa, ok), af = load4(pa + H, ok), ag = load4(pa + 2 * H, ok), ao = load4(pa + 3 * H, ok);
+      cell_bwd(dh, ai, af, ag, ao, c0r, pi, pf, pg, po, dc0);
+    }
+    if (ok) store_gates(a.g_gates0, row, u0, pi, pf, pg, po);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dg0T[(u0 + r) * TP + c] = pi[r], dg0T[(H + u0 + r) * TP + c] = pf[r];
+      dg0T[(2 * H + u0 + r) * TP + c] = pg[r], dg0T[(3 * H + u0 + r) * TP + c] = po[r];
+    }
+    __syncthreads();
+    // ---- layer-0 input gradient = gradient of the previous step's output
+    e0 = zero4(), e1 = zero4();
+#pragma unroll
+    for (int ks = 0; ks < G4 / 4; ks += 2) {
+      e0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0T[ks], dg0T[(4 * ks + g) * TP + c], e0, 0, 0, 0);
+      e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0T[ks + 1], dg0T[(4 * ks + 4 + g) * TP + c], e1, 0, 0, 0);
+    }
+    dx = e0 + e1;
+  }
+  if (ok) {
+    *reinterpret_cast<f32x4 *>(a.g_c0 + (size_t)b * H + u0) = dc0;
+    *reinterpret_cast<f32x4 *>(a.g_c1 + (size_t)b * H + u0) = dc1;
+  }
+}
+
+}  // namespace p2c_s2s
+
+using namespace p2c_s2s;
+
+static int fill(Args &a, const p2c_decoder_desc *d) {
+  if (!d || !d->k0 || !d->c0 || !d->k1 || !d->c1 || !d->w_ih0 || !d->w_ih1 || !d->w_fc || !d->b_fc) return P2C_E_NULL;
+  if (d->T < 0 || d->B < 0 || d->H != H || d->O < 1 || d->O > OMAX) return P2C_E_SHAPE;
+  a = Args{};
+  a.k0 = d->k0, a.c0 = d->c0, a.k1 = d->k1, a.c1 = d->c1, a.w_ih0 = d->w_ih0, a.w_ih1 = d->w_ih1, a.w_fc = d->w_fc;
+  a.b_fc = d->b_fc, a.x0 = d->x0, a.drop = d->drop, a.out = d->out, a.acts0 = d->acts0, a.acts1 = d->acts1, a.h0d = d->h0d;
+  a.h1 = d->h1, a.g_out = d->g_out, a.g_gates0 = d->g_gates0, a.g_gates1 = d->g_gates1, a.g_outtot = d->g_outtot;
+  a.g_c0 = d->g_c0, a.g_c1 = d->g_c1, a.T = d->T, a.B = d->B, a.O = d->O;
+  return 0;
+}
+
+static void allow_lds() {
+  static bool done = false;
+  if (done) return;
+  (void)hipFuncSetAttribute((const void *)decoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)decoder_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  done = true;
+}
+static size_t image_bytes() { return sizeof(float) * (size_t)G4 * (H + 1); }   // the largest staged matrix (4H x H, O <= H)
+
+extern "C" int p2c_decoder_fwd(const p2c_decoder_desc *d, void *stream) {
+  Args a;
+  int rc = fill(a, d);
+  if (rc) return rc;
+  if (!a.out || !a.acts0 || !a.acts1 || !a.h0d || !a.h1) return P2C_E_NULL;
+  if (a.B == 0 || a.T == 0) return 0;
+  allow_lds();
+  hipLaunchKernelGGL(decoder_fwd_kernel, dim3((unsigned)((a.B + TS - 1) / TS)), dim3(256), image_bytes(), (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int p2c_decoder_bwd(const p2c_decoder_desc *d, void *stream) {
+  Args a;
+  int rc = fill(a, d);
+  if (rc) return rc;
+  if (!a.g_out || !a.acts0 || !a.acts1 || !a.g_gates0 || !a.g_gates1 || !a.g_outtot || !a.g_c0 || !a.g_c1) return P2C_E_NULL;
+  if (a.B == 0) return 0;
+  allow_lds();
+  hipLaunchKernelGGL(decoder_bwd_kernel, dim3((unsigned)((a.B + TS - 1) / TS)), dim3(256), image_bytes(), (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

@@ -151,8 +151,11 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         original_shape = x.shape
         batch_size, clip_length = original_shape[:2]
         hidden, cell = self.encoder(self._format_input(x))
-        step_in = torch.zeros((batch_size, self.decoder.output_size), device=x.device, dtype=x.dtype)     # <sos>
         needs_forcing, forced, force_idx = self._teacher_forcing(targets)
+        if not needs_forcing and self._decoder_loop_fusable(x):
+            # K7c: the T decoder steps (frozen encoder state, output fed back) are ONE HIP launch
+            return self._format_output(original_shape, self._fused_decoder(hidden, cell, clip_length))
+        step_in = torch.zeros((batch_size, self.decoder.output_size), device=x.device, dtype=x.dtype)     # <sos>
         outputs = []
         for t in range(clip_length):
             # NB: (hidden, cell) are the encoder's for every frame -- see module docstring
@@ -162,6 +165,27 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
                 step_in = torch.where(force_idx[t].unsqueeze(-1), forced[t], out)
             outputs.append(out)
         return self._format_output(original_shape, torch.stack(outputs, 0))
+
+    def _decoder_loop_fusable(self, x: Tensor) -> bool:
+        from pedestrians_video_2_carla_amd import ops
+        rnn = self.decoder.rnn
+        return (_fused_ok(rnn, x) and rnn.bias and isinstance(self.decoder.fc_out, nn.Linear)
+                and ops.decoder_loop_supported(rnn.hidden_size, rnn.num_layers, self.decoder.output_size))
+
+    def _fused_decoder(self, hidden: Tensor, cell: Tensor, clip_length: int) -> Tensor:
+        from pedestrians_video_2_carla_amd import ops
+        rnn, fc = self.decoder.rnn, self.decoder.fc_out
+        lin = torch.nn.functional.linear
+        # the decoder state is the encoder's for every frame: its recurrent terms are per-clip constants
+        k0 = lin(hidden[0], rnn.weight_hh_l0, rnn.bias_ih_l0 + rnn.bias_hh_l0)
+        k1 = lin(hidden[1], rnn.weight_hh_l1, rnn.bias_ih_l1 + rnn.bias_hh_l1)
+        drop = None
+        if rnn.dropout > 0 and rnn.training:      # nn.LSTM's inter-layer dropout, one mask tensor for all frames
+            keep = 1.0 - rnn.dropout
+            drop = torch.empty(clip_length, hidden.shape[1], rnn.hidden_size, device=hidden.device,
+                               dtype=hidden.dtype).bernoulli_(keep).div_(keep)
+        return ops.decoder_loop(k0, cell[0].contiguous(), k1, cell[1].contiguous(), rnn.weight_ih_l0, rnn.weight_ih_l1,
+                                fc.weight, fc.bias, clip_length, drop)
 
     def _format_output(self, original_shape, outputs):
         outputs = outputs.permute(1, 0, 2).reshape(*original_shape[:2], len(self.output_nodes), self.output_features)

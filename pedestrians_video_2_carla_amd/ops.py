@@ -629,3 +629,77 @@ def lstm_layer(x: Tensor, h0: Tensor, c0: Tensor, w_ih: Tensor, w_hh: Tensor, b_
     bias = None if b_ih is None else (b_ih + b_hh if b_hh is not None else b_ih)
     gx = torch.nn.functional.linear(x.reshape(T * B, I), w_ih, bias).view(T, B, -1)
     return LSTMRecurrenceFunction.apply(gx, h0, c0, w_hh)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Seq2Seq decoder loop (K7c)
+# ----------------------------------------------------------------------------------------------------------------------
+def decoder_loop_supported(hidden_size: int, num_layers: int, output_size: int) -> bool:
+    return hidden_size == 64 and num_layers == 2 and 1 <= output_size <= 64
+
+
+class DecoderLoopFunction(torch.autograd.Function):
+    """out (T,B,O): T applications of fc(LSTM_2layers(x; frozen encoder state)) to its own output, one launch.
+
+    k0, k1 (B,4H) = b_ih_l + b_hh_l + hidden_l W_hh_l^T; c0, c1 (B,H) = encoder cell states; drop = (T,B,H) dropout mask
+    (already divided by the keep probability) or None."""
+
+    @staticmethod
+    def forward(ctx, k0, c0, k1, c1, w_ih0, w_ih1, w_fc, b_fc, drop, T: int):
+        lib = _lib.lib()
+        k0, c0, k1, c1, w_ih0, w_ih1, w_fc, b_fc = (_require_device(t, n) for t, n in (
+            (k0, 'k0'), (c0, 'c0'), (k1, 'k1'), (c1, 'c1'), (w_ih0, 'weight_ih_l0'), (w_ih1, 'weight_ih_l1'),
+            (w_fc, 'fc_out.weight'), (b_fc, 'fc_out.bias')))
+        drop = None if drop is None else _require_device(drop, 'dropout mask')
+        B, H = c0.shape
+        O = w_fc.shape[0]
+        if not decoder_loop_supported(H, 2, O) or w_ih0.shape != (4 * H, O) or w_ih1.shape != (4 * H, H) \
+                or w_fc.shape != (O, H) or k0.shape != (B, 4 * H) or k1.shape != (B, 4 * H) or c1.shape != (B, H):
+            raise RuntimeError('decoder loop: unsupported or inconsistent shapes')
+        f32 = dict(dtype=torch.float32, device=c0.device)
+        out = torch.empty(T, B, O, **f32)
+        acts0, acts1 = torch.empty(T, B, 4 * H, **f32), torch.empty(T, B, 4 * H, **f32)
+        h0d, h1 = torch.empty(T, B, H, **f32), torch.empty(T, B, H, **f32)
+        d = _lib.DecoderDesc()
+        d.T, d.B, d.H, d.O = T, B, H, O
+        d.k0, d.c0, d.k1, d.c1 = k0.data_ptr(), c0.data_ptr(), k1.data_ptr(), c1.data_ptr()
+        d.w_ih0, d.w_ih1, d.w_fc, d.b_fc = w_ih0.data_ptr(), w_ih1.data_ptr(), w_fc.data_ptr(), b_fc.data_ptr()
+        d.drop = _ptr(drop)
+        d.out, d.acts0, d.acts1, d.h0d, d.h1 = (t.data_ptr() for t in (out, acts0, acts1, h0d, h1))
+        with torch.cuda.device(c0.device):
+            _lib.check(lib.p2c_decoder_fwd(ctypes.byref(d), _stream()), 'p2c_decoder_fwd')
+        ctx.save_for_backward(k0, c0, k1, c1, w_ih0, w_ih1, w_fc, b_fc, drop, out, acts0, acts1, h0d, h1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.lib()
+        k0, c0, k1, c1, w_ih0, w_ih1, w_fc, b_fc, drop, out, acts0, acts1, h0d, h1 = ctx.saved_tensors
+        T, B, O = out.shape
+        H = c0.shape[1]
+        g_out = _require_device(g_out, 'grad out')
+        f32 = dict(dtype=torch.float32, device=out.device)
+        gg0, gg1 = torch.empty(T, B, 4 * H, **f32), torch.empty(T, B, 4 * H, **f32)
+        gtot, gc0, gc1 = torch.empty(T, B, O, **f32), torch.empty(B, H, **f32), torch.empty(B, H, **f32)
+        d = _lib.DecoderDesc()
+        d.T, d.B, d.H, d.O = T, B, H, O
+        d.k0, d.c0, d.k1, d.c1 = k0.data_ptr(), c0.data_ptr(), k1.data_ptr(), c1.data_ptr()
+        d.w_ih0, d.w_ih1, d.w_fc, d.b_fc = w_ih0.data_ptr(), w_ih1.data_ptr(), w_fc.data_ptr(), b_fc.data_ptr()
+        d.drop = _ptr(drop)
+        d.acts0, d.acts1, d.h0d, d.h1 = acts0.data_ptr(), acts1.data_ptr(), h0d.data_ptr(), h1.data_ptr()
+        d.g_out, d.g_gates0, d.g_gates1, d.g_outtot = g_out.data_ptr(), gg0.data_ptr(), gg1.data_ptr(), gtot.data_ptr()
+        d.g_c0, d.g_c1 = gc0.data_ptr(), gc1.data_ptr()
+        with torch.cuda.device(out.device):
+            _lib.check(lib.p2c_decoder_bwd(ctypes.byref(d), _stream()), 'p2c_decoder_bwd')
+        # weight gradients: dense reductions over all (t, b) at once -- library GEMMs
+        g0 = gg0.view(T * B, 4 * H)
+        g_w_ih0 = g0[B:].t() @ out[:-1].reshape(-1, O) if T > 1 else torch.zeros_like(w_ih0)   # x_0 = <sos> = 0
+        g_w_ih1 = gg1.view(T * B, 4 * H).t() @ h0d.view(T * B, H)
+        g_w_fc = gtot.view(T * B, O).t() @ h1.view(T * B, H)
+        return (gg0.sum(0), gc0, gg1.sum(0), gc1, g_w_ih0, g_w_ih1, g_w_fc, gtot.sum((0, 1)), None, None)
+
+
+def decoder_loop(k0: Tensor, c0: Tensor, k1: Tensor, c1: Tensor, w_ih0: Tensor, w_ih1: Tensor, w_fc: Tensor, b_fc: Tensor,
+                 T: int, drop: Optional[Tensor] = None) -> Tensor:
+    _prefer_rocblas_once()
+    return DecoderLoopFunction.apply(k0, c0, k1, c1, w_ih0, w_ih1, w_fc, b_fc, drop, T)

@@ -73,3 +73,41 @@ def test_no_cpu_fallback():
     with pytest.raises(_lib.P2CError):
         ops.lstm_layer(torch.zeros(2, 3, 4), torch.zeros(3, 16), torch.zeros(3, 16), torch.zeros(64, 4), torch.zeros(64, 16),
                        None, None)
+
+
+@pytest.mark.parametrize('T,B,O,with_drop', [(1, 1, 52, False), (16, 37, 52, True), (5, 16, 64, False), (16, 130, 12, True)])
+def test_decoder_loop_matches_the_per_step_formula(T, B, O, with_drop):
+    """K7c against the reference loop written out in fp64: out_t = fc(cell1(cell0(x_t))) with the frozen encoder state."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    H = 64
+    g = torch.Generator().manual_seed(T * 7 + B)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64) * 0.3
+    P = {'k0': rnd(B, 4 * H), 'c0': rnd(B, H), 'k1': rnd(B, 4 * H), 'c1': rnd(B, H), 'w_ih0': rnd(4 * H, O),
+         'w_ih1': rnd(4 * H, H), 'w_fc': rnd(O, H), 'b_fc': rnd(O)}
+    drop = (torch.rand(T, B, H, generator=g) < 0.8).double() / 0.8 if with_drop else None
+    up = torch.randn(T, B, O, generator=g, dtype=torch.float64)
+
+    def cell(gates, c_enc):
+        i, f, gg, o = gates.chunk(4, -1)
+        return torch.sigmoid(o) * torch.tanh(torch.sigmoid(f) * c_enc + torch.sigmoid(i) * torch.tanh(gg))
+
+    R = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    x, outs = torch.zeros(B, O, dtype=torch.float64), []
+    for t in range(T):
+        h0 = cell(x @ R['w_ih0'].t() + R['k0'], R['c0'])
+        if drop is not None:
+            h0 = h0 * drop[t]
+        h1 = cell(h0 @ R['w_ih1'].t() + R['k1'], R['c1'])
+        x = h1 @ R['w_fc'].t() + R['b_fc']
+        outs.append(x)
+    ref = torch.stack(outs)
+    (ref * up).sum().backward()
+
+    D = {k: v.float().to(d).requires_grad_(True) for k, v in P.items()}
+    out = ops.decoder_loop(D['k0'], D['c0'], D['k1'], D['c1'], D['w_ih0'], D['w_ih1'], D['w_fc'], D['b_fc'], T,
+                           None if drop is None else drop.float().to(d))
+    (out * up.float().to(d)).sum().backward()
+    close(out, ref, 'out')
+    for k in P:
+        close(D[k].grad, R[k].grad, 'grad ' + k, rtol=2e-4)
