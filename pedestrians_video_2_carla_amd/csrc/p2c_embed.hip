@@ -34,25 +34,43 @@ __device__ __forceinline__ int64_t out_row(const Args &a, int64_t in_row) {
   return (int64_t)(a.flip ? a.T - 1 - t : t) * a.B + bb;
 }
 
-// one thread = four consecutive embedding channels of one joint-frame (16-byte store)
+// one thread = four consecutive embedding channels of one joint, for ROWS consecutive frames: the 4 x C weights and the
+// bias are read once per thread and stay in registers; per frame it reads C floats and stores 16 bytes
+constexpr int ROWS = 8;
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const Args a) {
   const int e4n = a.E >> 2;
-  const int64_t total = (int64_t)a.B * a.T * a.J * e4n;
+  const int64_t N = (int64_t)a.B * a.T;
+  const int64_t nblk = (N + ROWS - 1) / ROWS;
+  const int64_t total = nblk * a.J * e4n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int e = (int)(i % e4n) * 4;
-    const int64_t nj = i / e4n;
-    const int j = (int)(nj % a.J);
-    const int64_t n = nj / a.J;
-    const float *xp = a.x + (n * a.J + j) * a.C;
+    const int64_t bj = i / e4n;
+    const int j = (int)(bj % a.J);
+    const int64_t n0 = (bj / a.J) * ROWS;
     const float *w = a.W + j * a.w_stride + (int64_t)e * a.C;
     const float *bp = a.b + j * a.b_stride + e;
-    f32x4 acc = {bp[0], bp[1], bp[2], bp[3]};
-    for (int c = 0; c < a.C; ++c) {
-      const float xv = xp[c];
+    float wr[4][MAXC];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = fmaf(w[k * a.C + c], xv, acc[k]);
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) wr[k][c] = (c < a.C) ? w[k * a.C + c] : 0.f;
+    const f32x4 bias = {bp[0], bp[1], bp[2], bp[3]};
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const int64_t n = n0 + r;
+      if (n < N) {
+        const float *xp = a.x + (n * a.J + j) * a.C;
+        f32x4 acc = bias;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < a.C) {
+            const float xv = xp[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] = fmaf(wr[k][c], xv, acc[k]);
+          }
+        *reinterpret_cast<f32x4 *>(a.y + (out_row(a, n) * a.J + j) * a.E + e) = acc;
+      }
     }
-    *reinterpret_cast<f32x4 *>(a.y + (out_row(a, n) * a.J + j) * a.E + e) = acc;
   }
 }
 
@@ -98,7 +116,15 @@ __global__ __launch_bounds__(256) void embed_bwd_reduce_kernel(const Args a) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   float s = 0.f;
-  for (int ch = 0; ch < a.n_chunks; ++ch) s += a.partials[(size_t)ch * total + i];
+  int ch = 0;
+  for (; ch + 8 <= a.n_chunks; ch += 8) {        // eight loads in flight, added in chunk order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = a.partials[(size_t)(ch + u) * total + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; ch < a.n_chunks; ++ch) s += a.partials[(size_t)ch * total + i];
   const int c = i % per, je = i / per, e = je % a.E, j = je / a.E;
   if (c < a.C) a.gW[j * a.w_stride + (int64_t)e * a.C + c] = s;
   else a.gb[j * a.b_stride + e] = s;
@@ -140,7 +166,7 @@ extern "C" int p2c_embed_fwd(const float *x, const float *W, const float *b, int
   if ((reinterpret_cast<uintptr_t>(y) & 15) != 0) return P2C_E_SHAPE;
   if (B == 0) return 0;
   a.y = y;
-  const int64_t total = (int64_t)B * T * J * (E >> 2);
+  const int64_t total = (((int64_t)B * T + ROWS - 1) / ROWS) * J * (E >> 2);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
