@@ -245,6 +245,26 @@ typedef struct p2c_decoder_desc {
 P2C_API int p2c_decoder_fwd(const p2c_decoder_desc *desc, void *stream);
 P2C_API int p2c_decoder_bwd(const p2c_decoder_desc *desc, void *stream);
 
+/* ---- validation metrics on device -------------------------------------------------------------------------
+ * p2c_eval_pose3d: MPJPE (metrics/mpjpe.py:29-45) and MRPE (metrics/mrpe.py:38-76) of one batch, ADDED to `state`
+ * (4 doubles, device, zeroed by the caller at reset): state[0] += sum over clips of mean_{t,j} |pred - gt| over the common
+ * joints, state[1] += B, state[2] += sum over clips of mean_t |(world_pred + hips_pred) - (world_gt + hips_gt)|,
+ * state[3] += B (only when the world locations are given). pred (B,T,26,3); gt (B,T,Jg,3); gmap[26] = gt joint of
+ * prediction joint j or -1; world_* = ABSOLUTE world locations (B,T,3) or both NULL. Metres in, metres out (compute() =
+ * 1000 * sum / count). partials: p2c_eval_workspace_floats(B) floats.
+ * p2c_eval_pck: PCK (metrics/pck.py:66-98): state[0] += correct, state[2] += total. pred (N,Jp,Cp), gt (N,Jg,Cg), N = B*T,
+ * Jg <= 64; pmap[Jg] = prediction joint paired with gt joint i or -1; mask_src = targets['projection_2d'] (N,Jg,Cg) or NULL
+ * (= gt); hips_joint = gt joint that is never masked or -1; norm_mode 0 = bounding-box diagonal, 1 = |neck - hips| of the
+ * gt frame. partials: p2c_eval_workspace_floats(N) floats. */
+P2C_API int64_t p2c_eval_workspace_floats(int64_t units);
+P2C_API int p2c_eval_pose3d(const float *pred, const float *gt, int32_t B, int32_t T, int32_t Jg, const int32_t *gmap,
+                    const int32_t *pred_hips, int32_t n_pred_hips, const int32_t *gt_hips, int32_t n_gt_hips,
+                    const float *world_pred, const float *world_gt, float *partials, double *state, void *stream);
+P2C_API int p2c_eval_pck(const float *pred, const float *gt, const float *mask_src, int64_t N, int32_t Jp, int32_t Cp,
+                 int32_t Jg, int32_t Cg, const int32_t *pmap, int32_t mask_missing, int32_t hips_joint, int32_t norm_mode,
+                 const int32_t *hips_idx, int32_t n_hips, const int32_t *neck_idx, int32_t n_neck, float threshold,
+                 float near_zero, float *partials, double *state, void *stream);
+
 /* ---- fused AdamW / Adam over one flat fp32 buffer ------------------------------------------------------------------
  * Replaces torch.optim.AdamW.step() as configured by the reference (modules/flow/base_model.py:156-158) when all
  * trainable parameters live in one flat buffer. Update rule = torch/optim/adamw.py (amsgrad=False, maximize=False):

@@ -98,6 +98,11 @@ SYMBOLS = {
     'p2c_lstm_rec_bwd': (ctypes.c_int, [ctypes.POINTER(LstmDesc), _vp]),
     'p2c_decoder_fwd': (ctypes.c_int, [ctypes.POINTER(DecoderDesc), _vp]),
     'p2c_decoder_bwd': (ctypes.c_int, [ctypes.POINTER(DecoderDesc), _vp]),
+    'p2c_eval_workspace_floats': (_i64, [_i64]),
+    'p2c_eval_pose3d': (ctypes.c_int, [_vp, _vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _ip, _ip, ctypes.c_int32, _ip,
+                                       ctypes.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    'p2c_eval_pck': (ctypes.c_int, [_vp, _vp, _vp, _i64] + [ctypes.c_int32] * 4 + [_ip] + [ctypes.c_int32] * 3
+                     + [_ip, ctypes.c_int32, _ip, ctypes.c_int32, ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     'p2c_embed_workspace_floats': (_i64, [ctypes.c_int32] * 5),
     'p2c_embed_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp] + [ctypes.c_int32] * 6 + [_vp]),
     'p2c_embed_bwd': (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + [_vp]),

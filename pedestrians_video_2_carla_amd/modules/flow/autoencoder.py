@@ -22,6 +22,14 @@ class LitAutoencoderFlow(LitBaseFlow):
     def get_default_models(cls) -> Dict[str, torch.nn.Module]:
         return {'movements': Seq2SeqEmbeddings}
 
+    def get_metrics(self):
+        """reference autoencoder.py:73-102 (the two PCK variants; the MSE wrapper is the loss itself)."""
+        from pedestrians_video_2_carla_amd.metrics import PCK
+        kw = dict(input_nodes=self.movements_model.input_nodes, output_nodes=self.movements_model.output_nodes,
+                  mask_missing_joints=self.mask_missing_joints, key=self._outputs_key)
+        return {'PCKhn@01': PCK(threshold=0.1, get_normalization_tensor='hn', **kw),
+                'PCK@005': PCK(threshold=0.05, get_normalization_tensor='bbox', **kw)}
+
     def _inner_step(self, frames, targets, edge_index=None, batch_vector=None, stage='train'):
         model = self.movements_model
         pose_inputs = model(frames, targets=targets if self.training and model.needs_targets else None,

@@ -11,7 +11,7 @@ Differences, all about host synchronisation:
     Here a NaN/inf loss is dropped only when ``strict_nan_check=True`` (reference behaviour, syncs); by default the value
     is kept on device and ``check_finite()`` can be called every N steps.
   * ``self.log`` receives device tensors; nothing calls ``.item()`` inside the step.
-Metrics / video logging / W&B are out of scope: ``get_metrics`` returns {} and
+Video logging / W&B are out of scope; validation metrics are device metrics (``get_metrics``) and
 ``_log_videos`` is a no-op hook.
 """
 import platform
@@ -102,7 +102,33 @@ class LitBaseFlow(LightningModuleBase):
         return {}
 
     def get_metrics(self):
+        """Metrics updated on every validation / test batch (reference base.py:146-151). The flows return device metrics
+        (``pedestrians_video_2_carla_amd.metrics``): one HIP launch per update, host sync only in ``compute()``."""
         return {}
+
+    @property
+    def metrics(self):
+        if getattr(self, '_metrics', None) is None:
+            self._metrics = dict(self.get_metrics())
+        return self._metrics
+
+    def _update_metrics(self, outputs):
+        """base.py:472-473 ``self.metrics(outputs['preds'], outputs['targets'])`` -- update only, nothing is read back."""
+        preds = {k: v for k, v in outputs['preds'].items() if v is not None}
+        for metric in self.metrics.values():
+            metric.update(preds, outputs['targets'])
+
+    def compute_metrics(self, reset: bool = True, sync: bool = True):
+        """End of a validation / test epoch: {name: value}; ``sync`` all-reduces the device states over the ranks first."""
+        out = {}
+        for name, metric in self.metrics.items():
+            if sync:
+                metric.sync()
+            if metric._state is not None and float(metric._state.abs().sum()) > 0:
+                out[name] = float(metric.compute())
+            if reset:
+                metric.reset()
+        return out
 
     def get_initial_metrics(self):
         return {}
@@ -145,10 +171,14 @@ class LitBaseFlow(LightningModuleBase):
         return self._step(batch, batch_idx, 'train')
 
     def validation_step(self, batch, batch_idx):
-        return self._step(batch, batch_idx, 'val')
+        out = self._step(batch, batch_idx, 'val')
+        self._update_metrics(out)
+        return out
 
     def test_step(self, batch, batch_idx):
-        return self._step(batch, batch_idx, 'test')
+        out = self._step(batch, batch_idx, 'test')
+        self._update_metrics(out)
+        return out
 
     # ---- the step ---------------------------------------------------------------------------------------------------
     def _unwrap_batch(self, batch):

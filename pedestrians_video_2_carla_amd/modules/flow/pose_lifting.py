@@ -59,6 +59,12 @@ class LitPoseLiftingFlow(LitBaseFlow):
     def get_default_models(cls) -> Dict[str, torch.nn.Module]:
         return {'trajectory': ZeroTrajectory, 'movements': LinearAE}
 
+    def get_metrics(self):
+        """reference pose_lifting.py:88-105 (MPJPE, MRPE; the FB_* wrappers need the absent third_party code)."""
+        from pedestrians_video_2_carla_amd.metrics import MPJPE, MRPE
+        nodes = dict(input_nodes=self.movements_model.input_nodes, output_nodes=self.movements_model.output_nodes)
+        return {'MPJPE': MPJPE(**nodes), 'MRPE': MRPE(**nodes)}
+
     def _get_crucial_keys(self):
         return [self._outputs_key, *_PROJECTION_KEYS]
 

@@ -329,5 +329,56 @@ def main():
         npz('model_' + name, frames=frames, out=out, n_params=sum(p.numel() for p in model.parameters()), **sd)
 
 
+def golden_metrics():
+    """Section 9: the reference's own MPJPE / MRPE / PCK classes (metrics/mpjpe.py, mrpe.py, pck.py), run on
+    two batches each. torchmetrics is absent from the image: its ``Metric`` base gets a stand-in that keeps ``add_state``
+    values as attributes (update / compute of the reference run unmodified)."""
+    class Metric(torch.nn.Module):
+        def __init__(self, dist_sync_on_step=False, **kwargs):
+            super().__init__()
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            setattr(self, name, default.clone())
+
+    _module('torchmetrics', Metric=Metric)
+    from pedestrians_video_2_carla.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla.data.openpose.skeleton import BODY_25_SKELETON
+    from pedestrians_video_2_carla.metrics.mpjpe import MPJPE
+    from pedestrians_video_2_carla.metrics.mrpe import MRPE
+    from pedestrians_video_2_carla.metrics.pck import PCK
+    g = torch.Generator().manual_seed(99)
+    out = {}
+    batches = []
+    for k in range(2):
+        B = 3 + k
+        batches.append(dict(
+            pred_abs=torch.randn(B, 16, 26, 3, generator=g), gt_abs=torch.randn(B, 16, 26, 3, generator=g),
+            gt_abs_b25=torch.randn(B, 16, 25, 3, generator=g),
+            pred_wlc=torch.randn(B, 16, 3, generator=g) * 0.05, gt_wlc=torch.randn(B, 16, 3, generator=g) * 0.05,
+            pred_p2d=torch.rand(B, 16, 26, 2, generator=g) * 400 + 100, gt_p2d=torch.rand(B, 16, 26, 2, generator=g) * 400 + 100))
+        batches[-1]['pred_p2d'] = batches[-1]['gt_p2d'] + torch.randn(B, 16, 26, 2, generator=g) * 12
+        batches[-1]['gt_p2d'][0, 0, 5] = 0          # a missing ground-truth joint (masked out of PCK)
+        for name, v in batches[-1].items():
+            out[f'b{k}_{name}'] = v
+    m1, m2 = MPJPE(), MPJPE(input_nodes=BODY_25_SKELETON, output_nodes=CARLA_SKELETON)
+    m3 = MRPE()
+    pck_bbox, pck_hn = PCK(), PCK(get_normalization_tensor='hn', threshold=0.2)
+    for b in batches:
+        m1.update({'absolute_pose_loc': b['pred_abs']}, {'absolute_pose_loc': b['gt_abs']})
+        m2.update({'absolute_pose_loc': b['pred_abs']}, {'absolute_pose_loc': b['gt_abs_b25']})
+        m3.update({'absolute_pose_loc': b['pred_abs'], 'world_loc_changes': b['pred_wlc']},
+                  {'absolute_pose_loc': b['gt_abs'], 'world_loc_changes': b['gt_wlc']})
+        for p in (pck_bbox, pck_hn):
+            p.update({'projection_2d': b['pred_p2d']}, {'projection_2d': b['gt_p2d']})
+    npz('metrics', mpjpe=m1.compute(), mpjpe_body25=m2.compute(), mrpe=m3.compute(), pck_bbox=pck_bbox.compute(),
+        pck_hn=pck_hn.compute(), pck_bbox_correct=pck_bbox.correct, pck_bbox_total=pck_bbox.total, **out)
+
+
 if __name__ == '__main__':
-    main()
+    if sys.argv[1:] == ['metrics']:
+        install_standins()
+        sys.path.insert(0, REF_SRC)
+        golden_metrics()
+    else:
+        main()
+        golden_metrics()

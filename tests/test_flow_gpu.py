@@ -274,3 +274,22 @@ def test_graph_replay_equals_eager_and_loss_curve_matches_cpu():
     rel = ((eager - cpu).abs() / cpu.abs()).max().item()
     print('loss curve: first', float(eager[0]), 'last', float(eager[-1]), 'max rel dev vs CPU', rel)
     assert rel < 1e-4, f'loss curve deviates by {rel:.2e}'
+
+
+def test_validation_updates_device_metrics():
+    """validation_step feeds MPJPE / MRPE (pose lifting) from the materialised outputs; values = oracle on the same tensors."""
+    from oracle import metrics as OM
+    d = dev()
+    flow, dm = make(B=6, missing=0.0, lean=False)
+    flow.attach_datamodule(dm)
+    flow.to(d).eval()
+    batch = dm.generate_batch(d)
+    flow.on_validation_batch_start(batch, 0)
+    with torch.no_grad():
+        out = flow.validation_step(batch, 0)
+        out2 = flow.validation_step(batch, 1)
+    vals = flow.compute_metrics(sync=False)
+    assert set(vals) >= {'MPJPE'}
+    s, n = OM.mpjpe_update(out['preds']['absolute_pose_loc'].double().cpu(), out['targets']['absolute_pose_loc'].double().cpu())
+    assert abs(vals['MPJPE'] - 1000 * float(s) / n) <= 1e-4 * vals['MPJPE']
+    assert flow.compute_metrics(sync=False) == {}                  # reset
