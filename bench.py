@@ -99,7 +99,7 @@ def kernel_times(device, B, reps=20):
             _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), s), 'fwd')
 
         def bwd():
-            _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, gy.data_ptr(), s), 'bwd')
+            _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, None, gy.data_ptr(), s), 'bwd')
 
         fwd()
         bwd()

@@ -128,10 +128,11 @@ P2C_API int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream);
  * NULL = no gradient, or one float): the upstream gradients of (loc_2d, loc_3d, loc_2d_3d) -- for a 3-vector gradient g
  * pass {g, g+1, g+2}; NULL array = all zero. desc->loss_sums and desc->final_rel_rot must hold the forward's values.
  * Optional upstream gradients of materialised outputs (NULL = none): grad_absolute_pose_loc (B,T,26,3),
- * grad_projection_2d_transformed (B,T,26,3) [channel 2 ignored]. One launch. */
+ * grad_projection_2d_transformed (B,T,26,3) [channel 2 ignored], grad_absolute_pose_rot (B,T,26,3,3) [6-D kinds only:
+ * rot_3d-type losses, reference loss/rot_3d.py; P2C_E_ENUM for the matrix kinds]. One launch. */
 P2C_API int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *const grad_losses[3],
                       const float *grad_absolute_pose_loc, const float *grad_projection_2d_transformed,
-                      float *grad_y, void *stream);
+                      const float *grad_absolute_pose_rot, float *grad_y, void *stream);
 
 /* Stand-alone normaliser (Normalizer.__call__, dim = 2 or 3) over N frames of J joints with C channels (C >= dim).
  * out (N,J,C), shift (N,dim), scale (N); shift/scale may be NULL. */

@@ -550,6 +550,20 @@ __device__ __forceinline__ void loss_coefs(const p2c_pose_head_desc &d, const Gr
   coef3 = (d.gt3d && n3 > 0.f) ? 2.f * g3 / n3 : 0.f;
 }
 
+// Torque of an upstream gradient G on the ABSOLUTE ROTATION of this lane's joint (rot_3d-type losses, loss/rot_3d.py:9-37):
+// a virtual world rotation d_theta of the subtree turns A_m into A_m (I + [d_theta]x), so dL = d_theta . t_m with
+// t_m = (P_zy - P_yz, P_xz - P_zx, P_yx - P_xy), P = A_m^T G_m; its subtree sum joins the location torque
+// (tools/proto_rot_bwd.py: 1e-15 against autograd).
+__device__ __forceinline__ V3 rotation_torque(const float *g_rot_ext, size_t joint_frame, const M3 &A, bool active) {
+  if (!active) return v3(0.f, 0.f, 0.f);
+  M3 G;
+  const float *p = g_rot_ext + joint_frame * 9;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) G.m[i] = p[i];
+  const M3 P = mulTN(A, G);
+  return v3(P.m[7] - P.m[5], P.m[2] - P.m[6], P.m[3] - P.m[1]);
+}
+
 template <int KIND>
 struct KindTraits {
   static constexpr bool SIXD = (KIND == P2C_KIND_POSE_CHANGES_6D || KIND == P2C_KIND_RELATIVE_ROT_6D);
@@ -833,7 +847,7 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
 template <int KIND>
 __global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(const p2c_pose_head_desc d, const GradLosses grad_losses,
                                                                  const float *g_abs_ext, const float *g_projt_ext,
-                                                                 float *grad_y) {
+                                                                 const float *g_rot_ext, float *grad_y) {
   using K = KindTraits<KIND>;
   static_assert(K::SIXD, "tangent-space backward is for the 6-D kinds");
   const LaneCtx L = make_lane(d);
@@ -888,6 +902,11 @@ __global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(
     V3 SubF = shfl(PF, L.base + L.sub_end) - (PF - F);
     V3 SubX = shfl(PX, L.base + L.sub_end) - (PX - FX);
     V3 tau = SubX - cross(SubF, x);
+    if (g_rot_ext) {
+      const V3 tm = rotation_torque(g_rot_ext, ((size_t)L.clip * T + t) * J + L.j, A, L.active);
+      const V3 PT = v3(group_prefix(tm.x), group_prefix(tm.y), group_prefix(tm.z));
+      tau = tau + (shfl(PT, L.base + L.sub_end) - (PT - tm));
+    }
     V3 taup = vmul(vmulT(tau, A), R);  // tau A^T R
     V3 g;
     if (K::SCAN) {
@@ -1039,7 +1058,7 @@ __global__ __launch_bounds__(1024) void pose_head_rot_fwd_tp(const p2c_pose_head
 template <int KIND>
 __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_pose_head_desc d, const GradLosses grad_losses,
                                                                      const float *g_abs_ext, const float *g_projt_ext,
-                                                                     float *grad_y) {
+                                                                     const float *g_rot_ext, float *grad_y) {
   using K = KindTraits<KIND>;
   static_assert(K::SIXD, "tangent-space backward is for the 6-D kinds");
   extern __shared__ float tp_lds[];
@@ -1083,6 +1102,11 @@ __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_p
   V3 SubF = shfl(PF, L.base + L.sub_end) - (PF - F);
   V3 SubX = shfl(PX, L.base + L.sub_end) - (PX - FX);
   V3 tau = SubX - cross(SubF, x);
+  if (g_rot_ext) {
+    const V3 tm = rotation_torque(g_rot_ext, ((size_t)L.clip * T + (t < T ? t : 0)) * J + L.j, A, L.active);
+    const V3 PT = v3(group_prefix(tm.x), group_prefix(tm.y), group_prefix(tm.z));
+    tau = tau + (shfl(PT, L.base + L.sub_end) - (PT - tm));
+  }
   V3 taup = vmul(vmulT(tau, A), R);  // tau A^T R
   V3 g = taup;
   if (K::SCAN) {
@@ -1384,7 +1408,7 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
 
 extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *const grad_losses_[3],
                                  const float *grad_absolute_pose_loc, const float *grad_projection_2d_transformed,
-                                 float *grad_y, void *stream_) {
+                                 const float *grad_absolute_pose_rot, float *grad_y, void *stream_) {
   int rc = validate(desc);
   if (rc) return rc;
   if (!grad_y) return P2C_E_NULL;
@@ -1394,32 +1418,34 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
   GradLosses grad_losses{{nullptr, nullptr, nullptr}};
   if (grad_losses_)
     for (int i = 0; i < 3; ++i) grad_losses.p[i] = grad_losses_[i];
-  const float *ga = grad_absolute_pose_loc, *gp = grad_projection_2d_transformed;
+  const float *ga = grad_absolute_pose_loc, *gp = grad_projection_2d_transformed, *gr = grad_absolute_pose_rot;
+  if (gr && d.kind != P2C_KIND_POSE_CHANGES_6D && d.kind != P2C_KIND_RELATIVE_ROT_6D)
+    return P2C_E_ENUM;      // rotation-loss gradients go through the tangent-space backward of the 6-D kinds
   switch (d.kind) {
     case P2C_KIND_POSE_CHANGES_6D:
       if (!d.final_rel_rot) return P2C_E_NULL;
-      if (use_pk(d) && !ga && !gp)
+      if (use_pk(d) && !ga && !gp && !gr)
         hipLaunchKernelGGL(pk::pose_head_rot_bwd_tangent_pk<P2C_KIND_POSE_CHANGES_6D>, dim3(grid_pk(d.B)), block, 0, stream, d,
                            grad_losses, grad_y);
       else if (use_tp(d))
         hipLaunchKernelGGL(pose_head_rot_bwd_tangent_tp<P2C_KIND_POSE_CHANGES_6D>, dim3((unsigned)d.B), dim3(tp_threads(d.T)),
-                           tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, grad_y);
+                           tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, gr, grad_y);
       else
-        hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_POSE_CHANGES_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+        hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_POSE_CHANGES_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, gr, grad_y);
       break;
     case P2C_KIND_POSE_CHANGES_MAT:
       if (!d.final_rel_rot) return P2C_E_NULL;
       hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_POSE_CHANGES_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
       break;
     case P2C_KIND_RELATIVE_ROT_6D:
-      if (use_pk(d) && !ga && !gp)
+      if (use_pk(d) && !ga && !gp && !gr)
         hipLaunchKernelGGL(pk::pose_head_rot_bwd_tangent_pk<P2C_KIND_RELATIVE_ROT_6D>, dim3(grid_pk(d.B)), block, 0, stream, d,
                            grad_losses, grad_y);
       else if (use_tp(d))
         hipLaunchKernelGGL(pose_head_rot_bwd_tangent_tp<P2C_KIND_RELATIVE_ROT_6D>, dim3((unsigned)d.B), dim3(tp_threads(d.T)),
-                           tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, grad_y);
+                           tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, gr, grad_y);
       else
-        hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_RELATIVE_ROT_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
+        hipLaunchKernelGGL(pose_head_rot_bwd_tangent<P2C_KIND_RELATIVE_ROT_6D>, grid, block, 0, stream, d, grad_losses, ga, gp, gr, grad_y);
       break;
     case P2C_KIND_RELATIVE_ROT_MAT:
       hipLaunchKernelGGL(pose_head_rot_bwd<P2C_KIND_RELATIVE_ROT_MAT>, grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);

@@ -1,8 +1,10 @@
 """Loss registry (reference loss/__init__.py:18-53): enum value = (function or class, criterion[, requirements]).
 
-Only the modes of the hot path are registered; the reference's other modes (rot_3d,
-loc_rot_3d, weighted_..., cum_pose_changes, per_joint_loc_2d, heatmaps) keep the same call contract and can be added to
-this enum by a plugin without touching the flows.
+Registered: the modes of the hot path (loc_2d, loc_3d, loc_2d_3d -- fused into the HIP pose head when
+they are the only ones requested) and the rotation losses of §8f rank 2 (rot_3d, loc_rot_3d, loc_2d_loc_rot_3d,
+weighted_loc_2d_loc_rot_3d), which run on the materialised ``absolute_pose_rot`` and back-propagate through the tangent-space
+HIP backward. Not registered: cum_pose_changes, pose_changes, per_joint_loc_2d, heatmaps, common_loc_2d (deprecated) -- same
+call contract, addable without touching the flows.
 """
 from enum import Enum
 
@@ -10,10 +12,18 @@ from torch import nn
 
 from .loc_2d import Loc2DPoseLoss
 from .loc_2d_3d import calculate_loss_loc_2d_3d
+from .loc_2d_loc_rot_3d import calculate_loss_loc_2d_loc_rot_3d
 from .loc_3d import calculate_loss_loc_3d
+from .loc_rot_3d import calculate_loss_loc_rot_3d
+from .rot_3d import calculate_loss_rot_3d
+from .weighted_loc_2d_loc_rot_3d import calculate_loss_weighted_loc_2d_loc_rot_3d
 
 
 class LossModes(Enum):
     loc_2d = (Loc2DPoseLoss, nn.MSELoss(reduction='mean'))
     loc_3d = (calculate_loss_loc_3d, nn.MSELoss(reduction='mean'))
+    rot_3d = (calculate_loss_rot_3d, nn.MSELoss(reduction='mean'))
     loc_2d_3d = (calculate_loss_loc_2d_3d, None, ('loc_2d', 'loc_3d'))
+    loc_2d_loc_rot_3d = (calculate_loss_loc_2d_loc_rot_3d, None, ('loc_2d', 'loc_3d', 'rot_3d'))
+    weighted_loc_2d_loc_rot_3d = (calculate_loss_weighted_loc_2d_loc_rot_3d, None, ('loc_2d', 'loc_3d', 'rot_3d'))
+    loc_rot_3d = (calculate_loss_loc_rot_3d, None, ('loc_3d', 'rot_3d'))

@@ -219,8 +219,10 @@ class PoseHeadFunction(torch.autograd.Function):
         ctx.save_for_backward(y, skel_type, dloc, drot, gt2d, gt3d, bufs['loss_sums'], bufs.get('final_rel_rot'))
         ctx.bufs = bufs
         result = [outs[k] for k in want]
+        rot_diff = spec.kind in ('pose_changes_6d', 'relative_rot_6d')      # rot_3d-type losses: tangent-space backward
         nondiff = [outs[k] for k in want if k not in ('absolute_pose_loc', 'projection_2d_transformed')
-                   and not (k == 'projection_2d' and spec.transform == 'none')]
+                   and not (k == 'projection_2d' and spec.transform == 'none')
+                   and not (k == 'absolute_pose_rot' and rot_diff)]
         ctx.mark_non_differentiable(*nondiff)
         ctx.set_materialize_grads(False)
         vec = bufs['losses']
@@ -235,12 +237,14 @@ class PoseHeadFunction(torch.autograd.Function):
         bufs['loss_sums'] = loss_sums
         if final_rel_rot is not None:
             bufs['final_rel_rot'] = final_rel_rot
-        g_abs = g_projt = None
+        g_abs = g_projt = g_rot = None
         for k, g in zip(ctx.want, g_outs):
             if g is None:
                 continue
             if k == 'absolute_pose_loc':
                 g_abs = _require_device(g, 'grad absolute_pose_loc')
+            elif k == 'absolute_pose_rot':
+                g_rot = _require_device(g, 'grad absolute_pose_rot')
             elif k == 'projection_2d_transformed' or (k == 'projection_2d' and spec.transform == 'none'):
                 g_projt = _require_device(g, 'grad ' + k)
         scalars = [None if g is None else _require_device(g, 'grad loss') for g in (g0, g1, g2)]
@@ -254,8 +258,8 @@ class PoseHeadFunction(torch.autograd.Function):
         desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, {})
         grad_y = torch.empty_like(y)
         with torch.cuda.device(y.device):
-            _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), gl, _ptr(g_abs), _ptr(g_projt), grad_y.data_ptr(),
-                                             _stream()), 'p2c_pose_head_bwd')
+            _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), gl, _ptr(g_abs), _ptr(g_projt), _ptr(g_rot),
+                                             grad_y.data_ptr(), _stream()), 'p2c_pose_head_bwd')
         return grad_y, None, None, None, None, None, None, None
 
 

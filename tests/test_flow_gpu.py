@@ -293,3 +293,27 @@ def test_validation_updates_device_metrics():
     s, n = OM.mpjpe_update(out['preds']['absolute_pose_loc'].double().cpu(), out['targets']['absolute_pose_loc'].double().cpu())
     assert abs(vals['MPJPE'] - 1000 * float(s) / n) <= 1e-4 * vals['MPJPE']
     assert flow.compute_metrics(sync=False) == {}                  # reset
+
+
+def test_rotation_loss_modes_train_through_the_generic_path():
+    """loc_2d_loc_rot_3d (reference loss/loc_2d_loc_rot_3d.py): value and parameter gradients vs LinearAE-on-CPU + oracle."""
+    import copy
+    d = dev()
+    flow, dm = make(loss_modes=('loc_2d_loc_rot_3d',), B=6, missing=0.0)
+    flow.attach_datamodule(dm)
+    flow.to(d).train()
+    batch = dm.generate_batch(d)
+    frames, targets, meta = batch
+    flow.on_train_batch_start(batch, 0)
+    out = flow.training_step(batch, 0)
+    out['loss'].backward()
+    cpu_model = copy.deepcopy(flow.movements_model).cpu().double()
+    cpu_model.rotation_output_format = 'rotation_6d'
+    o = O.pose_head(cpu_model(frames.double().cpu()), 'pose_changes_6d', meta['skel_type'].cpu(),
+                    gt2d=targets['projection_2d_transformed'].double().cpu(), gt3d=targets['absolute_pose_loc'].double().cpu())
+    rot = torch.nn.functional.mse_loss(o['absolute_pose_rot'], targets['absolute_pose_rot'].double().cpu())
+    ref = o['loc_2d'] + o['loc_3d'] + rot
+    ref.backward()
+    close(out['loss'], ref, 'loc_2d_loc_rot_3d')
+    for (n, pg), (_, pc) in zip(flow.movements_model.named_parameters(), cpu_model.named_parameters()):
+        close(pg.grad, pc.grad, 'grad ' + n, rtol=2e-4)

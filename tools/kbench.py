@@ -50,7 +50,7 @@ def main():
                 s = stream.cuda_stream
                 tf = graph_time(lambda: _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), s), 'fwd'), stream)
                 tb = graph_time(lambda: _lib.check(lib.p2c_pose_head_bwd(
-                    ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, gy.data_ptr(), s), 'bwd'),
+                    ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, None, gy.data_ptr(), s), 'bwd'),
                     stream)
             lib.p2c_pose_head_set_time_parallel_max_batch(prev)
             lib.p2c_pose_head_set_packed_min_batch(prev_pk)

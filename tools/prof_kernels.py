@@ -35,6 +35,6 @@ gy = torch.empty_like(y)
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(reps):
     _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), s), 'fwd')
-    _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, gy.data_ptr(), s), 'bwd')
+    _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, None, gy.data_ptr(), s), 'bwd')
 torch.cuda.synchronize()
 print('done', B, float(bufs['losses'][2]))
