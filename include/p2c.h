@@ -178,8 +178,15 @@ typedef struct p2c_mlp_desc {
   float *partials;                      /* backward workspace, p2c_mlp_workspace_floats floats */
   float *w_image;                       /* p2c_mlp_image_floats floats: packed weights, WRITTEN by p2c_mlp_fwd and
                                            read by p2c_mlp_bwd (same weights: call bwd before the optimizer) */
+  int32_t skip_pack;                    /* 1 = w_image is already current (kept so by p2c_mlp_pack + the optimizer's
+                                           scatter, see p2c_adamw_desc): p2c_mlp_fwd does not launch the pack kernel */
 } p2c_mlp_desc;
 P2C_API int64_t p2c_mlp_image_floats(const p2c_mlp_desc *desc);
+/* writes the packed image from the current weights (what p2c_mlp_fwd does first unless skip_pack) */
+P2C_API int p2c_mlp_pack(const p2c_mlp_desc *desc, void *stream);
+/* HOST array out: index[i] = float offset inside the image of parameter i, parameters counted in the order
+ * W_0 (row-major), b_0, W_1, b_1, ... (n = sum of n_out * (n_in + 1)); returns n, or a negative P2C_E_* code */
+P2C_API int64_t p2c_mlp_image_index(const p2c_mlp_desc *desc, int32_t *index, int64_t capacity);
 P2C_API int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *desc);
 P2C_API int p2c_mlp_fwd(const p2c_mlp_desc *desc, void *stream);
 P2C_API int p2c_mlp_bwd(const p2c_mlp_desc *desc, void *stream);
@@ -279,6 +286,10 @@ typedef struct p2c_adamw_desc {
   const float *hyper;        /* device, 6 floats: lr, beta1, beta2, eps, weight_decay, grad_scale */
   int32_t adamw;             /* 1 = decoupled weight decay (AdamW), 0 = L2 penalty (Adam) */
   int32_t zero_grad;         /* 1 = leave grad zeroed (replaces the next step's zero_grad memset) */
+  /* optional (both or neither): after the update, param[i] is also written to scatter_dst[scatter_idx[i]] where the index
+   * is >= 0 -- keeps a consumer's re-laid-out copy of the weights (the fused MLP's LDS image) current without a pack launch */
+  const int32_t *scatter_idx;
+  float *scatter_dst;
 } p2c_adamw_desc;
 P2C_API int p2c_adamw_step(const p2c_adamw_desc *desc, void *stream);
 

@@ -47,6 +47,7 @@ class MlpDesc(ctypes.Structure):
         ('n_layers', _i32), ('dims', _i32 * (P2C_MLP_MAX_LAYERS + 1)), ('N', ctypes.c_int64), ('x', _f32p),
         ('W', _f32p * P2C_MLP_MAX_LAYERS), ('b', _f32p * P2C_MLP_MAX_LAYERS), ('y', _f32p), ('gy', _f32p),
         ('gW', _f32p * P2C_MLP_MAX_LAYERS), ('gb', _f32p * P2C_MLP_MAX_LAYERS), ('partials', _f32p), ('w_image', _f32p),
+                ('skip_pack', ctypes.c_int32),
     ]
 
 
@@ -56,7 +57,7 @@ class AdamWDesc(ctypes.Structure):
     """p2c_adamw_desc (include/p2c.h)."""
     _fields_ = [('n', ctypes.c_int64), ('param', _f32p), ('grad', _f32p), ('exp_avg', _f32p), ('exp_avg_sq', _f32p),
                 ('step', _f32p), ('ticket', _f32p), ('hyper', _f32p), ('adamw', ctypes.c_int32),
-                ('zero_grad', ctypes.c_int32)]
+                ('zero_grad', ctypes.c_int32), ('scatter_idx', _f32p), ('scatter_dst', _f32p)]
 
 
 class LstmDesc(ctypes.Structure):
@@ -93,6 +94,8 @@ SYMBOLS = {
     'p2c_remap_nodes': (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _ip, _ip, _vp]),
     'p2c_mlp_workspace_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
     'p2c_mlp_image_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
+    'p2c_mlp_pack': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
+    'p2c_mlp_image_index': (_i64, [ctypes.POINTER(MlpDesc), _ip, _i64]),
     'p2c_adamw_step': (ctypes.c_int, [ctypes.POINTER(AdamWDesc), _vp]),
     'p2c_lstm_rec_fwd': (ctypes.c_int, [ctypes.POINTER(LstmDesc), _vp]),
     'p2c_lstm_rec_bwd': (ctypes.c_int, [ctypes.POINTER(LstmDesc), _vp]),

@@ -726,6 +726,34 @@ extern "C" int64_t p2c_mlp_image_floats(const p2c_mlp_desc *d) {
   return a.w_total;
 }
 
+extern "C" int p2c_mlp_pack(const p2c_mlp_desc *d, void *stream_) {
+  MlpArgs a;
+  int rc = fill(a, d);
+  if (rc) return rc;
+  if (!a.w_image) return P2C_E_NULL;
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3((a.w_total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int64_t p2c_mlp_image_index(const p2c_mlp_desc *d, int32_t *index, int64_t capacity) {
+  if (!d || !index) return P2C_E_NULL;
+  if (d->n_layers < 1 || d->n_layers > P2C_MLP_MAX_LAYERS) return P2C_E_SHAPE;
+  int64_t n = 0;
+  int off = 0;
+  for (int l = 0; l < d->n_layers; ++l) {
+    const int n_in = d->dims[l], n_out = d->dims[l + 1];
+    if (n_in < 1 || n_out < 1 || n_in > MAXW - 1 || n_out > MAXW - 1) return P2C_E_SHAPE;
+    const int ld = ld_of(n_in);
+    if (n + (int64_t)n_out * (n_in + 1) > capacity) return P2C_E_SHAPE;
+    for (int r = 0; r < n_out; ++r)
+      for (int k = 0; k < n_in; ++k) index[n++] = off + r * ld + k;
+    for (int r = 0; r < n_out; ++r) index[n++] = off + r * ld + n_in;
+    off += img_rows_of(n_out) * ld;
+  }
+  return n;
+}
+
 extern "C" int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *d) {
   MlpArgs a;
   if (fill(a, d)) return 0;
@@ -741,7 +769,8 @@ extern "C" int p2c_mlp_fwd(const p2c_mlp_desc *d, void *stream_) {
   const size_t lds = lds_fwd(a);
   if (lds > 160 * 1024) return P2C_E_SHAPE;
   allow_big_lds();
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3((a.w_total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
+  if (!d->skip_pack)
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3((a.w_total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
   hipLaunchKernelGGL(pick(a, false), dim3(n_blocks(a.N)), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

@@ -58,12 +58,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(const p2c_adamw_desc d) {
     }
     P[i] = p, M[i] = m, V[i] = v;
     if (d.zero_grad) G[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (d.scatter_idx) {                 // second copy of selected parameters in a consumer's own layout
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = d.scatter_idx[4 * i + k];
+        if (j >= 0) d.scatter_dst[j] = p[k];
+      }
+    }
   }
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += stride) {
     float p = d.param[i], m = d.exp_avg[i], v = d.exp_avg_sq[i];
     update<ADAMW>(c, p, d.grad[i], m, v);
     d.param[i] = p, d.exp_avg[i] = m, d.exp_avg_sq[i] = v;
     if (d.zero_grad) d.grad[i] = 0.f;
+    if (d.scatter_idx) {
+      const int j = d.scatter_idx[i];
+      if (j >= 0) d.scatter_dst[j] = p;
+    }
   }
   // The last workgroup to finish publishes the new step count. No fence: the counter is independent of the parameter
   // stores, every workgroup has consumed its (start-of-kernel) read of the old value before it draws a ticket, and a
@@ -84,6 +95,7 @@ extern "C" int p2c_adamw_step(const p2c_adamw_desc *desc, void *stream_) {
       !desc->hyper)
     return P2C_E_NULL;
   if (desc->n < 0) return P2C_E_SHAPE;
+  if ((desc->scatter_idx == nullptr) != (desc->scatter_dst == nullptr)) return P2C_E_NULL;
   if (desc->n == 0) return 0;
   for (const void *p : {(const void *)desc->param, (const void *)desc->grad, (const void *)desc->exp_avg,
                         (const void *)desc->exp_avg_sq})

@@ -418,15 +418,19 @@ class FusedMLPFunction(torch.autograd.Function):
     step (true for the flows here; do not combine with gradient accumulation)."""
 
     @staticmethod
-    def forward(ctx, x, n_layers, sinks, *params):
+    def forward(ctx, x, n_layers, sinks, image, skip_pack, *params):
         lib = _lib.lib()
         x = _require_device(x, 'x')
         weights = [_require_device(p, 'weight') for p in params[:n_layers]]
         biases = [_require_device(p, 'bias') for p in params[n_layers:]]
         desc = _mlp_desc(x, weights, biases)
         y = torch.empty(x.shape[0], weights[-1].shape[0], dtype=torch.float32, device=x.device)
-        image = torch.empty(lib.p2c_mlp_image_floats(ctypes.byref(desc)), dtype=torch.float32, device=x.device)
-        desc.y, desc.w_image = y.data_ptr(), image.data_ptr()
+        n_image = lib.p2c_mlp_image_floats(ctypes.byref(desc))
+        if image is None:        # per-call image, packed by this forward
+            image, skip_pack = torch.empty(n_image, dtype=torch.float32, device=x.device), False
+        elif image.numel() != n_image or image.device != x.device or image.dtype != torch.float32:
+            raise RuntimeError('packed weight image of the wrong size / device')
+        desc.y, desc.w_image, desc.skip_pack = y.data_ptr(), image.data_ptr(), int(bool(skip_pack))
         with torch.cuda.device(x.device):
             _lib.check(lib.p2c_mlp_fwd(ctypes.byref(desc), _stream()), 'p2c_mlp_fwd')
         ctx.save_for_backward(x, image, *weights, *biases)
@@ -454,13 +458,51 @@ class FusedMLPFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(lib.p2c_mlp_bwd(ctypes.byref(desc), _stream()), 'p2c_mlp_bwd')
         if ctx.sinks is not None:
-            return (None, None, None) + (None,) * (2 * n)
-        return (None, None, None, *gws, *gbs)
+            return (None, None, None, None, None) + (None,) * (2 * n)
+        return (None, None, None, None, None, *gws, *gbs)
 
 
 def fused_mlp(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor],
-              sinks: Optional[Sequence[Tensor]] = None) -> Tensor:
-    return FusedMLPFunction.apply(x, len(weights), None if sinks is None else list(sinks), *weights, *biases)
+              sinks: Optional[Sequence[Tensor]] = None, image: Optional[Tensor] = None,
+              image_is_current: bool = False) -> Tensor:
+    """``image``: optional persistent buffer (``mlp_image_floats`` floats) for the packed weights; with
+    ``image_is_current`` the forward trusts it (kept current by ``mlp_pack`` + the optimizer's scatter) and launches no
+    pack kernel."""
+    return FusedMLPFunction.apply(x, len(weights), None if sinks is None else list(sinks), image, image_is_current,
+                                  *weights, *biases)
+
+
+def mlp_image_layout(dims: Sequence[int]) -> Tuple[int, Tensor]:
+    """(floats of the packed image, int32 host tensor: image offset of every parameter in the order W_0, b_0, W_1, ...)."""
+    lib = _lib.lib()
+    d = _lib.MlpDesc()
+    d.n_layers = len(dims) - 1
+    for i, v in enumerate(dims):
+        d.dims[i] = int(v)
+    n_params = sum(o * (i + 1) for i, o in zip(dims[:-1], dims[1:]))
+    buf = (ctypes.c_int32 * n_params)()
+    n = lib.p2c_mlp_image_index(ctypes.byref(d), buf, n_params)
+    if n != n_params:
+        raise _lib.P2CError(f'p2c_mlp_image_index returned {n}')
+    # image size: the same arithmetic as the library, asked through a descriptor with dummy pointers
+    x = torch.empty(1, dims[0])
+    probe = _lib.MlpDesc()
+    probe.n_layers, probe.N, probe.x = d.n_layers, 1, 1
+    for i, v in enumerate(dims):
+        probe.dims[i] = int(v)
+    for l in range(d.n_layers):
+        probe.W[l], probe.b[l] = 1, 1
+    return int(lib.p2c_mlp_image_floats(ctypes.byref(probe))), torch.tensor(list(buf), dtype=torch.int32)
+
+
+def mlp_pack(weights: Sequence[Tensor], biases: Sequence[Tensor], image: Tensor):
+    """Write the packed image from the current weights (one small launch)."""
+    lib = _lib.lib()
+    x = weights[0]                       # any device tensor: only the geometry and the weight pointers are used
+    desc = _mlp_desc(x.new_empty(1, weights[0].shape[1]), weights, biases)
+    desc.w_image = image.data_ptr()
+    with torch.cuda.device(image.device):
+        _lib.check(lib.p2c_mlp_pack(ctypes.byref(desc), _stream()), 'p2c_mlp_pack')
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -31,11 +31,19 @@ class FlatAdamW(torch.optim.Optimizer):
         self.zero_grad_in_step = bool(zero_grad_in_step)
         self.grad_scale = 1.0
         self._uploaded = None
+        self._scatter = None                      # (int32 index per parameter, destination buffer) or None
         self._hyper = torch.zeros(6, dtype=torch.float32, device=p.device)
         self._ticket = torch.zeros(1, dtype=torch.int32, device=p.device)
         self.state[p] = {'step': torch.zeros((), dtype=torch.float32, device=p.device),
                          'exp_avg': torch.zeros_like(p, memory_format=torch.preserve_format),
                          'exp_avg_sq': torch.zeros_like(p, memory_format=torch.preserve_format)}
+
+    def set_scatter(self, index: torch.Tensor, dst: torch.Tensor):
+        """After every step, parameter i is also written to ``dst[index[i]]`` (index < 0: not copied)."""
+        (p,) = self.param_groups[0]['params']
+        if index.numel() != p.numel() or index.dtype != torch.int32 or not index.is_cuda or not dst.is_cuda:
+            raise ValueError('scatter index: one int32 per parameter, on the device')
+        self._scatter = (index.contiguous(), dst)
 
     def sync_hyper(self):
         """Upload lr / betas / eps / weight_decay / grad_scale if they changed on the host (call outside graph replay)."""
@@ -66,6 +74,8 @@ class FlatAdamW(torch.optim.Optimizer):
         d.exp_avg, d.exp_avg_sq, d.step = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), st['step'].data_ptr()
         d.ticket, d.hyper = self._ticket.data_ptr(), self._hyper.data_ptr()
         d.adamw, d.zero_grad = int(self.decoupled), int(self.zero_grad_in_step)
+        if self._scatter is not None:
+            d.scatter_idx, d.scatter_dst = self._scatter[0].data_ptr(), self._scatter[1].data_ptr()
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().p2c_adamw_step(ctypes.byref(d), torch.cuda.current_stream(p.device).cuda_stream),
                        'p2c_adamw_step')

@@ -61,6 +61,7 @@ class Trainer:
         self._graphs = None
         self._static_loss = None
         self._unit = None
+        self._packed = []
 
     # ------------------------------------------------------------------------------------------------------------
     def setup(self, flow, datamodule):
@@ -86,6 +87,9 @@ class Trainer:
                 raise ValueError('exactly one trainable plugin expected (ZeroTrajectory has no optimizer)')
             self.optimizers = [self.flat.rebuild_optimizer(configs[0]['optimizer'], **extra)]
             opt = self.optimizers[0]
+            # modules with a re-laid-out copy of their weights (the fused MLP's LDS image) let the optimizer keep it current
+            self._packed = [m for m in flow.modules() if hasattr(m, 'manage_packed_image')
+                            and m.manage_packed_image(self.flat.flat_param, opt)]
             if hasattr(opt, 'grad_scale') and self.exchange.enabled:    # FlatAdamW folds the DP averaging into its pass
                 opt.grad_scale = 1.0 / self.exchange.world
                 self.exchange.average_here = False
@@ -202,6 +206,8 @@ class Trainer:
                 t.copy_(s)
             for t in tensors[len(snapshot):]:            # optimizer state created during warm-up: back to step 0
                 t.zero_()
+        for m in getattr(self, '_packed', []):           # the parameters were rewritten behind the optimizer's back
+            m.repack()
         torch.cuda.synchronize()
 
     def fit(self, flow, datamodule, batches: Optional[Iterable] = None):

@@ -17,7 +17,7 @@ GROUPS = {
     # lean training kernels only (the materialising pose_head_rot_fwd<.., true> runs once at set-up, not in the step)
     'pose_head_rot_fwd<6D>(+loss_finalize)': ('pose_head_rot_fwd_tp<0>', 'pose_head_rot_fwd<0, false>', 'loss_finalize'),
     'pose_head_rot_bwd<6D>': ('pose_head_rot_bwd',),
-    'mlp_fwd(+pack)': ('mlp_pack_kernel', 'mlp_fwd_kernel'),
+    'mlp_fwd': ('mlp_fwd_kernel',),
     'mlp_bwd(+reduce)': ('mlp_bwd_kernel', 'mlp_reduce_kernel'),
     'adamw': ('adamw_kernel',),
 }
