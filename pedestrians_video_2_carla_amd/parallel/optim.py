@@ -45,6 +45,24 @@ class FlatAdamW(torch.optim.Optimizer):
             raise ValueError('scatter index: one int32 per parameter, on the device')
         self._scatter = (index.contiguous(), dst)
 
+    def _descriptor(self, p):
+        """The launch descriptor only holds addresses of long-lived buffers: built once, rebuilt if one of them moves."""
+        st = self.state[p]
+        key = (p.data_ptr(), p.grad.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), st['step'].data_ptr(),
+               None if self._scatter is None else (self._scatter[0].data_ptr(), self._scatter[1].data_ptr()),
+               self.decoupled, self.zero_grad_in_step)
+        if getattr(self, '_desc_key', None) != key:
+            d = _lib.AdamWDesc()
+            d.n = p.numel()
+            d.param, d.grad = p.data_ptr(), p.grad.data_ptr()
+            d.exp_avg, d.exp_avg_sq, d.step = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), st['step'].data_ptr()
+            d.ticket, d.hyper = self._ticket.data_ptr(), self._hyper.data_ptr()
+            d.adamw, d.zero_grad = int(self.decoupled), int(self.zero_grad_in_step)
+            if self._scatter is not None:
+                d.scatter_idx, d.scatter_dst = self._scatter[0].data_ptr(), self._scatter[1].data_ptr()
+            self._desc, self._desc_key = d, key
+        return self._desc
+
     def sync_hyper(self):
         """Upload lr / betas / eps / weight_decay / grad_scale if they changed on the host (call outside graph replay)."""
         g = self.param_groups[0]
@@ -67,15 +85,7 @@ class FlatAdamW(torch.optim.Optimizer):
             self.sync_hyper()
         elif self._uploaded is None:
             raise RuntimeError('FlatAdamW: call sync_hyper() (or one eager step) before capturing a graph')
-        st = self.state[p]
-        d = _lib.AdamWDesc()
-        d.n = p.numel()
-        d.param, d.grad = p.data_ptr(), p.grad.data_ptr()
-        d.exp_avg, d.exp_avg_sq, d.step = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), st['step'].data_ptr()
-        d.ticket, d.hyper = self._ticket.data_ptr(), self._hyper.data_ptr()
-        d.adamw, d.zero_grad = int(self.decoupled), int(self.zero_grad_in_step)
-        if self._scatter is not None:
-            d.scatter_idx, d.scatter_dst = self._scatter[0].data_ptr(), self._scatter[1].data_ptr()
+        d = self._descriptor(p)
         with torch.cuda.device(p.device):
             _lib.check(_lib.lib().p2c_adamw_step(ctypes.byref(d), torch.cuda.current_stream(p.device).cuda_stream),
                        'p2c_adamw_step')

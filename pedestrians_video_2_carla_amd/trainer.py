@@ -138,7 +138,10 @@ class Trainer:
             g_fb.replay()
             if g_opt is not None:
                 self.exchange.all_reduce_gradients()
-                g_opt.replay()
+                if g_opt == 'eager':
+                    self._optimizer_step()
+                else:
+                    g_opt.replay()
             loss = self._static_loss
         self.global_step += 1
         flow.global_step = self.global_step
@@ -174,9 +177,12 @@ class Trainer:
         if distributed:
             with torch.cuda.graph(g_fb):
                 self._static_loss = self._forward_backward(flow, batch, batch_idx)
-            g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_opt):
-                self._optimizer_step()
+            if all(hasattr(o, '_descriptor') for o in self.optimizers):
+                g_opt = 'eager'          # FlatAdamW is a single kernel: a direct launch has less latency than a 1-node graph
+            else:
+                g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_opt):
+                    self._optimizer_step()
         else:
             g_opt = None
             with torch.cuda.graph(g_fb):
