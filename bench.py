@@ -140,31 +140,40 @@ def _graph_us(fn, stream, reps=20, rounds=5):
     return e0.elapsed_time(e1) * 1e3 / (reps * rounds)
 
 
-def mlp_times(device, model, B):
-    """Device time of the fused LinearAE launches (pack + forward; backward + partial reduction) and of the fused AdamW
-    at N = B * T frames, through the C ABI, graph-timed like kernel_times(). Returns (times_us, macs_per_frame)."""
+def mlp_times(device, model, B, fused_update):
+    """Device time of the fused LinearAE launches at N = B * T frames, through the C ABI, graph-timed like
+    kernel_times(): forward (the optimizer keeps the weight image current: no pack launch), backward + partial reduction
+    (+ AdamW when the single-GPU trainer fuses the optimizer step into the reduction), stand-alone AdamW otherwise.
+    The weights / gradients / moments are views of flat buffers, as in the trainer."""
     import ctypes
     from pedestrians_video_2_carla_amd import _lib, ops
     from pedestrians_video_2_carla_amd.parallel.optim import FlatAdamW
     lib = _lib.lib()
-    linears = model._linears()
-    Ws = [l.weight.detach().clone() for l in linears]
-    bs = [l.bias.detach().clone() for l in linears]
+    shapes = [(l.weight.shape[0], l.weight.shape[1]) for l in model._linears()]
+    dims = [shapes[0][1]] + [o for o, _ in shapes]
+    n = sum(o * (i + 1) for o, i in shapes)
+    flat = torch.nn.Parameter(torch.randn(n, device=device) * 0.1)
+    flat.grad = torch.zeros_like(flat)
+    Ws, bs, gW, gb, off = [], [], [], [], 0
+    for o, i in shapes:
+        Ws.append(flat.data[off:off + o * i].view(o, i)), gW.append(flat.grad[off:off + o * i].view(o, i))
+        off += o * i
+        bs.append(flat.data[off:off + o]), gb.append(flat.grad[off:off + o])
+        off += o
     N = B * T_FRAMES
-    x = torch.randn(N, Ws[0].shape[1], device=device)
-    gy = torch.randn(N, Ws[-1].shape[0], device=device)
+    x = torch.randn(N, dims[0], device=device)
+    gy = torch.randn(N, dims[-1], device=device)
     desc = ops._mlp_desc(x, Ws, bs)
     f32 = dict(dtype=torch.float32, device=device)
-    y = torch.empty(N, Ws[-1].shape[0], **f32)
-    image = torch.empty(lib.p2c_mlp_image_floats(ctypes.byref(desc)), **f32)
+    y = torch.empty(N, dims[-1], **f32)
+    n_image, index = ops.mlp_image_layout(dims)
+    image = torch.empty(n_image, **f32)
     part = torch.empty(lib.p2c_mlp_workspace_floats(ctypes.byref(desc)), **f32)
-    gW, gb = [torch.empty_like(w) for w in Ws], [torch.empty_like(b) for b in bs]
     desc.y, desc.w_image, desc.gy, desc.partials = y.data_ptr(), image.data_ptr(), gy.data_ptr(), part.data_ptr()
     for i in range(len(Ws)):
         desc.gW[i], desc.gb[i] = gW[i].data_ptr(), gb[i].data_ptr()
-    flat = torch.nn.Parameter(torch.randn(sum(w.numel() + b.numel() for w, b in zip(Ws, bs)), device=device))
-    flat.grad = torch.randn_like(flat)
-    opt = FlatAdamW([flat], lr=1e-4)
+    opt = FlatAdamW([flat], lr=1e-4, zero_grad_in_step=False)
+    opt.set_scatter(index.to(device), image)
     opt.sync_hyper()
     out = {}
     stream = torch.cuda.Stream(device=device)
@@ -173,11 +182,17 @@ def mlp_times(device, model, B):
         _lib.check(lib.p2c_mlp_pack(ctypes.byref(desc), s), 'mlp pack')     # in the step the optimizer keeps the image current
         desc.skip_pack = 1
         out['mlp_fwd'] = _graph_us(lambda: _lib.check(lib.p2c_mlp_fwd(ctypes.byref(desc), s), 'mlp fwd'), stream)
-        out['mlp_bwd(+reduce)'] = _graph_us(lambda: _lib.check(lib.p2c_mlp_bwd(ctypes.byref(desc), s), 'mlp bwd'), stream)
-        out['adamw'] = _graph_us(opt.step, stream)
-    macs = sum(w.shape[0] * w.shape[1] for w in Ws)
-    macs_bwd = macs + sum(w.shape[0] * w.shape[1] for w in Ws[1:])        # wgrad of every layer + dgrad of layers 1..L-1
-    return out, {'mlp_fwd': 2 * macs * N, 'mlp_bwd(+reduce)': 2 * macs_bwd * N}
+        bwd_name = 'mlp_bwd(+reduce)'
+        if fused_update:
+            od = opt.descriptor_for_fusion()
+            desc.fused_adamw = ctypes.addressof(od)
+            bwd_name = 'mlp_bwd(+reduce+adamw)'
+        out[bwd_name] = _graph_us(lambda: _lib.check(lib.p2c_mlp_bwd(ctypes.byref(desc), s), 'mlp bwd'), stream)
+        if not fused_update:
+            out['adamw'] = _graph_us(opt.step, stream)
+    macs = sum(o * i for o, i in shapes)
+    macs_bwd = macs + sum(o * i for o, i in shapes[1:])        # wgrad of every layer + dgrad of layers 1..L-1
+    return out, {'mlp_fwd': 2 * macs * N, bwd_name: 2 * macs_bwd * N}
 
 
 def mfma_entry(name, B, us, flops):
@@ -299,7 +314,7 @@ def main():
                                         (traffic.get(f'{names[w]}@B{args.batch_size}') or {}).get('bytes')) for w in ('fwd', 'bwd')}
     breakdown = {names[w]: round(kt[w], 2) for w in ('fwd', 'bwd')}
     if getattr(flow.movements_model, 'fused_mlp', False):
-        mt, flops = mlp_times(device, flow.movements_model, args.batch_size)
+        mt, flops = mlp_times(device, flow.movements_model, args.batch_size, getattr(trainer, '_opt_in_backward', False))
         breakdown.update({k: round(v, 2) for k, v in mt.items()})
         for k, fl in flops.items():
             entries[k] = mfma_entry(k, args.batch_size, mt[k], fl)

@@ -164,6 +164,7 @@ P2C_API int p2c_remap_nodes(const float *src, float *dst, int64_t N, int32_t Jsr
  * gb[l] (dims[l+1]) -- WRITTEN, not accumulated -- through `partials` (p2c_mlp_workspace_floats floats) and a fixed-order
  * reduction (bitwise reproducible). x receives no gradient (the flows feed data). */
 #define P2C_MLP_MAX_LAYERS 8
+struct p2c_adamw_desc;
 typedef struct p2c_mlp_desc {
   int32_t n_layers;
   int32_t dims[P2C_MLP_MAX_LAYERS + 1];
@@ -178,6 +179,10 @@ typedef struct p2c_mlp_desc {
   float *partials;                      /* backward workspace, p2c_mlp_workspace_floats floats */
   float *w_image;                       /* p2c_mlp_image_floats floats: packed weights, WRITTEN by p2c_mlp_fwd and
                                            read by p2c_mlp_bwd (same weights: call bwd before the optimizer) */
+  /* optional, p2c_mlp_bwd only: apply this optimizer step to the MLP's parameters inside the gradient reduction (single-GPU
+   * training, no all-reduce in between): gW/gb must be views of fused_adamw->grad, the MLP must be all of its n parameters;
+   * w_image (if set) is refreshed with the new weights. Host pointer, read during the call. */
+  const struct p2c_adamw_desc *fused_adamw;
   int32_t skip_pack;                    /* 1 = w_image is already current (kept so by p2c_mlp_pack + the optimizer's
                                            scatter, see p2c_adamw_desc): p2c_mlp_fwd does not launch the pack kernel */
 } p2c_mlp_desc;

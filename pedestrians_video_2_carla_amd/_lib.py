@@ -47,7 +47,7 @@ class MlpDesc(ctypes.Structure):
         ('n_layers', _i32), ('dims', _i32 * (P2C_MLP_MAX_LAYERS + 1)), ('N', ctypes.c_int64), ('x', _f32p),
         ('W', _f32p * P2C_MLP_MAX_LAYERS), ('b', _f32p * P2C_MLP_MAX_LAYERS), ('y', _f32p), ('gy', _f32p),
         ('gW', _f32p * P2C_MLP_MAX_LAYERS), ('gb', _f32p * P2C_MLP_MAX_LAYERS), ('partials', _f32p), ('w_image', _f32p),
-                ('skip_pack', ctypes.c_int32),
+                ('fused_adamw', _f32p), ('skip_pack', ctypes.c_int32),
     ]
 
 

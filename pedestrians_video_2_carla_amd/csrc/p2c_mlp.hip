@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "../../include/p2c.h"
+#include "p2c_adam_math.h"
 
 namespace p2c_mlp {
 
@@ -573,10 +574,37 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
 // gradient tensors. One workgroup per dW tile: 64 lanes x 16 groups; group q adds workgroups q, q+16, ...
 constexpr int RG = 16;    // groups of workgroup partials added in parallel
 constexpr int RL = 16;    // lanes of a tile per reducing workgroup: 4 workgroups per tile -> every CU pulls partials
-__global__ __launch_bounds__(RL * RG) void mlp_reduce_kernel(const MlpArgs a, int n_blocks) {
+// ADAM: the optimizer step rides on the reduction (single-GPU training: no all-reduce sits between the two) -- the thread
+// that holds a finished gradient applies AdamW to its parameter in the flat buffers and refreshes the packed weight image;
+// the last workgroup to finish publishes the new step count. Same formula as p2c_optim::adamw_kernel (p2c_adam_math.h).
+template <bool ADAM>
+__global__ __launch_bounds__(RL * RG) void mlp_reduce_kernel(const MlpArgs a, int n_blocks, const p2c_adamw_desc o) {
   __shared__ f32x4 red[RG][RL];
   const int t = blockIdx.x / (64 / RL), li = threadIdx.x % RL, q = threadIdx.x / RL;
   const int lane = (blockIdx.x % (64 / RL)) * RL + li;        // lane of the MFMA C tile this thread reduces
+  float step = 0.f;
+  __shared__ p2c_optim::Coefs sc;
+  if (ADAM) {
+    step = *o.step + 1.f;                                     // read before this workgroup draws its completion ticket
+    if (threadIdx.x == RL * RG - 1) sc = p2c_optim::coefs(o, step);   // a thread of the last group: overlaps the partial loads
+  }
+  // where this thread's four gradients go (threads of group 0 finish the job); with ADAM their parameter and moments are
+  // requested now, so that their latency hides behind the partial-tile loads
+  const TileRef tr = locate_tile(a.dims, t);
+  const int n_in = a.dims[tr.l], n_out = a.dims[tr.l + 1];
+  const int m = tr.mtile * 16 + (lane & 15);
+  float *gp[4];
+  float pv[4], mv[4], vv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = tr.ntile * 16 + 4 * (lane >> 4) + r;
+    gp[r] = (q == 0 && n < n_out && m <= n_in) ? ((m < n_in) ? a.gW[tr.l] + n * n_in + m : a.gb[tr.l] + n) : nullptr;
+    pv[r] = mv[r] = vv[r] = 0.f;
+    if (ADAM && gp[r]) {
+      const ptrdiff_t off = gp[r] - o.grad;                    // same offset in every flat buffer
+      pv[r] = o.param[off], mv[r] = o.exp_avg[off], vv[r] = o.exp_avg_sq[off];
+    }
+  }
   const size_t stride = (size_t)a.n_tiles_w * 64;
   const f32x4 *p = reinterpret_cast<const f32x4 *>(a.partials) + (size_t)t * 64 + lane;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -591,18 +619,31 @@ __global__ __launch_bounds__(RL * RG) void mlp_reduce_kernel(const MlpArgs a, in
   for (; w < n_blocks; w += RG) s += __builtin_nontemporal_load(&p[(size_t)w * stride]);
   red[q][li] = s;
   __syncthreads();
-  if (q != 0) return;
+  if (q == 0) {
 #pragma unroll
-  for (int i = 1; i < RG; ++i) s += red[i][li];
-  const TileRef tr = locate_tile(a.dims, t);
-  const int n_in = a.dims[tr.l], n_out = a.dims[tr.l + 1];
-  const int m = tr.mtile * 16 + (lane & 15);
+    for (int i = 1; i < RG; ++i) s += red[i][li];
+    p2c_optim::Coefs c;
+    if (ADAM) c = sc;                                         // written before the barrier above
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = tr.ntile * 16 + 4 * (lane >> 4) + r;
-    if (n < n_out) {
-      if (m < n_in) a.gW[tr.l][n * n_in + m] = s[r];
-      else if (m == n_in) a.gb[tr.l][n] = s[r];
+    for (int r = 0; r < 4; ++r) {
+      if (gp[r]) {
+        *gp[r] = s[r];
+        if (ADAM) {
+          const ptrdiff_t off = gp[r] - o.grad;
+          if (o.adamw) p2c_optim::update<true>(c, pv[r], s[r], mv[r], vv[r]);
+          else p2c_optim::update<false>(c, pv[r], s[r], mv[r], vv[r]);
+          o.param[off] = pv[r], o.exp_avg[off] = mv[r], o.exp_avg_sq[off] = vv[r];
+          const int n = tr.ntile * 16 + 4 * (lane >> 4) + r;
+          if (a.w_image) a.w_image[a.w_off[tr.l] + n * a.ld[tr.l] + m] = pv[r];    // bias sits in column n_in == m
+        }
+      }
+    }
+  }
+  if (ADAM) {
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(o.ticket, 1) == (int)gridDim.x - 1) {
+      *o.step = step;
+      *o.ticket = 0;
     }
   }
 }
@@ -789,7 +830,20 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   const int blocks = n_blocks(a.N);
   allow_big_lds();
   hipLaunchKernelGGL(pick(a, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
-  hipLaunchKernelGGL(mlp_reduce_kernel, dim3(a.n_tiles_w * (64 / RL)), dim3(RL * RG), 0, (hipStream_t)stream_, a, blocks);
+  const dim3 rgrid(a.n_tiles_w * (64 / RL)), rblock(RL * RG);
+  if (d->fused_adamw) {
+    const p2c_adamw_desc o = *d->fused_adamw;
+    if (!o.param || !o.grad || !o.exp_avg || !o.exp_avg_sq || !o.step || !o.ticket || !o.hyper) return P2C_E_NULL;
+    for (int l = 0; l < a.n_layers; ++l) {                    // every gradient tensor must be a view of the optimizer's grad
+      const float *lo = o.grad, *hi = o.grad + o.n;
+      if (a.gW[l] < lo || a.gW[l] + (size_t)a.dims[l + 1] * a.dims[l] > hi || a.gb[l] < lo || a.gb[l] + a.dims[l + 1] > hi)
+        return P2C_E_INDEX;
+    }
+    if ((int64_t)a.n_params != o.n) return P2C_E_SHAPE;       // the MLP must be ALL the optimizer optimises (step counter)
+    hipLaunchKernelGGL(mlp_reduce_kernel<true>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, o);
+  } else {
+    hipLaunchKernelGGL(mlp_reduce_kernel<false>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, p2c_adamw_desc{});
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

@@ -30,6 +30,7 @@ class LinearAE(MovementsModelOutputTypeMixin, MovementsModel):
         self.grad_sink = False          # set by the trainer: write parameter gradients straight into .grad
         self._image = None              # persistent packed-weight image of the fused MLP (device buffer, not a parameter)
         self._image_managed = False     # True: an optimizer keeps the image current -> no pack launch in forward()
+        self.fused_optimizer = None     # set by the single-GPU trainer: the optimizer step rides on this module's backward
         self.__n_out = len(self.output_nodes)
         self.__in = len(self.input_nodes) * 2                  # (x, y) per joint
         out = self.__n_out * self.output_features
@@ -73,6 +74,16 @@ class LinearAE(MovementsModelOutputTypeMixin, MovementsModel):
             self._repack_hook = self.register_load_state_dict_post_hook(lambda module, keys: module.repack())
         return True
 
+    def accept_fused_optimizer(self, optimizer, flat_param: torch.Tensor) -> bool:
+        """Single-GPU training: let the backward of this module apply ``optimizer``'s step inside its gradient reduction
+        (one launch less per step). Only valid when this module's Linear layers are ALL the optimizer optimises."""
+        layers = self._linears()
+        n = sum(m.weight.numel() + m.bias.numel() for m in layers)
+        if not (self._image_managed and hasattr(optimizer, 'descriptor_for_fusion') and n == flat_param.numel()):
+            return False
+        self.fused_optimizer = optimizer
+        return True
+
     def repack(self):
         if self._image_managed and self._image is not None:
             from pedestrians_video_2_carla_amd import ops
@@ -90,8 +101,10 @@ class LinearAE(MovementsModelOutputTypeMixin, MovementsModel):
                 if self.grad_sink and torch.is_grad_enabled() and all(m.weight.grad is not None for m in layers):
                     sinks = [g for m in layers for g in (m.weight.grad, m.bias.grad)]
                 managed = self._image_managed and self._image is not None and self._image.device == flat.device
+                fused_opt = self.fused_optimizer if (sinks is not None and self.training) else None
                 h = ops.fused_mlp(flat, [m.weight for m in layers], [m.bias for m in layers], sinks,
-                                  image=self._image if managed else None, image_is_current=managed)
+                                  image=self._image if managed else None, image_is_current=managed,
+                                  fused_optimizer=fused_opt)
                 return self._format_output(h.view(*lead, self.__n_out, self.output_features))
         h = self.__decoder(self.__encoder(flat))
         return self._format_output(h.view(*lead, self.__n_out, self.output_features))

@@ -418,7 +418,7 @@ class FusedMLPFunction(torch.autograd.Function):
     step (true for the flows here; do not combine with gradient accumulation)."""
 
     @staticmethod
-    def forward(ctx, x, n_layers, sinks, image, skip_pack, *params):
+    def forward(ctx, x, n_layers, sinks, image, skip_pack, fused_opt, *params):
         lib = _lib.lib()
         x = _require_device(x, 'x')
         weights = [_require_device(p, 'weight') for p in params[:n_layers]]
@@ -435,6 +435,7 @@ class FusedMLPFunction(torch.autograd.Function):
             _lib.check(lib.p2c_mlp_fwd(ctypes.byref(desc), _stream()), 'p2c_mlp_fwd')
         ctx.save_for_backward(x, image, *weights, *biases)
         ctx.n_layers, ctx.sinks = n_layers, sinks
+        ctx.fused_opt = fused_opt if sinks is not None else None
         return y
 
     @staticmethod
@@ -455,21 +456,27 @@ class FusedMLPFunction(torch.autograd.Function):
             desc.gW[l], desc.gb[l] = gws[l].data_ptr(), gbs[l].data_ptr()
         partials = torch.empty(lib.p2c_mlp_workspace_floats(ctypes.byref(desc)), dtype=torch.float32, device=x.device)
         desc.partials = partials.data_ptr()
+        opt_desc = None
+        if ctx.fused_opt is not None:       # the optimizer step rides on the gradient reduction (see p2c_mlp_desc.fused_adamw)
+            opt_desc = ctx.fused_opt.descriptor_for_fusion()
+            desc.fused_adamw = ctypes.addressof(opt_desc)
         with torch.cuda.device(x.device):
             _lib.check(lib.p2c_mlp_bwd(ctypes.byref(desc), _stream()), 'p2c_mlp_bwd')
         if ctx.sinks is not None:
-            return (None, None, None, None, None) + (None,) * (2 * n)
-        return (None, None, None, None, None, *gws, *gbs)
+            return (None, None, None, None, None, None) + (None,) * (2 * n)
+        return (None, None, None, None, None, None, *gws, *gbs)
 
 
 def fused_mlp(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor],
               sinks: Optional[Sequence[Tensor]] = None, image: Optional[Tensor] = None,
-              image_is_current: bool = False) -> Tensor:
+              image_is_current: bool = False, fused_optimizer=None) -> Tensor:
     """``image``: optional persistent buffer (``mlp_image_floats`` floats) for the packed weights; with
     ``image_is_current`` the forward trusts it (kept current by ``mlp_pack`` + the optimizer's scatter) and launches no
-    pack kernel."""
+    pack kernel. ``fused_optimizer`` (a FlatAdamW over exactly these parameters, with ``sinks`` = views of its gradient
+    buffer): the backward applies the optimizer step inside its gradient reduction -- the caller must then NOT call
+    ``optimizer.step()`` for this backward."""
     return FusedMLPFunction.apply(x, len(weights), None if sinks is None else list(sinks), image, image_is_current,
-                                  *weights, *biases)
+                                  fused_optimizer, *weights, *biases)
 
 
 def mlp_image_layout(dims: Sequence[int]) -> Tuple[int, Tensor]:

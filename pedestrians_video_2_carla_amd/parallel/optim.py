@@ -63,6 +63,15 @@ class FlatAdamW(torch.optim.Optimizer):
             self._desc, self._desc_key = d, key
         return self._desc
 
+    def descriptor_for_fusion(self):
+        """Launch descriptor for a kernel that applies this optimizer's step itself (p2c_mlp_desc.fused_adamw)."""
+        (p,) = self.param_groups[0]['params']
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
+        elif self._uploaded is None:
+            raise RuntimeError('FlatAdamW: call sync_hyper() (or one eager step) before capturing a graph')
+        return self._descriptor(p)
+
     def sync_hyper(self):
         """Upload lr / betas / eps / weight_decay / grad_scale if they changed on the host (call outside graph replay)."""
         g = self.param_groups[0]

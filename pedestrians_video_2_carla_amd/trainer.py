@@ -62,6 +62,7 @@ class Trainer:
         self._static_loss = None
         self._unit = None
         self._packed = []
+        self._opt_in_backward = False
 
     # ------------------------------------------------------------------------------------------------------------
     def setup(self, flow, datamodule):
@@ -90,6 +91,10 @@ class Trainer:
             # modules with a re-laid-out copy of their weights (the fused MLP's LDS image) let the optimizer keep it current
             self._packed = [m for m in flow.modules() if hasattr(m, 'manage_packed_image')
                             and m.manage_packed_image(self.flat.flat_param, opt)]
+            # single GPU: a module that owns every parameter can apply the optimizer step inside its own backward
+            self._opt_in_backward = (not self.exchange.enabled and os.environ.get('P2C_FUSED_UPDATE', '1') == '1'
+                                     and any(m.accept_fused_optimizer(opt, self.flat.flat_param) for m in self._packed
+                                             if hasattr(m, 'accept_fused_optimizer')))
             if hasattr(opt, 'grad_scale') and self.exchange.enabled:    # FlatAdamW folds the DP averaging into its pass
                 opt.grad_scale = 1.0 / self.exchange.world
                 self.exchange.average_here = False
@@ -117,6 +122,8 @@ class Trainer:
         return loss.detach()
 
     def _optimizer_step(self):
+        if self._opt_in_backward:       # already applied by the backward launch of the module that owns the parameters
+            return
         for o in self.optimizers:
             o.step()
 

@@ -98,3 +98,46 @@ def test_static_and_generic_kernels_agree_on_the_linear_ae_shape():
             subprocess.run([sys.executable, '-c', code, f.name], check=True, env=env, timeout=300)
             outs.append(torch.load(f.name))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_optimizer_step_fused_into_the_backward_equals_the_separate_step():
+    """p2c_mlp_desc.fused_adamw: AdamW applied inside the gradient reduction vs backward + FlatAdamW.step() on the same
+    weights and batch: parameters, both moments, the step counter and the refreshed weight image."""
+    from pedestrians_video_2_carla_amd import ops
+    from pedestrians_video_2_carla_amd.parallel.optim import FlatAdamW
+    d = torch.device('cuda:0')
+    dims = [52, 26, 13, 6, 39, 78, 156]
+    n = sum(o * (i + 1) for i, o in zip(dims[:-1], dims[1:]))
+    torch.manual_seed(4)
+    init = torch.randn(n, device=d) * 0.2
+    x, gy = torch.randn(777, 52, device=d), torch.randn(777, 156, device=d)
+
+    def build():
+        flat = torch.nn.Parameter(init.clone())
+        flat.grad = torch.zeros_like(flat)
+        ws, bs, gws, gbs, off = [], [], [], [], 0
+        for i, o in zip(dims[:-1], dims[1:]):
+            ws.append(flat.data[off:off + o * i].view(o, i).requires_grad_(True)), gws.append(flat.grad[off:off + o * i].view(o, i))
+            off += o * i
+            bs.append(flat.data[off:off + o].requires_grad_(True)), gbs.append(flat.grad[off:off + o])
+            off += o
+        opt = FlatAdamW([flat], lr=1e-2, weight_decay=0.01, zero_grad_in_step=False)
+        n_image, index = ops.mlp_image_layout(dims)
+        image = torch.zeros(n_image, device=d)
+        opt.set_scatter(index.to(d), image)           # flat order == (W_0, b_0, W_1, ...) here
+        ops.mlp_pack(ws, bs, image)
+        sinks = [g for pair in zip(gws, gbs) for g in pair]
+        return flat, ws, bs, sinks, opt, image
+
+    fa, wa, ba, sa, oa, ia = build()
+    fb, wb, bb, sb, ob, ib = build()
+    for _ in range(3):
+        ops.fused_mlp(x, wa, ba, sa, image=ia, image_is_current=True).backward(gy)
+        oa.step()
+        ops.fused_mlp(x, wb, bb, sb, image=ib, image_is_current=True, fused_optimizer=ob).backward(gy)
+    torch.cuda.synchronize()
+    assert float(oa.state[fa]['step']) == float(ob.state[fb]['step']) == 3.0
+    for name, u, v in (('param', fa.data, fb.data), ('exp_avg', oa.state[fa]['exp_avg'], ob.state[fb]['exp_avg']),
+                       ('exp_avg_sq', oa.state[fa]['exp_avg_sq'], ob.state[fb]['exp_avg_sq']), ('image', ia, ib)):
+        err = float((u - v).abs().max() / v.abs().max())
+        assert err < 1e-6, (name, err)

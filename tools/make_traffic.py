@@ -19,6 +19,7 @@ GROUPS = {
     'pose_head_rot_bwd<6D>': ('pose_head_rot_bwd',),
     'mlp_fwd': ('mlp_fwd_kernel',),
     'mlp_bwd(+reduce)': ('mlp_bwd_kernel', 'mlp_reduce_kernel'),
+    'mlp_bwd(+reduce+adamw)': ('mlp_bwd_kernel', 'mlp_reduce_kernel'),
     'adamw': ('adamw_kernel',),
 }
 
