@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/p2c.h"
 #include "p2c_adam_math.h"
@@ -173,50 +174,72 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpArgs a) {
   a.w_image[i] = v;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() carries a full workgroup-scope release fence, which
+// on gfx9 means s_waitcnt vmcnt(0) -- every global load in flight (the rest of the weight image, the next tile's rows)
+// would have to land before any wave may pass. All data the waves exchange lives in LDS, so the fence is restricted to
+// the local address space and the loads keep streaming across the barriers.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Workgroup copy of the packed image HBM -> LDS, split into ISSUE (all global loads of the thread in flight at once:
 // the image was written by another XCD's pack kernel, so every load is an L2 miss of a few thousand cycles -- one such
-// latency is paid, not one per batch) and COMMIT (LDS stores). Every workgroup starts at a different offset so that the
-// 256 CUs do not ask for the same line at the same moment.
+// latency is paid, not one per batch) and COMMIT (LDS stores). Round u of a thread covers float4 [u * NTH, (u+1) * NTH)
+// of the image, i.e. the rounds are in layer order: with a static shape the rounds a layer needs are committed right
+// before that layer's barrier, so layer 0 starts as soon as the first 8 KB have landed while the big last layers (60 %
+// of the bytes) are still on their way. Inside a round every workgroup starts at a different offset so that the 256 CUs
+// do not ask for the same line at the same moment.
+constexpr int NTH = 64 * WAVES;
+static_assert((NTH & (NTH - 1)) == 0, "threads per workgroup must be a power of two");
 constexpr int STAGE_U = 12;   // float4 per thread and round (one round covers 96 KB with 512 threads)
 struct ImageRegs {
   f32x4 v[STAGE_U];
 };
-__device__ __forceinline__ int stage_index(int i0, int u, int total4, int rot, int nth, bool &ok) {
-  int i = i0 + u * nth;
+__device__ __forceinline__ int stage_index(int u, int total4, int base, bool &ok) {
+  const int rot = (int)((blockIdx.x * 40503u) & (NTH - 1));
+  const int i = base + u * NTH + ((threadIdx.x + rot) & (NTH - 1));
   ok = i < total4;
-  i += rot;
-  i -= (i >= total4) ? total4 : 0;
   return ok ? i : 0;
 }
-__device__ __forceinline__ void stage_issue(const MlpArgs &a, int total4, ImageRegs &r, int base = 0) {
-  const int nth = blockDim.x;
+__device__ __forceinline__ void stage_issue(const MlpArgs &a, int total4, ImageRegs &r, int base = 0,
+                                            int rounds = STAGE_U) {
   const f32x4 *src = reinterpret_cast<const f32x4 *>(a.w_image);
-  const int rot = (int)((blockIdx.x * 2654435761u) % (unsigned)total4);
 #pragma unroll
   for (int u = 0; u < STAGE_U; ++u) {
+    if (u >= rounds) continue;             // static shapes: no load for a round past the end of the image
     bool ok;
-    const int i = stage_index(base + threadIdx.x, u, total4, rot, nth, ok);
+    const int i = stage_index(u, total4, base, ok);
     r.v[u] = src[i];
   }
 }
-__device__ __forceinline__ void stage_commit(int total4, const ImageRegs &r, float *dst, int base = 0) {
-  const int nth = blockDim.x;
+// rounds [u0, u1) (compile-time after unrolling) -> LDS
+__device__ __forceinline__ void stage_commit(int total4, const ImageRegs &r, float *dst, int base = 0, int u0 = 0,
+                                             int u1 = STAGE_U) {
   f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
-  const int rot = (int)((blockIdx.x * 2654435761u) % (unsigned)total4);
 #pragma unroll
   for (int u = 0; u < STAGE_U; ++u) {
+    if (u < u0 || u >= u1) continue;
     bool ok;
-    const int i = stage_index(base + threadIdx.x, u, total4, rot, nth, ok);
+    const int i = stage_index(u, total4, base, ok);
     if (ok) d4[i] = r.v[u];
   }
 }
 // images larger than one round (wide custom MLPs): the remaining rounds
 __device__ __forceinline__ void stage_rest(const MlpArgs &a, int total4, ImageRegs &r, float *dst) {
-  const int per_round = STAGE_U * blockDim.x;
+  const int per_round = STAGE_U * NTH;
   for (int base = per_round; base < total4; base += per_round) {
     stage_issue(a, total4, r, base);
     stage_commit(total4, r, dst, base);
   }
+}
+// rounds that hold the images of layers 0..l
+template <class S>
+__host__ __device__ constexpr int rounds_upto(int l) {
+  const int end4 = (l + 1 >= S::n_layers()) ? (S::w_total() >> 2) : ((S::w_off(l + 1) + 3) >> 2);
+  const int r = (end4 + NTH - 1) / NTH;
+  return r > STAGE_U ? STAGE_U : r;
 }
 
 #ifdef P2C_MLP_TRACE   // developer build only (tools/mlptrace.py): shader-clock stamps of workgroup 0
@@ -456,23 +479,30 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
   float *H = lds + sh.w_total();
   const int64_t n_tiles = (a.N + TS - 1) / TS;
   TileRegs xr;
-  {
-    ImageRegs wr;
-    stage_issue(a, total4, wr);
-    tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // first tile: in flight with the image
-    init_rows(H, sh.h_off(0) + sh.dims(0), sh.h_off(0) + k_rows(sh.dims(0)), sh.h_off(0) + sh.dims(0));
+  ImageRegs wr;
+  int all_rounds = STAGE_U;
+  if constexpr (S::kStatic) all_rounds = rounds_upto<S>(S::n_layers() - 1);
+  tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // first tile, then the image behind it
+  stage_issue(a, total4, wr, 0, all_rounds);
+  init_rows(H, sh.h_off(0) + sh.dims(0), sh.h_off(0) + k_rows(sh.dims(0)), sh.h_off(0) + sh.dims(0));
+  if constexpr (!S::kStatic) {
     stage_commit(total4, wr, lds);
     stage_rest(a, total4, wr, lds);
   }
   TR(0, 1);
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  // the first tile of a workgroup is peeled (compile-time flag): only there the image registers are live
+  auto one_tile = [&](int64_t tile, auto first_c) {
+    constexpr bool first = decltype(first_c)::value;
     const int64_t row0 = tile * TS, row = row0 + L.c;
     const bool row_ok = row < a.N;
     TR(0, 2);
     tile_commit(sh.dims(0), a.vec_x != 0, xr, H + sh.h_off(0) * TP);
     tile_issue(a.x, (tile + gridDim.x) * TS, a.N, sh.dims(0), a.vec_x != 0, xr);    // prefetch the next tile of this block
     for_layers(sh, 0, nl, [&](int l) {
-      __syncthreads();
+      if constexpr (S::kStatic) {   // the image rounds this layer reads, as late as possible
+        if constexpr (first) stage_commit(total4, wr, lds, 0, l == 0 ? 0 : rounds_upto<S>(l - 1), rounds_upto<S>(l));
+      }
+      lds_barrier();
       TR(0, 3 + l);
       const bool last = (l == nl - 1);
       layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), !last, H + sh.h_off(l) * TP,
@@ -482,8 +512,10 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
     TR(0, 12);
     // the next tile's x rows overwrite H_0 only after every wave has passed layer 0's barrier chain: the barrier of
     // layer 1 (or, for a single layer, the one below) orders them
-    if (nl == 1) __syncthreads();
-  }
+    if (nl == 1) lds_barrier();
+  };
+  if ((int64_t)blockIdx.x < n_tiles) one_tile(blockIdx.x, std::true_type{});
+  for (int64_t tile = (int64_t)blockIdx.x + gridDim.x; tile < n_tiles; tile += gridDim.x) one_tile(tile, std::false_type{});
   TR(0, 39);
 }
 
@@ -502,13 +534,15 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   float *H = lds + sh.w_total();
   float *G = H + (sh.h_off(nl) - sh.h_off(1)) * TP;          // G_l lives at row h_off(l) of this base (l = 1..L)
   TileRegs xr, gr;
-  {
-    ImageRegs wr;
-    stage_issue(a, total4, wr);
-    tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);
-    tile_issue(a.gy, (int64_t)blockIdx.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr);
-    init_rows(H, sh.h_off(0) + sh.dims(0), sh.h_off(0) + k_rows(sh.dims(0)), sh.h_off(0) + sh.dims(0));
-    init_rows(G, sh.h_off(nl) + sh.dims(nl), sh.h_off(nl) + pad16(sh.dims(nl)), -1);
+  ImageRegs wr;
+  int all_rounds = STAGE_U;
+  if constexpr (S::kStatic) all_rounds = rounds_upto<S>(S::n_layers() - 1);
+  tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // needed first; the image in layer
+  stage_issue(a, total4, wr, 0, all_rounds);                                       // order behind it; gy (first read by
+  tile_issue(a.gy, (int64_t)blockIdx.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr); // the dgrad chain) last
+  init_rows(H, sh.h_off(0) + sh.dims(0), sh.h_off(0) + k_rows(sh.dims(0)), sh.h_off(0) + sh.dims(0));
+  init_rows(G, sh.h_off(nl) + sh.dims(nl), sh.h_off(nl) + pad16(sh.dims(nl)), -1);
+  if constexpr (!S::kStatic) {
     stage_commit(total4, wr, lds);
     stage_rest(a, total4, wr, lds);
   }
@@ -520,32 +554,45 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   for (int i = 0; i < MAX_SLOTS; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int64_t n_tiles = (a.N + TS - 1) / TS;
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  f32x4 *part = reinterpret_cast<f32x4 *>(a.partials) + (size_t)blockIdx.x * a.n_tiles_w * 64;
+  auto one_tile = [&](int64_t tile, auto first_c) {   // first tile peeled: only there the image registers are live
+    constexpr bool first = decltype(first_c)::value;
     const int64_t row0 = tile * TS;
-    __syncthreads();                       // previous tile's dW phase has consumed H and G
+    lds_barrier();                         // previous tile's dW phase has consumed H and G
     tile_commit(sh.dims(0), a.vec_x != 0, xr, H + sh.h_off(0) * TP);
-    tile_commit(sh.dims(nl), a.vec_gy != 0, gr, G + sh.h_off(nl) * TP);
     tile_issue(a.x, row0 + (int64_t)gridDim.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // prefetch this block's next tile
-    tile_issue(a.gy, row0 + (int64_t)gridDim.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr);
     // ---- phase F: activations H_1 .. H_{L-1}
     TR(1, 2);
     for_layers(sh, 0, nl - 1, [&](int l) {
-      __syncthreads();
+      if constexpr (S::kStatic) {   // the image rounds this layer reads, as late as possible
+        if constexpr (first) stage_commit(total4, wr, lds, 0, l == 0 ? 0 : rounds_upto<S>(l - 1), rounds_upto<S>(l));
+      }
+      lds_barrier();
       TR(1, 3 + l);
       layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), true, H + sh.h_off(l) * TP,
                     H + sh.h_off(l + 1) * TP, nullptr, false, false);
     });
+    // the last layer's image (first use: the head of the dgrad chain) and the gy tile arrive behind the recomputation
+    if constexpr (S::kStatic) {
+      if constexpr (first) stage_commit(total4, wr, lds, 0, nl >= 2 ? rounds_upto<S>(nl - 2) : 0, STAGE_U);
+    }
+    tile_commit(sh.dims(nl), a.vec_gy != 0, gr, G + sh.h_off(nl) * TP);
+    tile_issue(a.gy, row0 + (int64_t)gridDim.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr);
     // ---- phase D: G_l = relu'(H_l) .* (W_l^T G_{l+1}), l = L-1 .. 1
     for_layers_down(sh, nl - 1, 1, [&](int l) {
-      __syncthreads();
+      lds_barrier();
       TR(1, 12 + l);
       layer_dgrad(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), G + sh.h_off(l + 1) * TP, H + sh.h_off(l) * TP,
                   G + sh.h_off(l) * TP);
     });
-    __syncthreads();
+    lds_barrier();
     TR(1, 22);
     // ---- phase W: dW_aug_l[n][m] += sum_s G_{l+1}^T[n][s] * H_l^T_aug[m][s]; tile t = slot * WAVES + wave.
     // Branch-free: slots past the last tile alias tile 0 and are never written out. Samples beyond N carry G = 0.
+    // On the workgroup's last sample tile every finished slot goes straight out as this workgroup's partial gradient
+    // tile (tile-major in MFMA C layout: partials[block][tile][lane][4], one coalesced 16-byte store per lane;
+    // mlp_reduce_kernel maps them to the parameter tensors): the 80 KB of stores drain behind the remaining MFMAs.
+    const bool last_tile = tile + gridDim.x >= n_tiles;
 #pragma unroll
     for (int slot = 0; slot < MAX_SLOTS; ++slot) {
       const int t = slot * WAVES + L.wave;
@@ -556,16 +603,18 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
       for (int s = 0; s < TS / 4; ++s) av[s] = gp[4 * s], bv[s] = hp[4 * s];
 #pragma unroll
       for (int s = 0; s < TS / 4; ++s) acc[slot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[slot], 0, 0, 0);
+      if (last_tile && t < a.n_tiles_w) __builtin_nontemporal_store(acc[slot], &part[t * 64 + L.lane]);   // read once, by another kernel
     }
-  }
+  };
+  if ((int64_t)blockIdx.x < n_tiles) one_tile(blockIdx.x, std::true_type{});
+  for (int64_t tile = (int64_t)blockIdx.x + gridDim.x; tile < n_tiles; tile += gridDim.x) one_tile(tile, std::false_type{});
   TR(1, 23);
-  // ---- per-workgroup partial gradients, tile-major in MFMA C layout: partials[block][tile][lane][4] (one coalesced
-  // 16-byte store per lane and tile; mlp_reduce_kernel maps them to the parameter tensors)
-  f32x4 *part = reinterpret_cast<f32x4 *>(a.partials) + (size_t)blockIdx.x * a.n_tiles_w * 64;
+  if ((int64_t)blockIdx.x >= n_tiles) {   // empty batch: this workgroup saw no sample tile, its partial is zero
 #pragma unroll
-  for (int slot = 0; slot < MAX_SLOTS; ++slot) {
-    const int t = slot * WAVES + L.wave;
-    if (t < a.n_tiles_w) __builtin_nontemporal_store(acc[slot], &part[t * 64 + L.lane]);   // streamed: read once, by another kernel
+    for (int slot = 0; slot < MAX_SLOTS; ++slot) {
+      const int t = slot * WAVES + L.wave;
+      if (t < a.n_tiles_w) part[t * 64 + L.lane] = acc[slot];
+    }
   }
   TR(1, 39);
 }
