@@ -298,6 +298,47 @@ typedef struct p2c_adamw_desc {
 } p2c_adamw_desc;
 P2C_API int p2c_adamw_step(const p2c_adamw_desc *desc, void *stream);
 
+/* ---- K11: dataset-side input pipeline for a batch of clips, one launch -------------------
+ * Replaces, per clip and on the CPU in the reference, BaseDataset.__getitem__ (data/base/base_dataset.py:206-234):
+ *   Projection2DMixin.process_projection_2d   data/base/mixins/dataset/projection_2d_mixin.py:209-232
+ *     AugmentPose.__call__                     transforms/pose/augmentation/augment_pose.py:43-76
+ *       RandomFlip / RandomRotation            .../random_flip.py:39-76, .../random_rotation.py:34-68
+ *     apply_deform                             projection_2d_mixin.py:137-171 (noise, per-joint missing mask)
+ *     apply_transform x2                       projection_2d_mixin.py:177-189 -> normalizer.py:20-41 + extractors
+ *   ConfidenceMixin.process_confidence         data/base/mixins/dataset/confidence_mixin.py:13-20
+ *   BaseDataset._map_nodes                     data/base/base_dataset.py:156-190
+ * The reference draws its random numbers inside these calls; here every draw is an input tensor so that the kernel is
+ * a pure function of its arguments. Device pointers unless marked host; NULL = that step is off / that output is not
+ * wanted. Errors mirror the reference's: return_confidence with a 2-channel pose and rotation with boxes derived from
+ * a 3-channel pose both raise there (P2C_E_SHAPE here). */
+typedef struct p2c_collate_desc {
+  int64_t N;                   /* clips */
+  int32_t T, Jd, C;            /* frames per clip, joints of the data skeleton (<= 64), channels: 2 (x,y) or 3 (+confidence) */
+  const float *raw;            /* (N,T,Jd,C) */
+  const uint8_t *is_flipped;   /* (N) 0/1: RandomFlip decision per clip; NULL = no flip augmentation */
+  const int32_t *flip_perm;    /* host, Jd: Skeleton.get_flip_mask() of the data skeleton */
+  const float *rotation_deg;   /* (N) RandomRotation angle per clip; NULL = no rotation augmentation */
+  const float *bboxes;         /* (N,T,2,2) targets['bboxes'] or NULL (boxes of the raw pose, utils/tensors.py:12-26) */
+  const float *clip_size;      /* (N,2) meta clip_width / clip_height (0 = unknown) or NULL */
+  const float *noise;          /* (N,T,Jd,2) additive noise or NULL */
+  const float *miss_u;         /* (N,T,Jd) uniform draws or NULL; joint j is dropped where miss_u < miss_prob[j] */
+  const float *miss_prob;      /* host, Jd */
+  int32_t transform;           /* P2C_TRANSFORM_* of the data module (NONE: frames = deformed pose) */
+  int32_t n_hips, hips_idx[2], n_neck, neck_idx[2];   /* hips / neck points of the DATA skeleton (1 or 2 joints each) */
+  float near_zero;             /* 1e-5 in the reference */
+  int32_t return_confidence;   /* model needs_confidence: frames keep the confidence channel */
+  int32_t Ji, K;               /* joints of the model-input skeleton; common joints (0 = same skeleton, Ji == Jd) */
+  const int32_t *src_idx;      /* host, K: data joint ...                    (get_common_indices, skeleton.py:26-56) */
+  const int32_t *dst_idx;      /* host, K: ... lands on this model-input joint */
+  float *frames;               /* (N,T,Ji,return_confidence ? 3 : 2) model input */
+  float *t_projection_2d;      /* (N,T,Ji,2) augmented pose, or NULL */
+  float *t_deformed;           /* (N,T,Ji,2) projection_2d_deformed, or NULL */
+  float *t_transformed;        /* (N,T,Ji,2) projection_2d_transformed, or NULL */
+  float *shift, *scale;        /* (N,T,2), (N,T): projection_2d_shift / _scale, or NULL */
+  float *bboxes_out;           /* (N,T,2,2) augmented boxes (needs bboxes), or NULL */
+} p2c_collate_desc;
+P2C_API int p2c_collate_fwd(const p2c_collate_desc *desc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

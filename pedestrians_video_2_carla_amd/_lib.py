@@ -75,6 +75,17 @@ class DecoderDesc(ctypes.Structure):
                              'h0d', 'h1', 'g_out', 'g_gates0', 'g_gates1', 'g_outtot', 'g_c0', 'g_c1')]
 
 
+class CollateDesc(ctypes.Structure):
+    """p2c_collate_desc (include/p2c.h)."""
+    _fields_ = [('N', _i64), ('T', _i32), ('Jd', _i32), ('C', _i32), ('raw', _f32p), ('is_flipped', _vp),
+                ('flip_perm', _ip), ('rotation_deg', _f32p), ('bboxes', _f32p), ('clip_size', _f32p), ('noise', _f32p),
+                ('miss_u', _f32p), ('miss_prob', ctypes.POINTER(ctypes.c_float)), ('transform', _i32), ('n_hips', _i32),
+                ('hips_idx', _i32 * 2), ('n_neck', _i32), ('neck_idx', _i32 * 2), ('near_zero', ctypes.c_float),
+                ('return_confidence', _i32), ('Ji', _i32), ('K', _i32), ('src_idx', _ip), ('dst_idx', _ip),
+                ('frames', _f32p), ('t_projection_2d', _f32p), ('t_deformed', _f32p), ('t_transformed', _f32p),
+                ('shift', _f32p), ('scale', _f32p), ('bboxes_out', _f32p)]
+
+
 SYMBOLS = {
     'p2c_version': (ctypes.c_char_p, []),
     'p2c_pose_head_workspace_floats': (_i64, [_i32]),
@@ -97,6 +108,7 @@ SYMBOLS = {
     'p2c_mlp_pack': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
     'p2c_mlp_image_index': (_i64, [ctypes.POINTER(MlpDesc), _ip, _i64]),
     'p2c_adamw_step': (ctypes.c_int, [ctypes.POINTER(AdamWDesc), _vp]),
+    'p2c_collate_fwd': (ctypes.c_int, [ctypes.POINTER(CollateDesc), _vp]),
     'p2c_lstm_rec_fwd': (ctypes.c_int, [ctypes.POINTER(LstmDesc), _vp]),
     'p2c_lstm_rec_bwd': (ctypes.c_int, [ctypes.POINTER(LstmDesc), _vp]),
     'p2c_decoder_fwd': (ctypes.c_int, [ctypes.POINTER(DecoderDesc), _vp]),

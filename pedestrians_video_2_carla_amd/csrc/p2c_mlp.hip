@@ -203,12 +203,12 @@ __device__ __forceinline__ int stage_index(int u, int total4, int base, bool &ok
   ok = i < total4;
   return ok ? i : 0;
 }
-__device__ __forceinline__ void stage_issue(const MlpArgs &a, int total4, ImageRegs &r, int base = 0,
-                                            int rounds = STAGE_U) {
+__device__ __forceinline__ void stage_issue(const MlpArgs &a, int total4, ImageRegs &r, int base = 0, int u0 = 0,
+                                            int u1 = STAGE_U) {
   const f32x4 *src = reinterpret_cast<const f32x4 *>(a.w_image);
 #pragma unroll
   for (int u = 0; u < STAGE_U; ++u) {
-    if (u >= rounds) continue;             // static shapes: no load for a round past the end of the image
+    if (u < u0 || u >= u1) continue;
     bool ok;
     const int i = stage_index(u, total4, base, ok);
     r.v[u] = src[i];
@@ -234,12 +234,26 @@ __device__ __forceinline__ void stage_rest(const MlpArgs &a, int total4, ImageRe
     stage_commit(total4, r, dst, base);
   }
 }
+// Static shapes spread the ISSUE as well: the vector-memory path of a CU takes 64 B per cycle, so the ~100 KB a workgroup
+// asks for at once keep every wave stuck in its load instructions for > 2 000 cycles before the first MFMA. The prologue
+// asks only for what layers 0 and 1 read; slot j (= right behind the barrier of forward layer j, j = 0, 1, 2) asks for
+// the next four rounds: they land while the small middle layers compute.
+template <class S>
+__host__ __device__ constexpr int issue_mark(int slot);   // rounds [issue_mark(j), issue_mark(j + 1)) go out in slot j - 1
 // rounds that hold the images of layers 0..l
 template <class S>
+__host__ __device__ constexpr int static_layers() {   // 0 for the dynamic shape
+  if constexpr (S::kStatic) return S::NLAY;
+  else return 0;
+}
+template <class S>
 __host__ __device__ constexpr int rounds_upto(int l) {
+  if constexpr (!S::kStatic) return STAGE_U;
+  else {
   const int end4 = (l + 1 >= S::n_layers()) ? (S::w_total() >> 2) : ((S::w_off(l + 1) + 3) >> 2);
   const int r = (end4 + NTH - 1) / NTH;
   return r > STAGE_U ? STAGE_U : r;
+  }
 }
 
 #ifdef P2C_MLP_TRACE   // developer build only (tools/mlptrace.py): shader-clock stamps of workgroup 0
@@ -464,6 +478,17 @@ __device__ __forceinline__ TileRef locate_tile(const int32_t *dims, int t) {
   return r;
 }
 
+template <class S>
+__host__ __device__ constexpr int issue_mark(int slot) {
+  constexpr int nl = static_layers<S>();
+  const int total = rounds_upto<S>(nl - 1);
+  int m = rounds_upto<S>(nl > 1 ? 1 : 0);                   // prologue: layers 0 and 1
+  if (nl < 4) return slot == 0 ? 0 : total;                 // too few barriers to spread anything: all in the prologue
+  if (slot == 0) return 0;
+  for (int j = 1; j < slot; ++j) m = (j == 3 || m + 4 > total) ? total : m + 4;
+  return m > total ? total : m;
+}
+
 // ---- forward ---------------------------------------------------------------------------------------------------------
 // LDS: [weight images | H_0 .. H_{L-1}]   (the input rows of layer l are H_l, its output H_{l+1})
 template <class S>
@@ -480,10 +505,9 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
   const int64_t n_tiles = (a.N + TS - 1) / TS;
   TileRegs xr;
   ImageRegs wr;
-  int all_rounds = STAGE_U;
-  if constexpr (S::kStatic) all_rounds = rounds_upto<S>(S::n_layers() - 1);
   tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // first tile, then the image behind it
-  stage_issue(a, total4, wr, 0, all_rounds);
+  if constexpr (S::kStatic) stage_issue(a, total4, wr, 0, 0, issue_mark<S>(1));
+  else stage_issue(a, total4, wr);
   init_rows(H, sh.h_off(0) + sh.dims(0), sh.h_off(0) + k_rows(sh.dims(0)), sh.h_off(0) + sh.dims(0));
   if constexpr (!S::kStatic) {
     stage_commit(total4, wr, lds);
@@ -503,6 +527,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
         if constexpr (first) stage_commit(total4, wr, lds, 0, l == 0 ? 0 : rounds_upto<S>(l - 1), rounds_upto<S>(l));
       }
       lds_barrier();
+      if constexpr (S::kStatic && first) stage_issue(a, total4, wr, 0, issue_mark<S>(l + 1), issue_mark<S>(l + 2));
       TR(0, 3 + l);
       const bool last = (l == nl - 1);
       layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), !last, H + sh.h_off(l) * TP,
@@ -535,11 +560,11 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   float *G = H + (sh.h_off(nl) - sh.h_off(1)) * TP;          // G_l lives at row h_off(l) of this base (l = 1..L)
   TileRegs xr, gr;
   ImageRegs wr;
-  int all_rounds = STAGE_U;
-  if constexpr (S::kStatic) all_rounds = rounds_upto<S>(S::n_layers() - 1);
   tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // needed first; the image in layer
-  stage_issue(a, total4, wr, 0, all_rounds);                                       // order behind it; gy (first read by
-  tile_issue(a.gy, (int64_t)blockIdx.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr); // the dgrad chain) last
+  if constexpr (S::kStatic) stage_issue(a, total4, wr, 0, 0, issue_mark<S>(1));    // order behind it; gy (first read by
+  else stage_issue(a, total4, wr);                                                 // the dgrad chain) last
+  if constexpr (static_layers<S>() < 4)
+    tile_issue(a.gy, (int64_t)blockIdx.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr);
   init_rows(H, sh.h_off(0) + sh.dims(0), sh.h_off(0) + k_rows(sh.dims(0)), sh.h_off(0) + sh.dims(0));
   init_rows(G, sh.h_off(nl) + sh.dims(nl), sh.h_off(nl) + pad16(sh.dims(nl)), -1);
   if constexpr (!S::kStatic) {
@@ -568,6 +593,10 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
         if constexpr (first) stage_commit(total4, wr, lds, 0, l == 0 ? 0 : rounds_upto<S>(l - 1), rounds_upto<S>(l));
       }
       lds_barrier();
+      if constexpr (S::kStatic && first) {
+        stage_issue(a, total4, wr, 0, issue_mark<S>(l + 1), issue_mark<S>(l + 2));
+        if (static_layers<S>() >= 4 && l == 2) tile_issue(a.gy, row0, a.N, sh.dims(nl), a.vec_gy != 0, gr);   // behind the image
+      }
       TR(1, 3 + l);
       layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), true, H + sh.h_off(l) * TP,
                     H + sh.h_off(l + 1) * TP, nullptr, false, false);

@@ -383,6 +383,97 @@ def remap_nodes(src: Tensor, n_dst_joints: int, src_idx: Sequence[int], dst_idx:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# dataset-side input pipeline (K11)
+# ----------------------------------------------------------------------------------------------------------------------
+def collate(raw: Tensor, *, flip_perm: Optional[Sequence[int]] = None, is_flipped: Optional[Tensor] = None,
+            rotation: Optional[Tensor] = None, bboxes: Optional[Tensor] = None, clip_size: Optional[Tensor] = None,
+            noise: Optional[Tensor] = None, miss_u: Optional[Tensor] = None,
+            miss_prob: Optional[Sequence[float]] = None, transform: str = 'hips_neck_bbox',
+            hips_idx: Sequence[int] = (1,), neck_idx: Sequence[int] = (8,), near_zero: float = 1e-5,
+            return_confidence: bool = False, src_idx: Optional[Sequence[int]] = None,
+            dst_idx: Optional[Sequence[int]] = None, n_input_joints: Optional[int] = None
+            ) -> Tuple[Tensor, Dict[str, Tensor]]:
+    """``BaseDataset.__getitem__`` for a whole batch in one launch (p2c_collate_fwd): augmentation (flip / rotation with
+    the given per-clip draws), deformation (given noise / missing-joint draws), both normalisations, confidence handling
+    and the node map. raw (N,T,Jd,2|3) -> (frames (N,T,Ji,2|3), targets) with the reference's target keys
+    (projection_2d_mixin.py:209-232, augment_pose.py:62-76)."""
+    from pedestrians_video_2_carla_amd._lib import CollateDesc
+    lib = _lib.lib()
+    raw = _require_device(raw, 'projection_2d')
+    if raw.ndim != 4 or raw.shape[-1] not in (2, 3):
+        raise RuntimeError(f'projection_2d must be (N,T,J,2|3), got {tuple(raw.shape)}')
+    N, T, Jd, C = raw.shape
+    if return_confidence and C == 2:      # confidence_mixin.py:17-18 (torch.cat of a 3-D and a 2-D tensor)
+        raise RuntimeError('Tensors must have same number of dimensions: got 3 and 2')
+    if rotation is not None and bboxes is None and C != 2:   # random_rotation.py:50 (centres of a 3-channel box)
+        raise RuntimeError('The size of tensor a (2) must match the size of tensor b (3) at non-singleton dimension 3')
+    Ji = n_input_joints if n_input_joints is not None else Jd
+    f32 = dict(dtype=torch.float32, device=raw.device)
+    d = CollateDesc()
+    d.N, d.T, d.Jd, d.C, d.raw = N, T, Jd, C, raw.data_ptr()
+    keep = [raw]
+
+    def dev(t, shape, name, dtype=torch.float32):
+        t = _require_device(t, name) if dtype == torch.float32 else t.to(device=raw.device, dtype=dtype).contiguous()
+        if tuple(t.shape) != shape:
+            raise RuntimeError(f'{name} must be {shape}, got {tuple(t.shape)}')
+        keep.append(t)
+        return t.data_ptr()
+
+    targets: Dict[str, Tensor] = {}
+    if is_flipped is not None:
+        if flip_perm is None:
+            raise RuntimeError('is_flipped needs the flip mask of the data skeleton')
+        d.is_flipped = dev(is_flipped, (N,), 'is_flipped', torch.uint8)
+        perm = _iarr(flip_perm)
+        d.flip_perm = perm
+        targets['is_flipped'] = is_flipped
+    if rotation is not None:
+        d.rotation_deg = dev(rotation, (N,), 'rotation')
+        targets['rotation'] = rotation
+    augmented = is_flipped is not None or rotation is not None
+    if bboxes is not None and augmented:
+        d.bboxes = dev(bboxes, (N, T, 2, 2), 'bboxes')
+        targets['bboxes'] = torch.empty(N, T, 2, 2, **f32)
+        targets['orig_bboxes'] = bboxes
+        d.bboxes_out = targets['bboxes'].data_ptr()
+    if clip_size is not None and augmented:
+        d.clip_size = dev(clip_size, (N, 2), 'clip_size')
+    if noise is not None:
+        d.noise = dev(noise, (N, T, Jd, 2), 'noise')
+    if miss_u is not None:
+        d.miss_u = dev(miss_u, (N, T, Jd), 'miss_u')
+        probs = (ctypes.c_float * Jd)(*[float(v) for v in miss_prob])
+        d.miss_prob = probs
+    d.transform = TRANSFORM[transform]
+    d.n_hips, d.n_neck = len(hips_idx), len(neck_idx)
+    for i, v in enumerate(hips_idx):
+        d.hips_idx[i] = v
+    for i, v in enumerate(neck_idx):
+        d.neck_idx[i] = v
+    d.near_zero, d.return_confidence, d.Ji = near_zero, int(return_confidence), Ji
+    if src_idx is not None:
+        d.K = len(src_idx)
+        si, di = _iarr(src_idx), _iarr(dst_idx)
+        d.src_idx, d.dst_idx = si, di
+    frames = torch.empty(N, T, Ji, C if return_confidence else 2, **f32)
+    targets['projection_2d'] = torch.empty(N, T, Ji, 2, **f32)
+    d.frames, d.t_projection_2d = frames.data_ptr(), targets['projection_2d'].data_ptr()
+    if noise is not None or miss_u is not None:
+        targets['projection_2d_deformed'] = torch.empty(N, T, Ji, 2, **f32)
+        d.t_deformed = targets['projection_2d_deformed'].data_ptr()
+    if transform != 'none':
+        targets['projection_2d_transformed'] = torch.empty(N, T, Ji, 2, **f32)
+        targets['projection_2d_shift'] = torch.empty(N, T, 2, **f32)
+        targets['projection_2d_scale'] = torch.empty(N, T, **f32)
+        d.t_transformed, d.shift = targets['projection_2d_transformed'].data_ptr(), targets['projection_2d_shift'].data_ptr()
+        d.scale = targets['projection_2d_scale'].data_ptr()
+    with torch.cuda.device(raw.device):
+        _lib.check(lib.p2c_collate_fwd(ctypes.byref(d), _stream()), 'p2c_collate_fwd')
+    return frames, targets
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # fused small MLP (LinearAE) on fp32 MFMA
 # ----------------------------------------------------------------------------------------------------------------------
 def _mlp_desc(x, weights, biases):

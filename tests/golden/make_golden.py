@@ -374,8 +374,138 @@ def golden_metrics():
         pck_hn=pck_hn.compute(), pck_bbox_correct=pck_bbox.correct, pck_bbox_total=pck_bbox.total, **out)
 
 
+def golden_collate():
+    """collate.npz: the reference's dataset-side input pipeline run clip by clip (BaseDataset.__getitem__:
+    process_projection_2d -> process_confidence -> _map_nodes, data/base/base_dataset.py:206-234) on small in-memory
+    sets. The random draws are recorded by replaying the dataset generator in the order the reference consumes it
+    (flip, rotation, noise, missing) so that the oracle and the HIP kernel can be fed the same numbers."""
+    if not os.path.isdir(REF_SRC):
+        sys.exit('reference tree not present: the committed .npz files are the artefact to use')
+    install_standins()
+    _module('h5py')                      # third-party, only touched by _load_data (overridden below)
+    try:
+        import importlib_metadata  # noqa: F401
+    except ImportError:
+        _module('importlib_metadata', metadata=None)
+    sys.path.insert(0, REF_SRC)
+    from pedestrians_video_2_carla.data.base.base_dataset import BaseDataset
+    from pedestrians_video_2_carla.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla.data.openpose.skeleton import BODY_25_SKELETON, COCO_SKELETON
+    from pedestrians_video_2_carla.transforms.pose.normalization import Normalizer
+    from pedestrians_video_2_carla.transforms.pose.normalization.hips_neck_extractor import HipsNeckExtractor
+    from pedestrians_video_2_carla.transforms.pose.normalization.bbox_extractor import BBoxExtractor
+    from pedestrians_video_2_carla.transforms.pose.normalization.hips_neck_bbox_fallback_extractor import \
+        HipsNeckBBoxFallbackExtractor
+
+    class MemoryDataset(BaseDataset):
+        def __init__(self, clips, bboxes=None, clip_size=None, **kwargs):
+            self._clips, self._bboxes, self._clip_size = clips, bboxes, clip_size
+            super().__init__(set_filepath=None, skip_metadata=True, **kwargs)
+
+        def _load_data(self, ignore_metadata=False):
+            self.projection_2d = self._clips
+            self.meta = [{}] * len(self._clips)
+
+        def _get_targets(self, idx, raw_projection_2d, intermediate_outputs):
+            return {} if self._bboxes is None else {'bboxes': torch.from_numpy(self._bboxes[idx])}
+
+        def _get_meta(self, idx):
+            if self._clip_size is None:
+                return {'clip_width': float('nan'), 'clip_height': float('nan')}
+            return {'clip_width': float(self._clip_size[idx, 0]), 'clip_height': float(self._clip_size[idx, 1])}
+
+    def synth(nodes, N, T, C, seed, missing=0.1):
+        g = torch.Generator().manual_seed(seed)
+        J = len(nodes)
+        centre = torch.rand(N, 1, 1, 2, generator=g) * torch.tensor([900., 500.]) + torch.tensor([300., 200.])
+        walk = torch.cumsum(torch.randn(N, T, 1, 2, generator=g) * 3.0, dim=1)
+        pts = centre + walk + torch.randn(N, 1, J, 2, generator=g) * torch.tensor([40., 90.]) \
+            + torch.randn(N, T, J, 2, generator=g) * 2.0
+        gone = torch.rand(N, T, J, generator=g) < missing
+        if C == 3:
+            conf = torch.rand(N, T, J, 1, generator=g) * 0.9 + 0.05
+            pts = torch.cat((pts, conf), dim=-1)
+        pts[gone] = 0.0
+        return pts.numpy().astype(np.float32)
+
+    def boxes_of(clips, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.from_numpy(clips[..., :2]).clone()
+        seen = ~torch.all(x < 1e-5, dim=-1, keepdim=True)
+        lo = torch.where(seen, x, torch.full_like(x, float('inf'))).amin(dim=-2)
+        hi = torch.where(seen, x, torch.full_like(x, float('-inf'))).amax(dim=-2)
+        pad = torch.rand(*lo.shape, generator=g) * 10.0
+        return torch.stack((lo - pad, hi + pad), dim=-2).numpy().astype(np.float32)      # (N,T,2,2)
+
+    hn = lambda nodes: Normalizer(HipsNeckExtractor(nodes))
+    hnb = lambda nodes: Normalizer(HipsNeckBBoxFallbackExtractor(nodes))
+    bb = lambda nodes: Normalizer(BBoxExtractor(nodes))
+    N, T = 3, 8
+    cases = {
+        # name: data nodes, input nodes, channels, has bboxes / clip size, dataset kwargs
+        'body25_full': (BODY_25_SKELETON, CARLA_SKELETON, 3, True, True,
+                        dict(transform=hnb(BODY_25_SKELETON), noise='gaussian', noise_param=2.5, augment_flip=1.0,
+                             augment_rotate=15.0, missing_joint_probabilities=[0.1], is_training=True)),
+        'body25_nosize': (BODY_25_SKELETON, CARLA_SKELETON, 3, True, False,
+                          dict(transform=hn(BODY_25_SKELETON), augment_flip=1.0, is_training=True,
+                               needs_confidence=True)),
+        'carla_2ch': (CARLA_SKELETON, CARLA_SKELETON, 2, False, False,
+                      dict(transform=hn(CARLA_SKELETON), noise='gaussian', noise_param=1.0, augment_flip=0.5,
+                           augment_rotate=True, is_training=True,
+                           missing_joint_probabilities=[0.02 * (j % 5) for j in range(26)])),
+        'coco_eval': (COCO_SKELETON, CARLA_SKELETON, 3, False, False,
+                      dict(transform=bb(COCO_SKELETON), missing_joint_probabilities=[0.2], needs_confidence=True,
+                           augment_flip=True, augment_rotate=True, is_training=False)),
+        'carla_plain': (CARLA_SKELETON, CARLA_SKELETON, 2, False, False, dict(transform=None, is_training=True)),
+    }
+    out = {}
+    for ci, (name, (dn, inn, C, has_box, has_size, kw)) in enumerate(cases.items()):
+        clips = synth(dn, N, T, C, seed=100 + ci)
+        boxes = boxes_of(clips, seed=200 + ci) if has_box else None
+        size = np.array([[1920., 1080.], [1280., 720.], [1920., 1080.]], np.float32) if has_size else None
+        ds = MemoryDataset(clips, boxes, size, data_nodes=dn, input_nodes=inn, **kw)
+        ds.generator.manual_seed(4242 + ci)
+        twin = torch.Generator().manual_seed(4242 + ci)
+        J = len(dn)
+        rec = {k: [] for k in ('is_flipped', 'rotation', 'noise', 'miss_u')}
+        frames, tg = [], {}
+        for n in range(N):
+            f, t, _ = ds[n]
+            frames.append(f)
+            for k, v in t.items():
+                tg.setdefault(k, []).append(torch.as_tensor(v))
+            # replay the draws of this clip on the twin generator, in the reference's order of consumption
+            if ds.needs_augmentation:
+                if ds.augmentation.flip is not None:
+                    rec['is_flipped'].append(torch.rand((1,), generator=twin) < ds.augmentation.flip.prob)
+                if ds.augmentation.rotate is not None:
+                    rec['rotation'].append((torch.rand((1,), generator=twin) * 2 - 1)
+                                           * ds.augmentation.rotate.max_rotation_angle)
+            if ds.needs_noise:
+                rec['noise'].append(torch.normal(mean=0.0, std=ds.noise_param, size=(T, J, 2), generator=twin))
+            if ds.needs_missing_points:
+                rec['miss_u'].append(torch.rand((T, J), generator=twin))
+        assert torch.equal(twin.get_state(), ds.generator.get_state()), name     # the replay consumed exactly the same
+        out[name + '/raw'] = clips
+        if boxes is not None:
+            out[name + '/bboxes_in'] = boxes
+        if size is not None:
+            out[name + '/clip_size'] = size
+        out[name + '/frames'] = torch.stack(frames)
+        for k, v in tg.items():
+            out[name + '/t_' + k] = torch.stack([x.reshape(x.shape) for x in v])
+        for k, v in rec.items():
+            if v:
+                out[name + '/' + k] = torch.stack(v) if k in ('noise', 'miss_u') else torch.cat(v)
+        if ds.needs_missing_points:
+            out[name + '/miss_prob'] = np.asarray(ds.missing_joint_probabilities, np.float32)
+    npz('collate', **out)
+
+
 if __name__ == '__main__':
-    if sys.argv[1:] == ['metrics']:
+    if sys.argv[1:] == ['collate']:
+        golden_collate()
+    elif sys.argv[1:] == ['metrics']:
         install_standins()
         sys.path.insert(0, REF_SRC)
         golden_metrics()
