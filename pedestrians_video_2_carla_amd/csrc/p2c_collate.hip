@@ -24,6 +24,13 @@
 namespace p2c_collate {
 
 constexpr int MAXJ = 64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+// the (x, y) pairs and (x, y, conf) triples move as one 8- / 12-byte access per lane (4-byte aligned: torch tensors)
+__device__ __forceinline__ f32x2 ld2(const float *p) { return *reinterpret_cast<const f32x2 __attribute__((aligned(4))) *>(p); }
+__device__ __forceinline__ void st2(float *p, float a, float b) {
+  *reinterpret_cast<f32x2 __attribute__((aligned(4))) *>(p) = (f32x2){a, b};
+}
 
 struct Args {
   const float *raw, *rotation, *bboxes, *clip_size, *noise, *miss_u;
@@ -105,21 +112,41 @@ __global__ __launch_bounds__(256) void collate_kernel(const Args a) {
   const bool active = live && j < a.Jd;
   const int C = a.C;
 
-  float x = 0.f, y = 0.f, conf = 0.f;
-  if (active) {
-    const float *p = a.raw + (fc * a.Jd + j) * C;
-    x = p[0], y = p[1];
-    if (C > 2) conf = p[2];
-  }
+  // every HBM read of the frame goes out before the first use: one memory latency per wave, not one per stage
+  float x = 0.f, y = 0.f, conf = 0.f, nx = 0.f, ny = 0.f, mu = 2.f;
+  float bx[4] = {0.f, 0.f, 0.f, 0.f}, cw = 0.f, ch = 0.f, deg = 0.f;
   const bool flip = a.is_flipped && a.is_flipped[n] != 0;
   const bool rotate = a.rotation != nullptr;
+  if (active) {
+    const float *p = a.raw + (fc * a.Jd + j) * C;
+    if (C > 2) {
+      const f32x3 v = *reinterpret_cast<const f32x3 __attribute__((aligned(4))) *>(p);
+      x = v[0], y = v[1], conf = v[2];
+    } else {
+      const f32x2 v = ld2(p);
+      x = v[0], y = v[1];
+    }
+    if (a.noise) {
+      const f32x2 q = ld2(a.noise + (fc * a.Jd + j) * 2);
+      nx = q[0], ny = q[1];
+    }
+    if (a.miss_u) mu = a.miss_u[fc * a.Jd + j];
+  }
+  if (a.bboxes) {
+    const float *b = a.bboxes + fc * 4;
+    bx[0] = b[0], bx[1] = b[1], bx[2] = b[2], bx[3] = b[3];
+  }
+  if (a.clip_size) cw = a.clip_size[2 * n], ch = a.clip_size[2 * n + 1];
+  if (rotate) deg = a.rotation[n];
+  const int lj = j & (MAXJ - 1);
+  const float mp = a.miss_prob[lj];               // per-lane reads of the kernel-argument tables, also up front
+  const int perm_j = a.perm[lj], inv_j = a.inv[lj];
 
   // ---- AugmentPose: boxes and centres (augment_pose.py:57-60) ------------------------------------------------------
   float lo[2] = {0.f, 0.f}, hi[2] = {0.f, 0.f}, ctr[2] = {0.f, 0.f};
   if (a.is_flipped || rotate) {
     if (a.bboxes) {
-      const float *b = a.bboxes + fc * 4;
-      lo[0] = b[0], lo[1] = b[1], hi[0] = b[2], hi[1] = b[3];
+      lo[0] = bx[0], lo[1] = bx[1], hi[0] = bx[2], hi[1] = bx[3];
     } else {                                                   // get_bboxes(pose), utils/tensors.py:12-26
       const bool missing = !active || (x < a.near_zero && y < a.near_zero);
       const float inf = __builtin_inff();
@@ -131,13 +158,13 @@ __global__ __launch_bounds__(256) void collate_kernel(const Args a) {
   // ---- RandomFlip (random_flip.py:39-76) -----------------------------------------------------------------------------
   if (__any(flip)) {
     const bool gone = (x == 0.f) || (y == 0.f) || (C > 2 && conf == 0.f);    // remembered before the permutation
-    const int src = base + (active ? a.perm[j] : j);
+    const int src = base + (active ? perm_j : j);
     const float qx = __shfl(x, src, 64), qy = __shfl(y, src, 64), qc = __shfl(conf, src, 64);
     if (flip) {
       float fx = (qx - ctr[0]) * -1.f;
-      const bool sized = a.clip_size && a.clip_size[2 * n] != 0.f && a.clip_size[2 * n + 1] != 0.f;
+      const bool sized = a.clip_size && cw != 0.f && ch != 0.f;
       if (sized) {
-        const float half = a.clip_size[2 * n] / 2.f;
+        const float half = cw / 2.f;
         const float l2 = (lo[0] - half) * -1.f + half, h2 = (hi[0] - half) * -1.f + half;
         lo[0] = h2, hi[0] = l2;
         ctr[0] = (lo[0] + hi[0]) * 0.5f;
@@ -149,8 +176,9 @@ __global__ __launch_bounds__(256) void collate_kernel(const Args a) {
   // ---- RandomRotation (random_rotation.py:34-68) -----------------------------------------------------------------------
   if (rotate) {
     const bool gone = (x == 0.f) || (y == 0.f) || (C > 2 && conf == 0.f);
-    const float rad = a.rotation[n] * 0.017453292519943295f;
-    const float cs = cosf(rad), sn = sinf(rad);
+    const float rad = deg * 0.017453292519943295f;
+    float sn, cs;
+    sincosf(rad, &sn, &cs);                  // one range reduction for both
     const float dx = x - ctr[0], dy = y - ctr[1];
     const float rx = fmaf(dy, sn, dx * cs) + ctr[0], ry = fmaf(dy, cs, dx * -sn) + ctr[1];
     x = gone ? 0.f : rx, y = gone ? 0.f : ry, conf = gone ? 0.f : conf;
@@ -171,11 +199,8 @@ __global__ __launch_bounds__(256) void collate_kernel(const Args a) {
   // ---- apply_deform (projection_2d_mixin.py:137-171) ---------------------------------------------------------------------
   float dx = x, dy = y;
   if (active) {
-    if (a.noise) {
-      const float *q = a.noise + (fc * a.Jd + j) * 2;
-      dx += q[0], dy += q[1];
-    }
-    if (a.miss_u && a.miss_u[fc * a.Jd + j] < a.miss_prob[j]) dx = 0.f, dy = 0.f;
+    if (a.noise) dx += nx, dy += ny;
+    if (a.miss_u && mu < mp) dx = 0.f, dy = 0.f;
   }
   // ---- apply_transform twice: model input (deformed) and target (augmented); shift / scale of the second call ----------
   float ix = dx, iy = dy, ic = conf, tx = x, ty = y, s[2] = {0.f, 0.f}, scale = 1.f;
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(256) void collate_kernel(const Args a) {
     if (a.scale && live && j == 0) a.scale[f] = scale;
   }
   // ---- node map: lane = model-input joint --------------------------------------------------------------------------------
-  const int srcj = (j < a.Ji) ? a.inv[j] : -1;
+  const int srcj = (j < a.Ji) ? inv_j : -1;
   const int from = base + (srcj < 0 ? 0 : srcj);
   const float o_ix = __shfl(ix, from, 64), o_iy = __shfl(iy, from, 64), o_ic = __shfl(ic, from, 64);
   const float o_x = __shfl(x, from, 64), o_y = __shfl(y, from, 64);
@@ -197,11 +222,15 @@ __global__ __launch_bounds__(256) void collate_kernel(const Args a) {
   const bool has = srcj >= 0;
   const int64_t o = f * a.Ji + j;
   float *fr = a.frames + o * a.Cf;
-  fr[0] = has ? o_ix : 0.f, fr[1] = has ? o_iy : 0.f;
-  if (a.Cf > 2) fr[2] = has ? o_ic : 0.f;
-  if (a.t_projection_2d) a.t_projection_2d[2 * o] = has ? o_x : 0.f, a.t_projection_2d[2 * o + 1] = has ? o_y : 0.f;
-  if (a.t_deformed) a.t_deformed[2 * o] = has ? o_dx : 0.f, a.t_deformed[2 * o + 1] = has ? o_dy : 0.f;
-  if (a.t_transformed) a.t_transformed[2 * o] = has ? o_tx : 0.f, a.t_transformed[2 * o + 1] = has ? o_ty : 0.f;
+  if (a.Cf > 2) {
+    *reinterpret_cast<f32x3 __attribute__((aligned(4))) *>(fr) =
+        (f32x3){has ? o_ix : 0.f, has ? o_iy : 0.f, has ? o_ic : 0.f};
+  } else {
+    st2(fr, has ? o_ix : 0.f, has ? o_iy : 0.f);
+  }
+  if (a.t_projection_2d) st2(a.t_projection_2d + 2 * o, has ? o_x : 0.f, has ? o_y : 0.f);
+  if (a.t_deformed) st2(a.t_deformed + 2 * o, has ? o_dx : 0.f, has ? o_dy : 0.f);
+  if (a.t_transformed) st2(a.t_transformed + 2 * o, has ? o_tx : 0.f, has ? o_ty : 0.f);
 }
 
 }  // namespace p2c_collate
