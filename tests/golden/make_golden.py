@@ -502,8 +502,41 @@ def golden_collate():
     npz('collate', **out)
 
 
+def golden_losses_extra():
+    """losses_extra.npz: the reference's cum_pose_changes function and PerJointLoc2DPoseLoss class on small inputs."""
+    if not os.path.isdir(REF_SRC):
+        sys.exit('reference tree not present: the committed .npz files are the artefact to use')
+    install_standins()
+    sys.path.insert(0, REF_SRC)
+    from pedestrians_video_2_carla.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla.data.openpose.skeleton import BODY_25_SKELETON
+    from pedestrians_video_2_carla.loss import LossModes
+    from pytorch3d.transforms import euler_angles_to_matrix
+    g = torch.Generator().manual_seed(77)
+    B, T, J = 3, 16, 26
+    pred = euler_angles_to_matrix((torch.rand(B, T, J, 3, generator=g) * 2 - 1) * 0.2, 'XYZ')
+    tgt = euler_angles_to_matrix((torch.rand(B, T, J, 3, generator=g) * 2 - 1) * 0.2, 'XYZ')
+    fn, crit = LossModes.cum_pose_changes.value
+    out = {'cum_pred': pred, 'cum_tgt': tgt, 'cum_loss': fn(criterion=crit, pose_inputs=pred, targets={'pose_changes': tgt})}
+    weights = (torch.rand(25, generator=g) + 0.5).tolist()
+    for name, inn, outn, wts in (('carla', CARLA_SKELETON, CARLA_SKELETON, (torch.rand(26, generator=g) + 0.5).tolist()),
+                                 ('b25', BODY_25_SKELETON, CARLA_SKELETON, weights)):
+        p2 = torch.randn(B, T, len(outn), 3, generator=g)
+        gt = torch.randn(B, T, len(inn), 2, generator=g)
+        gt[torch.rand(B, T, len(inn), generator=g) < 0.15] = 0.0
+        cls, crit = LossModes.per_joint_loc_2d.value
+        for mask in (True, False):
+            loss = cls(criterion=crit, input_nodes=inn, output_nodes=outn, mask_missing_joints=mask, loss_params=wts)
+            out[f'pj_{name}_loss_mask{int(mask)}'] = loss(projection_2d_transformed=p2,
+                                                         targets={'projection_2d_transformed': gt})
+        out[f'pj_{name}_pred'], out[f'pj_{name}_gt'], out[f'pj_{name}_weights'] = p2, gt, torch.tensor(wts)
+    npz('losses_extra', **out)
+
+
 if __name__ == '__main__':
-    if sys.argv[1:] == ['collate']:
+    if sys.argv[1:] == ['losses_extra']:
+        golden_losses_extra()
+    elif sys.argv[1:] == ['collate']:
         golden_collate()
     elif sys.argv[1:] == ['metrics']:
         install_standins()
