@@ -40,9 +40,11 @@ def _fused_ok(rnn, x) -> bool:
             and x.dtype == torch.float32 and rnn.hidden_size in (16, 32, 48, 64))
 
 
-def _run_stack(rnn: nn.LSTM, x: Tensor, hidden: Tensor = None, cell: Tensor = None):
+def _run_stack(rnn: nn.LSTM, x: Tensor, hidden: Tensor = None, cell: Tensor = None, input_map=None):
     """nn.LSTM.forward semantics (layer loop, inter-layer dropout in training) on the fused layer op.
-    x (T,B,I); hidden / cell (num_layers,B,H) or None. Returns (out (T,B,H), hidden, cell)."""
+    x (T,B,I); hidden / cell (num_layers,B,H) or None. Returns (out (T,B,H), hidden, cell).
+    ``input_map`` = (weight (4H,I'), bias (4H)) replaces layer 0's input projection (weight_ih_l0, bias_ih_l0 + bias_hh_l0)
+    -- used when a linear front end has been folded into it."""
     from pedestrians_video_2_carla_amd import ops
     B, H = x.shape[1], rnn.hidden_size
     hs, cs = [], []
@@ -51,8 +53,10 @@ def _run_stack(rnn: nn.LSTM, x: Tensor, hidden: Tensor = None, cell: Tensor = No
         c0 = cell[k] if cell is not None else x.new_zeros(B, H)
         b_ih = getattr(rnn, f'bias_ih_l{k}', None) if rnn.bias else None
         b_hh = getattr(rnn, f'bias_hh_l{k}', None) if rnn.bias else None
-        x, hT, cT = ops.lstm_layer(x, h0.contiguous(), c0.contiguous(), getattr(rnn, f'weight_ih_l{k}'),
-                                   getattr(rnn, f'weight_hh_l{k}'), b_ih, b_hh)
+        w_ih = getattr(rnn, f'weight_ih_l{k}')
+        if k == 0 and input_map is not None:
+            w_ih, b_ih, b_hh = input_map[0], input_map[1], None
+        x, hT, cT = ops.lstm_layer(x, h0.contiguous(), c0.contiguous(), w_ih, getattr(rnn, f'weight_hh_l{k}'), b_ih, b_hh)
         hs.append(hT), cs.append(cT)
         if rnn.dropout > 0 and rnn.training and k < rnn.num_layers - 1:
             x = torch.nn.functional.dropout(x, rnn.dropout, True)
@@ -150,7 +154,7 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
     def forward(self, x: Tensor, targets: Dict[str, Tensor] = None, *args, **kwargs) -> Tensor:
         original_shape = x.shape
         batch_size, clip_length = original_shape[:2]
-        hidden, cell = self.encoder(self._format_input(x))
+        hidden, cell = self._encode(x)
         needs_forcing, forced, force_idx = self._teacher_forcing(targets)
         if not needs_forcing and self._decoder_loop_fusable(x):
             # K7c: the T decoder steps (frozen encoder state, output fed back) are ONE HIP launch
@@ -165,6 +169,9 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
                 step_in = torch.where(force_idx[t].unsqueeze(-1), forced[t], out)
             outputs.append(out)
         return self._format_output(original_shape, torch.stack(outputs, 0))
+
+    def _encode(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+        return self.encoder(self._format_input(x))
 
     def _decoder_loop_fusable(self, x: Tensor) -> bool:
         from pedestrians_video_2_carla_amd import ops

@@ -7,6 +7,14 @@ encoder LSTM consumes, time-reversed when ``invert_sequence``; with the flat tra
 gradients are read and written in place in the flat buffers. Host tensors / non-fp32 (the CPU parity pipeline) take the
 batched contraction (T,B,J,2) x (J,E,2) -> (T,B,J,E). Parameters stay in the ``embeddings.{i}.weight/bias`` ModuleList so
 reference checkpoints load unchanged.
+
+``fold_embeddings`` (default on): nothing non-linear sits between the embeddings and the encoder's first input projection
+(nn.LSTM applies its dropout BETWEEN layers only, seq2seq.py:36-58), so ``W_ih0 . concat_j(W_j x_j + b_j)`` is a
+(4H x 2J) map of the raw keypoints: W_eff[:, 2j:2j+2] = W_ih0[:, jE:(j+1)E] W_j, b_eff = b_ih0 + b_hh0 + sum_j W_ih0[:, j] b_j.
+The fused encoder path composes that map per step (26 products of 256x64 by 64x2 -- autograd carries the gradients back to
+the embedding and LSTM parameters) and runs the encoder on the (T,B,52) keypoints: the (T,B,1664) embedding tensor, its
+8192x1664x256 GEMM and the two gradient GEMMs of the same size disappear (cfg3: 1.02 -> see DESIGN.md section 7). Same function;
+fp32 rounding differs by the re-association only.
 """
 import torch
 from torch import nn
@@ -14,11 +22,54 @@ from torch import nn
 from .seq2seq import Seq2Seq
 
 
+def _block_view(tensors):
+    """One strided view (n, *shape) over n equally spaced contiguous views of the same buffer (the trainer's flat
+    parameter / gradient buffers hold embeddings.0.weight, embeddings.0.bias, embeddings.1.weight, ... back to back),
+    or None."""
+    from pedestrians_video_2_carla_amd import ops
+    t0 = tensors[0]
+    step = ops._uniform_stride(tensors)
+    if step is None or any(t.untyped_storage().data_ptr() != t0.untyped_storage().data_ptr() for t in tensors):
+        return None
+    return torch.as_strided(t0.detach(), (len(tensors),) + tuple(t0.shape), (step,) + tuple(t0.stride()))
+
+
+class _FoldedInputMap(torch.autograd.Function):
+    """(w_eff (G, J*C), b_fold (G)) = (W_ih0 restricted to joint j) @ (W_j | b_j) for all joints, with the embedding
+    parameters and their gradients addressed as ONE strided block each: the backward adds dW / db into the gradient block
+    (two launches) instead of 52 per-parameter accumulations behind a 52-way ``torch.stack``. Contractions are written as
+    broadcast-multiply + sum: the library's batched GEMM for 26 x (256x64x2) takes ~19 us per call."""
+
+    @staticmethod
+    def forward(ctx, w_ih, anchor, W, b, gW, gb):
+        G = w_ih.shape[0]
+        J, E, C = W.shape
+        w3 = w_ih.view(G, J, E)
+        w_eff = (w3.unsqueeze(-1) * W.unsqueeze(0)).sum(2)                  # (G,J,C)
+        b_fold = (w3 * b.unsqueeze(0)).sum((1, 2))                           # (G)
+        ctx.save_for_backward(w_ih)
+        ctx.blocks = (W, b, gW, gb)
+        return w_eff.reshape(G, J * C), b_fold
+
+    @staticmethod
+    def backward(ctx, g_eff, g_b):
+        (w_ih,) = ctx.saved_tensors
+        W, b, gW, gb = ctx.blocks
+        G = w_ih.shape[0]
+        J, E, C = W.shape
+        w3, g3 = w_ih.view(G, J, E), g_eff.reshape(G, J, 1, C)
+        g_w = (g3 * W.unsqueeze(0)).sum(-1) + g_b.view(G, 1, 1) * b.unsqueeze(0)          # (G,J,E)
+        gW.add_((g3 * w3.unsqueeze(-1)).sum(0))                                           # (J,E,C)
+        gb.add_((g_b.view(G, 1, 1) * w3).sum(0))                                          # (J,E)
+        return g_w.reshape(G, J * E), None, None, None, None, None
+
+
 class Seq2SeqEmbeddings(Seq2Seq):
     def __init__(self, single_joint_embeddings_size=64, **kwargs):
         super().__init__(**{**kwargs, 'input_features': single_joint_embeddings_size})
         self.single_joint_embeddings_size = single_joint_embeddings_size
         self.grad_sink = False     # set by the flat trainer: gradients go straight into the flat gradient buffer
+        self.fold_embeddings = True
         self.embeddings = nn.ModuleList([nn.Linear(2, single_joint_embeddings_size)
                                          for _ in range(len(self.input_nodes))])
         self._hparams.update({'single_joint_embeddings_size': single_joint_embeddings_size})
@@ -29,6 +80,32 @@ class Seq2SeqEmbeddings(Seq2Seq):
         group = parent_parser.add_argument_group('Seq2SeqEmbeddings Movements Module')
         group.add_argument('--single_joint_embeddings_size', default=64, type=int)
         return parent_parser
+
+    def _encode(self, x):
+        from .seq2seq import _fused_ok, _run_stack
+        rnn = self.encoder.rnn
+        if not (self.fold_embeddings and _fused_ok(rnn, x) and rnn.bias):
+            return super()._encode(x)
+        B, T, J = x.shape[:3]
+        E, G = self.single_joint_embeddings_size, 4 * rnn.hidden_size
+        assert J == len(self.input_nodes) == len(self.embeddings)
+        ws, bs = [e.weight for e in self.embeddings], [e.bias for e in self.embeddings]
+        blocks = None
+        if self.grad_sink and torch.is_grad_enabled() and all(p.grad is not None for p in ws + bs):
+            blocks = [_block_view(t) for t in (ws, bs, [p.grad for p in ws], [p.grad for p in bs])]
+        if blocks is not None and all(v is not None for v in blocks):
+            w_eff, b_fold = _FoldedInputMap.apply(rnn.weight_ih_l0, ws[0], *blocks)
+        else:                                                                     # any parameter layout: autograd
+            weight, bias = torch.stack(ws), torch.stack(bs)                       # (J, E, C), (J, E)
+            w_ih = rnn.weight_ih_l0.view(G, J, E)
+            w_eff = (w_ih.unsqueeze(-1) * weight.unsqueeze(0)).sum(2).reshape(G, J * weight.shape[-1])
+            b_fold = (w_ih * bias.unsqueeze(0)).sum((1, 2))
+        b_eff = b_fold + rnn.bias_ih_l0 + rnn.bias_hh_l0
+        seq = x.permute(1, 0, 2, 3).reshape(T, B, -1)                             # sequence first, raw keypoints
+        if self.invert_sequence:
+            seq = seq.flip(0)
+        _, hidden, cell = _run_stack(rnn, seq.contiguous(), input_map=(w_eff, b_eff))
+        return hidden, cell
 
     def _format_input(self, x):
         joints = x.shape[2]

@@ -111,3 +111,38 @@ def test_decoder_loop_matches_the_per_step_formula(T, B, O, with_drop):
     close(out, ref, 'out')
     for k in P:
         close(D[k].grad, R[k].grad, 'grad ' + k, rtol=2e-4)
+
+
+def test_folded_embeddings_with_the_flat_trainer_match_the_unfolded_model():
+    """Seq2SeqEmbeddings under the flat trainer (embedding parameters / gradients addressed as strided blocks of the flat
+    buffers, ``_FoldedInputMap``): loss and the whole flat gradient of one train step vs the same model with the fold
+    switched off (K7a embeddings + the 1664-wide input projection)."""
+    from pedestrians_video_2_carla_amd.data.carla.carla_recorded_synthetic import SyntheticCarlaRecordedDataModule
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.autoencoder import LitAutoencoderFlow
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2SeqEmbeddings
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import seq2seq_embeddings as SE
+    from pedestrians_video_2_carla_amd.trainer import Trainer, seed_everything
+    d = dev()
+    res = {}
+    for fold in (True, False):
+        seed_everything(11)
+        dm = SyntheticCarlaRecordedDataModule(clip_length=16, batch_size=24)
+        model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d,
+                                  p_dropout=0.0)
+        model.fold_embeddings = fold
+        flow = LitAutoencoderFlow(movements_model=model, loss_modes=['loc_2d'], transform='hips_neck_bbox')
+        trainer = Trainer(device=d, use_graph=False).setup(flow, dm)
+        assert model.grad_sink
+        if fold:      # the strided-block path is the one that runs
+            ws = [e.weight for e in model.embeddings]
+            assert SE._block_view(ws) is not None and SE._block_view([p.grad for p in ws]) is not None
+        batch = dm.generate_batch(d)
+        flow.train()
+        flow.on_train_batch_start(batch, 0)
+        loss = flow.training_step(batch, 0)['loss']
+        loss.backward()
+        res[fold] = (loss.detach().clone(), trainer.flat.flat_grad.detach().clone())
+    close(res[True][0], res[False][0], 'loss', rtol=1e-5)
+    close(res[True][1], res[False][1], 'flat gradient', rtol=2e-4)

@@ -19,6 +19,8 @@ d = torch.device('cuda:0')
 seed_everything(22742)
 dm = SyntheticCarlaRecordedDataModule(clip_length=16, batch_size=B)
 model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d)
+if os.environ.get('P2C_NO_FOLD'):
+    model.fold_embeddings = False
 flow = LitAutoencoderFlow(movements_model=model, loss_modes=['loc_2d'], transform='hips_neck_bbox')
 trainer = Trainer(device=d, use_graph=use_graph).setup(flow, dm)
 batch = dm.generate_batch(d)
