@@ -156,19 +156,28 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         batch_size, clip_length = original_shape[:2]
         hidden, cell = self._encode(x)
         needs_forcing, forced, force_idx = self._teacher_forcing(targets)
-        if not needs_forcing and self._decoder_loop_fusable(x):
+        if not needs_forcing and type(self)._decode_frame is Seq2Seq._decode_frame and self._decoder_loop_fusable(x):
             # K7c: the T decoder steps (frozen encoder state, output fed back) are ONE HIP launch
             return self._format_output(original_shape, self._fused_decoder(hidden, cell, clip_length))
         step_in = torch.zeros((batch_size, self.decoder.output_size), device=x.device, dtype=x.dtype)     # <sos>
         outputs = []
         for t in range(clip_length):
-            # NB: (hidden, cell) are the encoder's for every frame -- see module docstring
-            out, _, _ = self.decoder(step_in, hidden, cell)
-            step_in = out
-            if needs_forcing:
-                step_in = torch.where(force_idx[t].unsqueeze(-1), forced[t], out)
+            step_in, out = self._decode_frame(hidden, cell, step_in, needs_forcing,
+                                              force_idx[t] if needs_forcing else None,
+                                              forced[t] if needs_forcing else None)
             outputs.append(out)
         return self._format_output(original_shape, torch.stack(outputs, 0))
+
+    def _decode_frame(self, hidden: Tensor, cell: Tensor, step_in: Tensor, needs_forcing: bool, force_indices: Tensor,
+                      target: Tensor) -> Tuple[Tensor, Tensor]:
+        """One decoded frame -> (next input, output) (reference seq2seq.py:272-288; the hook the residual variants override).
+        NB: (hidden, cell) are the encoder's for every frame -- see module docstring. ``force_indices`` (B,) bool and
+        ``target`` (B,O) replace the reference's boolean-mask writes by ``torch.where`` (no host sync)."""
+        out, _, _ = self.decoder(step_in, hidden, cell)
+        step_in = out
+        if needs_forcing:
+            step_in = torch.where(force_indices.unsqueeze(-1), target, out)
+        return step_in, out
 
     def _encode(self, x: Tensor) -> Tuple[Tensor, Tensor]:
         return self.encoder(self._format_input(x))

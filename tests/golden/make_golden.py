@@ -533,8 +533,54 @@ def golden_losses_extra():
     npz('losses_extra', **out)
 
 
+def golden_models_extra():
+    """model_*.npz for the SURVEY 8f rank-4 plugins: the reference's LinearAEResidual(+Leaky) and Seq2SeqResidualA/B/C under
+    a fixed state_dict, eval mode (BatchNorm running statistics perturbed so that they matter; Dropout off)."""
+    if not os.path.isdir(REF_SRC):
+        sys.exit('reference tree not present: the committed .npz files are the artefact to use')
+    install_standins()
+    sys.path.insert(0, REF_SRC)
+    from pedestrians_video_2_carla.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla.modules.movements.linear_ae.linear_ae_residual import LinearAEResidual
+    from pedestrians_video_2_carla.modules.movements.linear_ae.linear_ae_residual_leaky import LinearAEResidualLeaky
+    from pedestrians_video_2_carla.modules.movements.seq2seq.seq2seq_residual_a import Seq2SeqResidualA
+    from pedestrians_video_2_carla.modules.movements.seq2seq.seq2seq_residual_b import Seq2SeqResidualB
+    from pedestrians_video_2_carla.modules.movements.seq2seq.seq2seq_residual_c import Seq2SeqResidualC
+    g = torch.Generator().manual_seed(5)
+    frames = torch.randn(4, 16, 26, 2, generator=g)
+    for name, cls, kw in (
+            ('linear_ae_residual', LinearAEResidual, {}),
+            ('linear_ae_residual_leaky', LinearAEResidualLeaky, dict(linear_size=64)),
+            # A and B: same architecture, seed and construction order as model_seq2seq_embeddings_pose_2d -> same weights;
+            # only the outputs are stored (checked below). C (6-D output) gets a small configuration of its own.
+            ('seq2seq_residual_a', Seq2SeqResidualA, dict(movements_output_type=MT.pose_2d)),
+            ('seq2seq_residual_b', Seq2SeqResidualB, dict(movements_output_type=MT.pose_2d)),
+            ('seq2seq_residual_c', Seq2SeqResidualC, dict(movements_output_type=MT.pose_changes, hidden_size=16,
+                                                          single_joint_embeddings_size=8)),
+    ):
+        torch.manual_seed(22742)
+        model = cls(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, **kw).eval()
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.3)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+        with torch.no_grad():
+            out = model(frames)
+        sd = {('sd__' + k): v for k, v in model.state_dict().items()}
+        if name in ('seq2seq_residual_a', 'seq2seq_residual_b'):
+            base = np.load(os.path.join(HERE, 'model_seq2seq_embeddings_pose_2d.npz'))
+            assert all(np.array_equal(base[k], v.numpy()) for k, v in sd.items()) and len(sd) == sum(
+                k.startswith('sd__') for k in base.files)
+            sd = {}
+        outs = {'out': out} if isinstance(out, torch.Tensor) else {'out_loc': out[0], 'out_rot': out[1]}
+        npz('model_' + name, frames=frames, n_params=sum(p.numel() for p in model.parameters()), **outs, **sd)
+
+
 if __name__ == '__main__':
-    if sys.argv[1:] == ['losses_extra']:
+    if sys.argv[1:] == ['models_extra']:
+        golden_models_extra()
+    elif sys.argv[1:] == ['losses_extra']:
         golden_losses_extra()
     elif sys.argv[1:] == ['collate']:
         golden_collate()

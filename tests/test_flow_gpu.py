@@ -317,3 +317,45 @@ def test_rotation_loss_modes_train_through_the_generic_path():
     close(out['loss'], ref, 'loc_2d_loc_rot_3d')
     for (n, pg), (_, pc) in zip(flow.movements_model.named_parameters(), cpu_model.named_parameters()):
         close(pg.grad, pc.grad, 'grad ' + n, rtol=2e-4)
+
+
+def test_linear_ae_residual_trains_through_the_flow():
+    """LinearAEResidual (absolute_loc_rot plugin) in LitPoseLiftingFlow: the training step's loss and
+    parameter gradients (BatchNorm in training mode, Dropout switched off for determinism) vs the same module in fp64 on the
+    CPU + the oracle pose head on its locations."""
+    import copy
+    from pedestrians_video_2_carla_amd.data.carla.carla_recorded_synthetic import SyntheticCarlaRecordedDataModule
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.pose_lifting import LitPoseLiftingFlow
+    from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAEResidual
+    from pedestrians_video_2_carla_amd.trainer import Trainer, seed_everything
+    seed_everything(5)
+    d = dev()
+    dm = SyntheticCarlaRecordedDataModule(clip_length=16, batch_size=12, missing_joint_probabilities=0.1)
+    model = LinearAEResidual(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    flow = LitPoseLiftingFlow(movements_model=model, loss_modes=['loc_2d_3d'], transform=dm.transform.name)
+    cpu_model = copy.deepcopy(model).double().train()
+    trainer = Trainer(device=d, flatten=False).setup(flow, dm)
+    batch = dm.generate_batch(d)
+    frames, targets, meta = batch
+    flow.train()
+    flow.on_train_batch_start(batch, 0)
+    out = flow.training_step(batch, 0)
+    out['loss'].backward()
+    loc, _ = cpu_model(frames.double().cpu())
+    o = O.pose_head(loc, 'absolute_loc', meta['skel_type'].cpu(), gt2d=targets['projection_2d_transformed'].double().cpu(),
+                    gt3d=targets['absolute_pose_loc'].double().cpu())
+    o['loc_2d_3d'].backward()
+    close(out['loss'], o['loc_2d_3d'], 'loss')
+    # biases in front of a BatchNorm have an analytically zero gradient (fp64: 1e-15, fp32: rounding noise): every gradient
+    # is judged against the larger of its own scale and 1e-3 of the largest gradient in the model
+    top = max(float(pc.grad.abs().max()) for pc in cpu_model.parameters() if pc.grad is not None)
+    for (n, pg), (_, pc) in zip(flow.movements_model.named_parameters(), cpu_model.named_parameters()):
+        if pc.grad is None:
+            assert pg.grad is None or float(pg.grad.abs().max()) == 0.0, n
+            continue
+        err = float((pg.grad.double().cpu() - pc.grad).abs().max())
+        assert err <= 5e-4 * max(float(pc.grad.abs().max()), 1e-3 * top), (n, err)

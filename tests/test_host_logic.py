@@ -216,3 +216,41 @@ def test_flat_parameters_keep_optimizer_semantics():
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.allclose(pa, pb, atol=1e-6)
     assert flat.nbytes() == 4 * sum(p.numel() for p in a.parameters())
+
+
+# ------------------------------------------------------------------------------ the other model plugins
+def _load_sd(model, g, sd_from=None):
+    sd = {k[4:]: v for k, v in (sd_from or g).items() if k.startswith('sd__')}
+    model.load_state_dict(sd)                 # reference checkpoint keys load unchanged
+    return model
+
+
+@pytest.mark.parametrize('name,kw', [('linear_ae_residual', {}), ('linear_ae_residual_leaky', {'linear_size': 64})])
+def test_linear_ae_residual_drops_in(golden, name, kw):
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.movements import linear_ae
+    cls = {'linear_ae_residual': linear_ae.LinearAEResidual, 'linear_ae_residual_leaky': linear_ae.LinearAEResidualLeaky}[name]
+    g = golden('model_' + name)
+    model = _load_sd(cls(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, **kw).eval(), g)
+    assert sum(p.numel() for p in model.parameters()) == int(g['n_params'])
+    loc, rot = model(g['frames'])
+    assert model.output_type.name == 'absolute_loc_rot'
+    assert torch.allclose(loc, g['out_loc'], atol=1e-5) and torch.allclose(rot, g['out_rot'], atol=1e-5)
+    assert isinstance(model.configure_optimizers()['optimizer'], torch.optim.Adam)
+
+
+@pytest.mark.parametrize('name', ['a', 'b', 'c'])
+def test_seq2seq_residual_variants_drop_in(golden, name):
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements import seq2seq
+    g = golden('model_seq2seq_residual_' + name)
+    cls = getattr(seq2seq, 'Seq2SeqResidual' + name.upper())
+    if name == 'c':
+        model = cls(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_changes,
+                    hidden_size=16, single_joint_embeddings_size=8).eval()
+        _load_sd(model, g)
+    else:       # same weights as the Seq2SeqEmbeddings golden (asserted when the vectors were generated)
+        model = cls(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d).eval()
+        _load_sd(model, g, golden('model_seq2seq_embeddings_pose_2d'))
+    assert torch.allclose(model(g['frames']), g['out'], atol=1e-5)

@@ -146,3 +146,31 @@ def test_folded_embeddings_with_the_flat_trainer_match_the_unfolded_model():
         res[fold] = (loss.detach().clone(), trainer.flat.flat_grad.detach().clone())
     close(res[True][0], res[False][0], 'loss', rtol=1e-5)
     close(res[True][1], res[False][1], 'flat gradient', rtol=2e-4)
+
+
+@pytest.mark.parametrize('variant', ['A', 'B'])
+def test_residual_seq2seq_variants_on_the_gpu_match_cpu(variant):
+    """Seq2SeqResidualA/B (per-frame decoder through the fused LSTM layer op, folded encoder) vs the module in fp64 on the
+    CPU: output and every parameter gradient, with teacher forcing on identical forcing decisions."""
+    import copy
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements import seq2seq
+    d = dev()
+    torch.manual_seed(4)
+    cls = getattr(seq2seq, 'Seq2SeqResidual' + variant)
+    model = cls(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d, p_dropout=0.0,
+                teacher_mode='frames_force', teacher_force_ratio=0.3).train()
+    cpu, gpu = copy.deepcopy(model).double(), model.to(d)
+    x, up, tgt = torch.randn(7, 16, 26, 2), torch.randn(7, 16, 26, 2), torch.randn(7, 16, 26, 2)
+    idx = torch.rand(16, 7) < 0.3
+    for m, dev_, dt in ((cpu, 'cpu', torch.float64), (gpu, d, torch.float32)):
+        forced = tgt.permute(1, 0, 2, 3).reshape(16, 7, 52).to(dev_, dt)
+        m._teacher_forcing = lambda targets, f=forced, i=idx.to(dev_): (True, f, i)
+    yr = cpu(x.double(), {})
+    (yr * up.double()).sum().backward()
+    y = gpu(x.to(d), {})
+    (y * up.to(d)).sum().backward()
+    close(y, yr, 'model output', rtol=2e-4)
+    for (n, pg), (_, pc) in zip(gpu.named_parameters(), cpu.named_parameters()):
+        close(pg.grad, pc.grad, 'grad ' + n, rtol=5e-4)
