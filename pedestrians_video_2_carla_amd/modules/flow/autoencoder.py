@@ -8,15 +8,17 @@ from typing import Dict
 import torch
 
 from pedestrians_video_2_carla_amd.modules.flow.base import LitBaseFlow
-from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE
-from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2Seq, Seq2SeqEmbeddings
+from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE, LinearAEResidual, LinearAEResidualLeaky
+from pedestrians_video_2_carla_amd.modules.movements.seq2seq import (Seq2Seq, Seq2SeqEmbeddings, Seq2SeqResidualA, Seq2SeqResidualB,
+                                                                   Seq2SeqResidualC)
 from pedestrians_video_2_carla_amd.modules.movements.zero import ZeroMovements
 
 
 class LitAutoencoderFlow(LitBaseFlow):
     @classmethod
     def get_available_models(cls) -> Dict[str, Dict[str, torch.nn.Module]]:
-        return {'movements': {m.__name__: m for m in [ZeroMovements, LinearAE, Seq2Seq, Seq2SeqEmbeddings]}}
+        return {'movements': {m.__name__: m for m in [ZeroMovements, LinearAE, Seq2Seq, Seq2SeqEmbeddings, Seq2SeqResidualA,
+                                                      Seq2SeqResidualB, Seq2SeqResidualC]}}
 
     @classmethod
     def get_default_models(cls) -> Dict[str, torch.nn.Module]:

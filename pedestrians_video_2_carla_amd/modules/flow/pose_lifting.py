@@ -21,8 +21,9 @@ from pedestrians_video_2_carla_amd.loss.fused import FusedLosses
 from pedestrians_video_2_carla_amd.modules.flow.base import LitBaseFlow
 from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType
 from pedestrians_video_2_carla_amd.modules.layers.projection import ProjectionModule
-from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE
-from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2Seq, Seq2SeqEmbeddings
+from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE, LinearAEResidual, LinearAEResidualLeaky
+from pedestrians_video_2_carla_amd.modules.movements.seq2seq import (Seq2Seq, Seq2SeqEmbeddings, Seq2SeqResidualA, Seq2SeqResidualB,
+                                                                   Seq2SeqResidualC)
 from pedestrians_video_2_carla_amd.modules.movements.pose_former import PoseFormer
 from pedestrians_video_2_carla_amd.modules.movements.zero import ZeroMovements
 from pedestrians_video_2_carla_amd.modules.trajectory.zero import ZeroTrajectory
@@ -51,7 +52,9 @@ class LitPoseLiftingFlow(LitBaseFlow):
     @classmethod
     def get_available_models(cls) -> Dict[str, Dict[str, torch.nn.Module]]:
         return {
-            'movements': {m.__name__: m for m in [ZeroMovements, LinearAE, Seq2Seq, Seq2SeqEmbeddings, PoseFormer]},
+            'movements': {m.__name__: m for m in [ZeroMovements, LinearAE, Seq2Seq, Seq2SeqEmbeddings, Seq2SeqResidualA,
+                                                  Seq2SeqResidualB, Seq2SeqResidualC, LinearAEResidual,
+                                                  LinearAEResidualLeaky, PoseFormer]},
             'trajectory': {m.__name__: m for m in [ZeroTrajectory]},
         }
 
