@@ -64,6 +64,10 @@ struct MlpArgs {
   int32_t vec_x, vec_y, vec_gy;  // 16-byte row loads/stores are legal (row length % 4 == 0 and base aligned)
   float *w_image;                // packed, zero-padded weight images in HBM (w_total floats), written by mlp_pack_kernel
   int32_t tab[2 * MAX_SLOTS * WAVES];   // dW tile t: LDS float offsets (relative to H) of its G rows and its H rows
+  // split weight gradient (small batches): per sample tile the backward leaves H_1..H_{L-1} and G_1..G_{L-1} transposed
+  // ([row][16 samples]) in `factors`; row f_off[l] (+ f_half for G) is the first row of layer l, f_rows = 2 * f_half
+  float *factors;
+  int32_t f_off[NL + 1], f_half, f_rows;
 };
 
 __host__ __device__ constexpr int pad16(int n) { return (n + 15) & ~15; }
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
 
 // ---- backward --------------------------------------------------------------------------------------------------------
 // LDS: [weight images | H_0 .. H_{L-1} | G_1 .. G_L (G_L = gy tile)]
-template <class S>
+template <class S, bool FACTORS = false>
 __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
   const S sh(a);
@@ -616,6 +620,21 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
     });
     lds_barrier();
     TR(1, 22);
+    if constexpr (FACTORS) {
+      // ---- split weight gradient: the tile's activations and output gradients go out as they sit in LDS (transposed,
+      // 16 samples = 64 B per row); mlp_wgrad_kernel contracts them over ALL samples. H_0 = x and G_L = gy are in HBM.
+      f32x4 *fdst = reinterpret_cast<f32x4 *>(a.factors) + (size_t)tile * a.f_rows * 4;
+      for_layers(sh, 1, nl, [&](int l) {
+        const int rows4 = sh.dims(l) * 4;
+        const float *hsrc = H + sh.h_off(l) * TP, *gsrc = G + sh.h_off(l) * TP;
+        f32x4 *hd = fdst + a.f_off[l] * 4, *gd = fdst + (a.f_half + a.f_off[l]) * 4;
+        for (int i = threadIdx.x; i < rows4; i += NTH) {
+          const int o = (i >> 2) * TP + (i & 3) * 4;
+          hd[i] = (f32x4){hsrc[o], hsrc[o + 1], hsrc[o + 2], hsrc[o + 3]};
+          gd[i] = (f32x4){gsrc[o], gsrc[o + 1], gsrc[o + 2], gsrc[o + 3]};
+        }
+      });
+    } else {
     // ---- phase W: dW_aug_l[n][m] += sum_s G_{l+1}^T[n][s] * H_l^T_aug[m][s]; tile t = slot * WAVES + wave.
     // Branch-free: slots past the last tile alias tile 0 and are never written out. Samples beyond N carry G = 0.
     // On the workgroup's last sample tile every finished slot goes straight out as this workgroup's partial gradient
@@ -634,11 +653,12 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
       for (int s = 0; s < TS / 4; ++s) acc[slot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[slot], 0, 0, 0);
       if (last_tile && t < a.n_tiles_w) __builtin_nontemporal_store(acc[slot], &part[t * 64 + L.lane]);   // read once, by another kernel
     }
+    }
   };
   if ((int64_t)blockIdx.x < n_tiles) one_tile(blockIdx.x, std::true_type{});
   for (int64_t tile = (int64_t)blockIdx.x + gridDim.x; tile < n_tiles; tile += gridDim.x) one_tile(tile, std::false_type{});
   TR(1, 23);
-  if ((int64_t)blockIdx.x >= n_tiles) {   // empty batch: this workgroup saw no sample tile, its partial is zero
+  if (!FACTORS && (int64_t)blockIdx.x >= n_tiles) {   // empty batch: this workgroup saw no sample tile, its partial is zero
 #pragma unroll
     for (int slot = 0; slot < MAX_SLOTS; ++slot) {
       const int t = slot * WAVES + L.wave;
@@ -646,6 +666,90 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
     }
   }
   TR(1, 39);
+}
+
+// ---- split weight gradient (small batches: about one sample tile per CU) ---------------------------------------------
+// With one 16-sample tile per workgroup the fused wgrad phase leaves 256 x 80 KB of partial dW tiles (20 MB written, 20 MB
+// re-read by the reduction) for 70 KB of gradient. Here the backward leaves its FACTORS instead (20 KB per sample tile) and
+// this kernel contracts them over all samples: workgroup (t, q) owns dW tile t and every KS-th group of WAVES sample
+// tiles; wave w walks sample tiles q * WAVES + w, + KS * WAVES, ... with one accumulator, the eight waves are added in
+// wave order through LDS, and the KS partial tiles per dW tile go to mlp_reduce_kernel (n_blocks = KS) in the usual
+// tile-major layout. Fixed order everywhere: bitwise reproducible. Lane (r, k) of the MFMA A / B operand holds samples
+// 4k .. 4k+3 of the tile as one float4 and feeds component i to MFMA step i -- the contraction runs over the 16 samples in
+// the order (4k + i), the same bijection on both operands.
+constexpr int WG_UNROLL = 4;
+// `o` / `coefs_out` (optimizer in backward): the double-precision bias corrections of this step are worked out here, by
+// one thread, while the contraction runs -- the reduction that follows only loads them.
+__global__ __launch_bounds__(64 * WAVES) void mlp_wgrad_kernel(const MlpArgs a, int n_stiles, int ks, const p2c_adamw_desc o,
+                                                               p2c_optim::Coefs *coefs_out) {
+  if (coefs_out && blockIdx.x == 0 && threadIdx.x == 64 * WAVES - 1) *coefs_out = p2c_optim::coefs(o, *o.step + 1.f);
+  __shared__ f32x4 red[WAVES][64];
+  const int lane = threadIdx.x & 63, r = lane & 15, k = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // consecutive workgroups land on consecutive XCDs: q = blockIdx % ks (ks = 8 XCDs) makes XCD q read only the sample
+  // tiles st = q (mod 8) -- the ones the backward's workgroups ON THE SAME XCD just wrote, still in its L2 -- instead of
+  // every XCD pulling all factors through its own L2 (measured: 11.4 -> see DESIGN.md)
+  const int q = blockIdx.x % ks, t = blockIdx.x / ks;
+  const TileRef tr = locate_tile(a.dims, t);
+  const int nl = a.n_layers, n_in = a.dims[tr.l], n_out = a.dims[tr.l + 1];
+  const int n = tr.ntile * 16 + r, m = tr.mtile * 16 + r;
+  const bool a_ok = n < n_out, b_ok = m < n_in, b_one = m == n_in;
+  const bool a_gy = tr.l + 1 == nl, b_x = tr.l == 0;
+  // row of this lane inside a sample tile's factor block (unused for the gy / x operands)
+  const size_t a_row = (size_t)(a.f_half + a.f_off[a_gy ? 1 : tr.l + 1] + n) * 16 + 4 * k;
+  const size_t b_row = (size_t)(a.f_off[b_x ? 1 : tr.l] + m) * 16 + 4 * k;
+  const size_t f_tile = (size_t)a.f_rows * 16;
+  const int nL = a.dims[nl], n0 = a.dims[0];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, ones = {1.f, 1.f, 1.f, 1.f};
+  auto load_a = [&](int st) -> f32x4 {
+    if (!a_ok) return zero;
+    if (!a_gy) return *reinterpret_cast<const f32x4 *>(a.factors + (size_t)st * f_tile + a_row);
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t s = (int64_t)st * TS + 4 * k + i;
+      v[i] = s < a.N ? a.gy[s * nL + n] : 0.f;
+    }
+    return v;
+  };
+  auto load_b = [&](int st) -> f32x4 {
+    if (b_one) return ones;                                   // the bias column (G is zero for samples beyond N)
+    if (!b_ok) return zero;
+    if (!b_x) return *reinterpret_cast<const f32x4 *>(a.factors + (size_t)st * f_tile + b_row);
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t s = (int64_t)st * TS + 4 * k + i;
+      v[i] = s < a.N ? a.x[s * n0 + m] : 0.f;
+    }
+    return v;
+  };
+  const int step = ks * WAVES;
+  int st = q + ks * wave;
+  for (; st + (WG_UNROLL - 1) * step < n_stiles; st += WG_UNROLL * step) {   // WG_UNROLL sample tiles in flight
+    f32x4 av[WG_UNROLL], bv[WG_UNROLL];
+#pragma unroll
+    for (int u = 0; u < WG_UNROLL; ++u) av[u] = load_a(st + u * step), bv[u] = load_b(st + u * step);
+#pragma unroll
+    for (int u = 0; u < WG_UNROLL; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][i], acc, 0, 0, 0);
+    }
+  }
+  for (; st < n_stiles; st += step) {
+    const f32x4 av = load_a(st), bv = load_b(st);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    f32x4 s = red[0][lane];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) s += red[w][lane];
+    reinterpret_cast<f32x4 *>(a.partials)[((size_t)q * a.n_tiles_w + t) * 64 + lane] = s;
+  }
 }
 
 // grad = sum over workgroups of their partial tiles, in a fixed order (bitwise reproducible), scattered to the per-layer
@@ -656,7 +760,8 @@ constexpr int RL = 16;    // lanes of a tile per reducing workgroup: 4 workgroup
 // that holds a finished gradient applies AdamW to its parameter in the flat buffers and refreshes the packed weight image;
 // the last workgroup to finish publishes the new step count. Same formula as p2c_optim::adamw_kernel (p2c_adam_math.h).
 template <bool ADAM>
-__global__ __launch_bounds__(RL * RG) void mlp_reduce_kernel(const MlpArgs a, int n_blocks, const p2c_adamw_desc o) {
+__global__ __launch_bounds__(RL * RG) void mlp_reduce_kernel(const MlpArgs a, int n_blocks, const p2c_adamw_desc o,
+                                                          const p2c_optim::Coefs *coefs_in) {
   __shared__ f32x4 red[RG][RL];
   const int t = blockIdx.x / (64 / RL), li = threadIdx.x % RL, q = threadIdx.x / RL;
   const int lane = (blockIdx.x % (64 / RL)) * RL + li;        // lane of the MFMA C tile this thread reduces
@@ -664,7 +769,7 @@ __global__ __launch_bounds__(RL * RG) void mlp_reduce_kernel(const MlpArgs a, in
   __shared__ p2c_optim::Coefs sc;
   if (ADAM) {
     step = *o.step + 1.f;                                     // read before this workgroup draws its completion ticket
-    if (threadIdx.x == RL * RG - 1) sc = p2c_optim::coefs(o, step);   // a thread of the last group: overlaps the partial loads
+    if (threadIdx.x == RL * RG - 1) sc = coefs_in ? *coefs_in : p2c_optim::coefs(o, step);   // overlaps the partial loads
   }
   // where this thread's four gradients go (threads of group 0 finish the job); with ADAM their parameter and moments are
   // requested now, so that their latency hides behind the partial-tile loads
@@ -757,6 +862,12 @@ static int fill(MlpArgs &a, const p2c_mlp_desc *d) {
     wtot += img_rows_of(a.dims[l + 1]) * a.ld[l];
   }
   a.act_rows = rows;
+  for (int l = 1, r = 0; l <= d->n_layers; ++l) {
+    a.f_off[l] = r;
+    if (l < d->n_layers) r += a.dims[l];
+    a.f_half = r;
+  }
+  a.f_rows = 2 * a.f_half;
   a.n_tiles_w = tiles;
   a.n_params = params;
   a.w_total = (wtot + 3) & ~3;
@@ -798,7 +909,8 @@ static bool force_generic() {
 }
 template <class S>
 static void allow_big_lds_for() {
-  (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 static void allow_big_lds() {
@@ -810,13 +922,18 @@ static void allow_big_lds() {
   allow_big_lds_for<LinearAE52>();
   done = true;
 }
-static mlp_kernel_t pick(const MlpArgs &a, bool bwd) {
+template <class S>
+static mlp_kernel_t pick_of(bool bwd, bool factors) {
+  if (!bwd) return mlp_fwd_kernel<S>;
+  return factors ? mlp_bwd_kernel<S, true> : mlp_bwd_kernel<S, false>;
+}
+static mlp_kernel_t pick(const MlpArgs &a, bool bwd, bool factors = false) {
   if (!force_generic()) {
-    if (LinearAE156::matches(a)) return bwd ? mlp_bwd_kernel<LinearAE156> : mlp_fwd_kernel<LinearAE156>;
-    if (LinearAE78::matches(a)) return bwd ? mlp_bwd_kernel<LinearAE78> : mlp_fwd_kernel<LinearAE78>;
-    if (LinearAE52::matches(a)) return bwd ? mlp_bwd_kernel<LinearAE52> : mlp_fwd_kernel<LinearAE52>;
+    if (LinearAE156::matches(a)) return pick_of<LinearAE156>(bwd, factors);
+    if (LinearAE78::matches(a)) return pick_of<LinearAE78>(bwd, factors);
+    if (LinearAE52::matches(a)) return pick_of<LinearAE52>(bwd, factors);
   }
-  return bwd ? mlp_bwd_kernel<DynShape> : mlp_fwd_kernel<DynShape>;
+  return pick_of<DynShape>(bwd, factors);
 }
 
 static int max_blocks() {
@@ -831,6 +948,30 @@ static inline int n_blocks(int64_t N) {
   int64_t n_tiles = (N + TS - 1) / TS;
   const int cap = max_blocks();
   return (int)(n_tiles < cap ? (n_tiles < 1 ? 1 : n_tiles) : cap);   // persistent: one workgroup per CU
+}
+
+// Weight-gradient strategy. The fused phase (accumulators in registers across the persistent tile loop, one partial per
+// workgroup) costs 2 x 80 KB of HBM traffic per WORKGROUP; the split path costs 20 KB of factors per SAMPLE TILE plus one
+// more launch. Split pays where the fused path's partials peak relative to its compute: about one sample tile per CU
+// (measured, train step at B = 128 / 256 / 512 / 768 clips of 16 frames: fused 47.0 / 51.8 / 67.2 / 82.3 us, split
+// 47.1 / 49.8 / 71.4 / 93.0 us). P2C_MLP_WGRAD=fused|split overrides (tests, measurements).
+constexpr int WGRAD_KS = 8;      // = XCDs: see mlp_wgrad_kernel
+static bool split_wgrad(int64_t N) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("P2C_MLP_WGRAD");
+    mode = !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'f' ? 2 : 0));
+  }
+  const int64_t n_stiles = (N + TS - 1) / TS;
+  if (n_stiles < 1) return false;
+  if (mode == 1) return true;
+  if (mode == 2) return false;
+  const int64_t cus = max_blocks();
+  return 4 * n_stiles > 3 * cus && 2 * n_stiles <= 3 * cus;      // (0.75, 1.5] sample tiles per workgroup slot
+}
+static inline int64_t split_floats(const MlpArgs &a) {
+  const int64_t n_stiles = (a.N + TS - 1) / TS;
+  return (int64_t)WGRAD_KS * a.n_tiles_w * 256 + n_stiles * a.f_rows * 16 + 16;     // + this step's optimizer coefficients
 }
 
 #ifdef P2C_MLP_TRACE
@@ -876,7 +1017,8 @@ extern "C" int64_t p2c_mlp_image_index(const p2c_mlp_desc *d, int32_t *index, in
 extern "C" int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *d) {
   MlpArgs a;
   if (fill(a, d)) return 0;
-  return (int64_t)n_blocks(a.N) * a.n_tiles_w * 256;
+  const int64_t fused = (int64_t)n_blocks(a.N) * a.n_tiles_w * 256;
+  return split_wgrad(a.N) && split_floats(a) > fused ? split_floats(a) : fused;
 }
 
 extern "C" int p2c_mlp_fwd(const p2c_mlp_desc *d, void *stream_) {
@@ -905,9 +1047,22 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   if (a.n_tiles_w > MAX_SLOTS * WAVES) return P2C_E_SHAPE;
   const size_t lds = lds_bwd(a);
   if (lds > 160 * 1024) return P2C_E_SHAPE;
-  const int blocks = n_blocks(a.N);
+  int blocks = n_blocks(a.N);
+  p2c_optim::Coefs *coefs = nullptr;
   allow_big_lds();
-  hipLaunchKernelGGL(pick(a, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+  if (d->fused_adamw && (!d->fused_adamw->step || !d->fused_adamw->hyper)) return P2C_E_NULL;
+  if (split_wgrad(a.N)) {
+    const int n_stiles = (int)((a.N + TS - 1) / TS);
+    a.factors = a.partials + (size_t)WGRAD_KS * a.n_tiles_w * 256;      // [KS partial tiles | factors]
+    hipLaunchKernelGGL(pick(a, true, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+    coefs = reinterpret_cast<p2c_optim::Coefs *>(a.factors + (size_t)n_stiles * a.f_rows * 16);
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(a.n_tiles_w * WGRAD_KS), dim3(64 * WAVES), 0, (hipStream_t)stream_, a,
+                       n_stiles, WGRAD_KS, d->fused_adamw ? *d->fused_adamw : p2c_adamw_desc{},
+                       d->fused_adamw ? coefs : nullptr);
+    blocks = WGRAD_KS;                                                   // what the reduction adds up
+  } else {
+    hipLaunchKernelGGL(pick(a, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+  }
   const dim3 rgrid(a.n_tiles_w * (64 / RL)), rblock(RL * RG);
   if (d->fused_adamw) {
     const p2c_adamw_desc o = *d->fused_adamw;
@@ -918,9 +1073,9 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
         return P2C_E_INDEX;
     }
     if ((int64_t)a.n_params != o.n) return P2C_E_SHAPE;       // the MLP must be ALL the optimizer optimises (step counter)
-    hipLaunchKernelGGL(mlp_reduce_kernel<true>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, o);
+    hipLaunchKernelGGL(mlp_reduce_kernel<true>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, o, coefs);
   } else {
-    hipLaunchKernelGGL(mlp_reduce_kernel<false>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, p2c_adamw_desc{});
+    hipLaunchKernelGGL(mlp_reduce_kernel<false>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, p2c_adamw_desc{}, nullptr);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

@@ -141,3 +141,35 @@ def test_optimizer_step_fused_into_the_backward_equals_the_separate_step():
                        ('exp_avg_sq', oa.state[fa]['exp_avg_sq'], ob.state[fb]['exp_avg_sq']), ('image', ia, ib)):
         err = float((u - v).abs().max() / v.abs().max())
         assert err < 1e-6, (name, err)
+
+
+def test_split_weight_gradient_at_one_tile_per_cu_matches_fp64():
+    """N = 4096 frames (B = 256 clips): 256 sample tiles, one per CU -- the regime where p2c_mlp_bwd leaves factors and
+    mlp_wgrad_kernel contracts them (XCD-local K split, 8 partials per dW tile). Ragged N around it too."""
+    from pedestrians_video_2_carla_amd import ops
+    d = torch.device('cuda:0')
+    dims = [52, 26, 13, 6, 39, 78, 156]
+    torch.manual_seed(9)
+    for N in (4096, 4090, 3200):
+        layers = [torch.nn.Linear(i, o) for i, o in zip(dims[:-1], dims[1:])]
+        seq = torch.nn.Sequential(*[m for l in layers for m in (l, torch.nn.ReLU())][:-1]).to(d)
+        ref = copy.deepcopy(seq).double()
+        x, w = torch.randn(N, dims[0], device=d), torch.randn(N, dims[-1], device=d)
+        lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+        y = ops.fused_mlp(x, [m.weight for m in lin], [m.bias for m in lin])
+        (y * w).sum().backward()
+        (ref(x.double()) * w.double()).sum().backward()
+        for p, q in zip(seq.parameters(), ref.parameters()):
+            close(p.grad, q.grad, f'grad N={N}')
+
+
+def test_every_mlp_test_also_passes_with_the_split_weight_gradient_forced():
+    """P2C_MLP_WGRAD=split (read once per process, so a child pytest) sends every batch size through the factor path:
+    ragged tails, one-tile batches, the generic shapes, the optimizer-in-backward variant."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, P2C_MLP_WGRAD='split')
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_mlp_gpu.py'), '-q', '-x', '-m', 'gpu',
+                          '-p', 'no:cacheprovider', '-k', 'not forced'], env=env, cwd=root, capture_output=True, text=True,
+                         timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
