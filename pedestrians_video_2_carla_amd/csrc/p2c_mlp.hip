@@ -682,7 +682,6 @@ constexpr int WG_UNROLL = 4;
 // one thread, while the contraction runs -- the reduction that follows only loads them.
 __global__ __launch_bounds__(64 * WAVES) void mlp_wgrad_kernel(const MlpArgs a, int n_stiles, int ks, const p2c_adamw_desc o,
                                                                p2c_optim::Coefs *coefs_out) {
-  if (coefs_out && blockIdx.x == 0 && threadIdx.x == 64 * WAVES - 1) *coefs_out = p2c_optim::coefs(o, *o.step + 1.f);
   __shared__ f32x4 red[WAVES][64];
   const int lane = threadIdx.x & 63, r = lane & 15, k = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -742,6 +741,8 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_wgrad_kernel(const MlpArgs a, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
   }
+  // (after this wave's loads and MFMAs are in the pipes: the fp64 arithmetic of one thread hides behind them)
+  if (coefs_out && blockIdx.x == 0 && threadIdx.x == 64 * WAVES - 1) *coefs_out = p2c_optim::coefs(o, *o.step + 1.f);
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0) {
@@ -819,6 +820,64 @@ __global__ __launch_bounds__(RL * RG) void mlp_reduce_kernel(const MlpArgs a, in
           const int n = tr.ntile * 16 + 4 * (lane >> 4) + r;
           if (a.w_image) a.w_image[a.w_off[tr.l] + n * a.ld[tr.l] + m] = pv[r];    // bias sits in column n_in == m
         }
+      }
+    }
+  }
+  if (ADAM) {
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(o.ticket, 1) == (int)gridDim.x - 1) {
+      *o.step = step;
+      *o.ticket = 0;
+    }
+  }
+}
+
+// The same job for a handful of partials per tile (split weight gradient: NB = 8): one thread per (tile, lane) adds them in
+// order -- no LDS, no barrier in front of the update.
+template <bool ADAM, int NB>
+__global__ __launch_bounds__(256) void mlp_reduce_small_kernel(const MlpArgs a, const p2c_adamw_desc o,
+                                                               const p2c_optim::Coefs *coefs_in) {
+  const int idx = blockIdx.x * 256 + threadIdx.x, t = idx >> 6, lane = idx & 63;
+  const bool live = t < a.n_tiles_w;
+  float step = 0.f;
+  if (ADAM) step = *o.step + 1.f;
+  if (live) {
+    const size_t stride = (size_t)a.n_tiles_w * 64;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(a.partials) + (size_t)t * 64 + lane;
+    f32x4 v[NB];
+#pragma unroll
+    for (int w = 0; w < NB; ++w) v[w] = __builtin_nontemporal_load(&p[(size_t)w * stride]);
+    const TileRef tr = locate_tile(a.dims, t);
+    const int n_in = a.dims[tr.l], n_out = a.dims[tr.l + 1];
+    const int m = tr.mtile * 16 + (lane & 15);
+    float *gp[4];
+    float pv[4], mv[4], vv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = tr.ntile * 16 + 4 * (lane >> 4) + r;
+      gp[r] = (n < n_out && m <= n_in) ? ((m < n_in) ? a.gW[tr.l] + n * n_in + m : a.gb[tr.l] + n) : nullptr;
+      pv[r] = mv[r] = vv[r] = 0.f;
+      if (ADAM && gp[r]) {
+        const ptrdiff_t off = gp[r] - o.grad;
+        pv[r] = o.param[off], mv[r] = o.exp_avg[off], vv[r] = o.exp_avg_sq[off];
+      }
+    }
+    p2c_optim::Coefs c;
+    if (ADAM) c = *coefs_in;
+    f32x4 s = v[0];
+#pragma unroll
+    for (int w = 1; w < NB; ++w) s += v[w];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (!gp[r]) continue;
+      *gp[r] = s[r];
+      if (ADAM) {
+        const ptrdiff_t off = gp[r] - o.grad;
+        if (o.adamw) p2c_optim::update<true>(c, pv[r], s[r], mv[r], vv[r]);
+        else p2c_optim::update<false>(c, pv[r], s[r], mv[r], vv[r]);
+        o.param[off] = pv[r], o.exp_avg[off] = mv[r], o.exp_avg_sq[off] = vv[r];
+        const int n = tr.ntile * 16 + 4 * (lane >> 4) + r;
+        if (a.w_image) a.w_image[a.w_off[tr.l] + n * a.ld[tr.l] + m] = pv[r];
       }
     }
   }
@@ -1063,7 +1122,7 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   } else {
     hipLaunchKernelGGL(pick(a, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
   }
-  const dim3 rgrid(a.n_tiles_w * (64 / RL)), rblock(RL * RG);
+  const dim3 rgrid(a.n_tiles_w * (64 / RL)), rblock(RL * RG), sgrid((a.n_tiles_w * 64 + 255) / 256);
   if (d->fused_adamw) {
     const p2c_adamw_desc o = *d->fused_adamw;
     if (!o.param || !o.grad || !o.exp_avg || !o.exp_avg_sq || !o.step || !o.ticket || !o.hyper) return P2C_E_NULL;
@@ -1073,9 +1132,16 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
         return P2C_E_INDEX;
     }
     if ((int64_t)a.n_params != o.n) return P2C_E_SHAPE;       // the MLP must be ALL the optimizer optimises (step counter)
-    hipLaunchKernelGGL(mlp_reduce_kernel<true>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, o, coefs);
+    if (coefs)
+      hipLaunchKernelGGL((mlp_reduce_small_kernel<true, WGRAD_KS>), sgrid, dim3(256), 0, (hipStream_t)stream_, a, o, coefs);
+    else
+      hipLaunchKernelGGL(mlp_reduce_kernel<true>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, o, coefs);
   } else {
-    hipLaunchKernelGGL(mlp_reduce_kernel<false>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, p2c_adamw_desc{}, nullptr);
+    if (blocks == WGRAD_KS && split_wgrad(a.N))
+      hipLaunchKernelGGL((mlp_reduce_small_kernel<false, WGRAD_KS>), sgrid, dim3(256), 0, (hipStream_t)stream_, a,
+                         p2c_adamw_desc{}, nullptr);
+    else
+      hipLaunchKernelGGL(mlp_reduce_kernel<false>, rgrid, rblock, 0, (hipStream_t)stream_, a, blocks, p2c_adamw_desc{}, nullptr);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
