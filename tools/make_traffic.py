@@ -18,8 +18,8 @@ GROUPS = {
     'pose_head_rot_fwd<6D>(+loss_finalize)': ('pose_head_rot_fwd_tp<0>', 'pose_head_rot_fwd<0, false>', 'loss_finalize'),
     'pose_head_rot_bwd<6D>': ('pose_head_rot_bwd',),
     'mlp_fwd': ('mlp_fwd_kernel',),
-    'mlp_bwd(+reduce)': ('mlp_bwd_kernel', 'mlp_reduce_kernel'),
-    'mlp_bwd(+reduce+adamw)': ('mlp_bwd_kernel', 'mlp_reduce_kernel'),
+    'mlp_bwd(+reduce)': ('mlp_bwd_kernel', 'mlp_wgrad_kernel', 'mlp_reduce_kernel', 'mlp_reduce_small_kernel'),
+    'mlp_bwd(+reduce+adamw)': ('mlp_bwd_kernel', 'mlp_wgrad_kernel', 'mlp_reduce_kernel', 'mlp_reduce_small_kernel'),
     'adamw': ('adamw_kernel',),
 }
 
