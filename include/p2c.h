@@ -162,7 +162,9 @@ P2C_API int p2c_remap_nodes(const float *src, float *dst, int64_t N, int32_t Jsr
  * y = W_{L-1} relu( ... relu(W_0 x + b_0) ... ) + b_{L-1} over N rows; dims[l] -> dims[l+1], every width <= 159.
  * Forward: x (N,dims[0]) -> y (N,dims[L]). Backward (activations recomputed): gy (N,dims[L]) -> gW[l] (dims[l+1],dims[l]),
  * gb[l] (dims[l+1]) -- WRITTEN, not accumulated -- through `partials` (p2c_mlp_workspace_floats floats) and a fixed-order
- * reduction (bitwise reproducible). x receives no gradient (the flows feed data). */
+ * reduction (bitwise reproducible). x receives no gradient (the flows feed data). Two or three launches: per-workgroup
+ * partial gradient tiles + reduction, or -- around one 16-row tile per CU -- activation / gradient factors + a contraction
+ * over all rows + reduction (environment P2C_MLP_WGRAD=fused|split overrides the choice); the workspace size covers both. */
 #define P2C_MLP_MAX_LAYERS 8
 struct p2c_adamw_desc;
 typedef struct p2c_mlp_desc {
