@@ -678,11 +678,15 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
 // 4k .. 4k+3 of the tile as one float4 and feeds component i to MFMA step i -- the contraction runs over the 16 samples in
 // the order (4k + i), the same bijection on both operands.
 constexpr int WG_UNROLL = 4;
+#ifndef P2C_WGRAD_WAVES
+#define P2C_WGRAD_WAVES 8
+#endif
+constexpr int WGW = P2C_WGRAD_WAVES;   // waves per workgroup of the contraction
 // `o` / `coefs_out` (optimizer in backward): the double-precision bias corrections of this step are worked out here, by
 // one thread, while the contraction runs -- the reduction that follows only loads them.
-__global__ __launch_bounds__(64 * WAVES) void mlp_wgrad_kernel(const MlpArgs a, int n_stiles, int ks, const p2c_adamw_desc o,
+__global__ __launch_bounds__(64 * WGW) void mlp_wgrad_kernel(const MlpArgs a, int n_stiles, int ks, const p2c_adamw_desc o,
                                                                p2c_optim::Coefs *coefs_out) {
-  __shared__ f32x4 red[WAVES][64];
+  __shared__ f32x4 red[WGW][64];
   const int lane = threadIdx.x & 63, r = lane & 15, k = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // consecutive workgroups land on consecutive XCDs: q = blockIdx % ks (ks = 8 XCDs) makes XCD q read only the sample
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_wgrad_kernel(const MlpArgs a, 
     }
     return v;
   };
-  const int step = ks * WAVES;
+  const int step = ks * WGW;
   int st = q + ks * wave;
   for (; st + (WG_UNROLL - 1) * step < n_stiles; st += WG_UNROLL * step) {   // WG_UNROLL sample tiles in flight
     f32x4 av[WG_UNROLL], bv[WG_UNROLL];
@@ -742,13 +746,13 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_wgrad_kernel(const MlpArgs a, 
     for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
   }
   // (after this wave's loads and MFMAs are in the pipes: the fp64 arithmetic of one thread hides behind them)
-  if (coefs_out && blockIdx.x == 0 && threadIdx.x == 64 * WAVES - 1) *coefs_out = p2c_optim::coefs(o, *o.step + 1.f);
+  if (coefs_out && blockIdx.x == 0 && threadIdx.x == 64 * WGW - 1) *coefs_out = p2c_optim::coefs(o, *o.step + 1.f);
   red[wave][lane] = acc;
   __syncthreads();
   if (wave == 0) {
     f32x4 s = red[0][lane];
 #pragma unroll
-    for (int w = 1; w < WAVES; ++w) s += red[w][lane];
+    for (int w = 1; w < WGW; ++w) s += red[w][lane];
     reinterpret_cast<f32x4 *>(a.partials)[((size_t)q * a.n_tiles_w + t) * 64 + lane] = s;
   }
 }
@@ -1115,7 +1119,7 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
     a.factors = a.partials + (size_t)WGRAD_KS * a.n_tiles_w * 256;      // [KS partial tiles | factors]
     hipLaunchKernelGGL(pick(a, true, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
     coefs = reinterpret_cast<p2c_optim::Coefs *>(a.factors + (size_t)n_stiles * a.f_rows * 16);
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(a.n_tiles_w * WGRAD_KS), dim3(64 * WAVES), 0, (hipStream_t)stream_, a,
+    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(a.n_tiles_w * WGRAD_KS), dim3(64 * WGW), 0, (hipStream_t)stream_, a,
                        n_stiles, WGRAD_KS, d->fused_adamw ? *d->fused_adamw : p2c_adamw_desc{},
                        d->fused_adamw ? coefs : nullptr);
     blocks = WGRAD_KS;                                                   // what the reduction adds up
