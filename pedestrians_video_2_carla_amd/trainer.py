@@ -171,16 +171,14 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g_fb = torch.cuda.CUDAGraph()
-        if distributed and os.environ.get('P2C_GRAPH_ALLREDUCE', '0') == '1':
-            # opt-in: the RCCL all-reduce is captured too, the whole step is ONE graph replay (needs an RCCL build that
-            # supports stream capture; verified with one rank only -- see DESIGN.md section 6)
-            with torch.cuda.graph(g_fb):
-                self._static_loss = self._forward_backward(flow, batch, batch_idx)
-                self.exchange.all_reduce_gradients()
-                self._optimizer_step()
-            self._graphs = (g_fb, None)
-            self._restore(flow, snapshot)
-            return
+        mode = os.environ.get('P2C_GRAPH_ALLREDUCE', 'auto')
+        if distributed and mode != '0':
+            # the RCCL all-reduce is captured too: the whole step is ONE graph replay (one-rank rehearsal: 49 us against
+            # 59 us for graph + eager collective + optimizer launch). Guarded: a failed capture / first replay on any rank,
+            # or ranks whose parameters differ after that replay, send every rank to the eager-collective path below.
+            if self._capture_with_allreduce(flow, batch, batch_idx, g_fb, snapshot, strict=(mode == '1')):
+                return
+            g_fb = torch.cuda.CUDAGraph()
         if distributed:
             with torch.cuda.graph(g_fb):
                 self._static_loss = self._forward_backward(flow, batch, batch_idx)
@@ -197,6 +195,37 @@ class Trainer:
                 self._optimizer_step()
         self._graphs = (g_fb, g_opt)
         self._restore(flow, snapshot)
+
+    def _capture_with_allreduce(self, flow, batch, batch_idx, graph, snapshot, strict: bool) -> bool:
+        import torch.distributed as dist
+        ok, err = True, None
+        try:
+            with torch.cuda.graph(graph):
+                self._static_loss = self._forward_backward(flow, batch, batch_idx)
+                self.exchange.all_reduce_gradients()
+                self._optimizer_step()
+            graph.replay()                      # one real step: every rank must come out with the same parameters
+            torch.cuda.synchronize()
+        except Exception as e:                  # noqa: BLE001 -- any failure means "use the eager collective"
+            ok, err = False, e
+        device = self.flat.flat_param.device if self.flat is not None else next(flow.parameters()).device
+        params = self.flat.flat_param.data if self.flat is not None else torch.cat([p.data.reshape(-1) for p in flow.parameters()])
+        chk = params.double().sum() if ok else torch.zeros((), dtype=torch.float64, device=device)
+        votes = torch.stack((torch.tensor(1.0 if ok else 0.0, dtype=torch.float64, device=device), -chk, chk))
+        lo = votes.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)           # eager collectives: agreement on the outcome
+        hi = votes.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        agreed = bool(lo[0] > 0.5) and bool(torch.isfinite(chk)) and float(hi[2]) == float(lo[2])
+        self._restore(flow, snapshot)
+        if agreed:
+            self._graphs = (graph, None)
+            return True
+        if strict:
+            raise RuntimeError(f'P2C_GRAPH_ALLREDUCE=1: capturing the all-reduce failed ({err!r})')
+        if dist.get_rank() == 0:
+            print(f'[trainer] captured all-reduce unavailable ({err!r}); using the eager collective', flush=True)
+        return False
 
     def _state_tensors(self, flow):
         tensors = [p.data for p in flow.parameters()] if self.flat is None else [self.flat.flat_param.data]

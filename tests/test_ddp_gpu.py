@@ -11,7 +11,10 @@ import torch.distributed as dist
 pytestmark = pytest.mark.gpu
 
 
-def test_two_graph_step_with_rccl_matches_single_graph_step(monkeypatch):
+@pytest.mark.parametrize('captured', ['auto', '0'])
+def test_distributed_step_with_rccl_matches_single_graph_step(monkeypatch, captured):
+    """captured = 'auto': the all-reduce is part of the one step graph (default; guarded by a first-replay check with an eager
+    fall-back); '0': two stages with the eager collective between them (P2C_GRAPH_ALLREDUCE=0)."""
     assert torch.cuda.is_available(), 'needs the MI355X'
     from test_flow_gpu import make
     from pedestrians_video_2_carla_amd.trainer import Trainer
@@ -25,6 +28,7 @@ def test_two_graph_step_with_rccl_matches_single_graph_step(monkeypatch):
     single = torch.stack([ta.train_step(flow_a, batch, i).clone() for i in range(steps)]).cpu()
 
     monkeypatch.setenv('P2C_FORCE_EXCHANGE', '1')
+    monkeypatch.setenv('P2C_GRAPH_ALLREDUCE', captured)
     monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
     monkeypatch.setenv('MASTER_PORT', '29533')
     dist.init_process_group(backend='nccl', rank=0, world_size=1)
@@ -32,7 +36,10 @@ def test_two_graph_step_with_rccl_matches_single_graph_step(monkeypatch):
         tb = Trainer(device=d, use_graph=True).setup(flow_b, dm)
         assert tb.exchange.enabled and tb.exchange.world == 1 and not tb.exchange.average_here
         multi = torch.stack([tb.train_step(flow_b, batch, i).clone() for i in range(steps)]).cpu()
-        assert tb._graphs[1] is not None, 'distributed step = two graphs with the collective between them'
+        if captured == '0':
+            assert tb._graphs[1] is not None, 'two stages with the eager collective between them'
+        else:
+            assert tb._graphs[1] is None, 'the collective is part of the one step graph'
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -45,3 +52,40 @@ def test_two_graph_step_with_rccl_matches_single_graph_step(monkeypatch):
     # Adam moves a parameter by ~lr (1e-4) per step whatever the size of its gradient: where the gradient is rounding
     # noise the two instruction streams may step differently -- a few lr over the 12 steps at most
     assert float((pa - pb).abs().max()) <= 3e-4
+
+
+def test_failed_capture_of_the_collective_falls_back_to_the_eager_path(monkeypatch, capsys):
+    """If capturing (or first replaying) the all-reduce fails on any rank, every rank agrees on the eager-collective step and
+    training goes on with unchanged state."""
+    from test_flow_gpu import make
+    from pedestrians_video_2_carla_amd.parallel.flat import GradientExchange
+    from pedestrians_video_2_carla_amd.trainer import Trainer
+    d = torch.device('cuda:0')
+    torch.cuda.set_device(d)
+    flow_a, dm = make(B=16, missing=0.0)
+    flow_b, _ = make(B=16, missing=0.0)
+    batch = dm.generate_batch(d)
+    monkeypatch.setenv('P2C_FORCE_EXCHANGE', '1')
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', '29534')
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        monkeypatch.setenv('P2C_GRAPH_ALLREDUCE', '0')
+        ta = Trainer(device=d, use_graph=True).setup(flow_a, dm)
+        want = torch.stack([ta.train_step(flow_a, batch, i).clone() for i in range(6)]).cpu()
+
+        monkeypatch.setenv('P2C_GRAPH_ALLREDUCE', 'auto')
+        real = GradientExchange.all_reduce_gradients
+
+        def broken(self):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('collective not capturable (simulated)')
+            return real(self)
+        monkeypatch.setattr(GradientExchange, 'all_reduce_gradients', broken)
+        tb = Trainer(device=d, use_graph=True).setup(flow_b, dm)
+        got = torch.stack([tb.train_step(flow_b, batch, i).clone() for i in range(6)]).cpu()
+        assert tb._graphs[1] is not None                       # the eager-collective structure
+        assert 'using the eager collective' in capsys.readouterr().out
+    finally:
+        dist.destroy_process_group()
+    assert torch.equal(want, got), (want, got)
