@@ -156,7 +156,7 @@ def _random_case(B, T, seed, missing=0.1):
     return y, st, gt2, tgt['absolute_pose_loc'], tgt['projection_2d']
 
 
-@pytest.mark.parametrize('B,T', [(1, 1), (3, 5), (37, 7), (64, 16), (129, 30)])
+@pytest.mark.parametrize('B,T', [(1, 1), (3, 5), (37, 7), (64, 16), (129, 30), (5, 33), (9, 81)])   # 81 = PoseFormer's clip (cfg5)
 def test_random_ragged_sizes(B, T):
     """Odd batch sizes (half-filled wavefronts), T != 16, masked gt joints, each loss requested on its own."""
     from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
