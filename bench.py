@@ -170,6 +170,10 @@ def mlp_times(device, model, B, fused_update):
     image = torch.empty(n_image, **f32)
     part = torch.empty(lib.p2c_mlp_workspace_floats(ctypes.byref(desc)), **f32)
     desc.y, desc.w_image, desc.gy, desc.partials = y.data_ptr(), image.data_ptr(), gy.data_ptr(), part.data_ptr()
+    n_saved = lib.p2c_mlp_saved_floats(ctypes.byref(desc))        # many tiles per workgroup: activations saved, as in training
+    saved = torch.empty(max(n_saved, 1), **f32)
+    if n_saved > 0:
+        desc.saved = saved.data_ptr()
     for i in range(len(Ws)):
         desc.gW[i], desc.gb[i] = gW[i].data_ptr(), gb[i].data_ptr()
     opt = FlatAdamW([flat], lr=1e-4, zero_grad_in_step=False)

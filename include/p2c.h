@@ -187,6 +187,9 @@ typedef struct p2c_mlp_desc {
   const struct p2c_adamw_desc *fused_adamw;
   int32_t skip_pack;                    /* 1 = w_image is already current (kept so by p2c_mlp_pack + the optimizer's
                                            scatter, see p2c_adamw_desc): p2c_mlp_fwd does not launch the pack kernel */
+  float *saved;                         /* optional, p2c_mlp_saved_floats floats (0 = not worth it at this N: pass NULL): the
+                                           forward leaves the hidden activations there and the backward of the SAME call pair
+                                           loads them instead of recomputing (bit-identical results) */
 } p2c_mlp_desc;
 P2C_API int64_t p2c_mlp_image_floats(const p2c_mlp_desc *desc);
 /* writes the packed image from the current weights (what p2c_mlp_fwd does first unless skip_pack) */
@@ -195,6 +198,7 @@ P2C_API int p2c_mlp_pack(const p2c_mlp_desc *desc, void *stream);
  * W_0 (row-major), b_0, W_1, b_1, ... (n = sum of n_out * (n_in + 1)); returns n, or a negative P2C_E_* code */
 P2C_API int64_t p2c_mlp_image_index(const p2c_mlp_desc *desc, int32_t *index, int64_t capacity);
 P2C_API int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *desc);
+P2C_API int64_t p2c_mlp_saved_floats(const p2c_mlp_desc *desc);
 P2C_API int p2c_mlp_fwd(const p2c_mlp_desc *desc, void *stream);
 P2C_API int p2c_mlp_bwd(const p2c_mlp_desc *desc, void *stream);
 

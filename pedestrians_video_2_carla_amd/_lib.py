@@ -47,7 +47,7 @@ class MlpDesc(ctypes.Structure):
         ('n_layers', _i32), ('dims', _i32 * (P2C_MLP_MAX_LAYERS + 1)), ('N', ctypes.c_int64), ('x', _f32p),
         ('W', _f32p * P2C_MLP_MAX_LAYERS), ('b', _f32p * P2C_MLP_MAX_LAYERS), ('y', _f32p), ('gy', _f32p),
         ('gW', _f32p * P2C_MLP_MAX_LAYERS), ('gb', _f32p * P2C_MLP_MAX_LAYERS), ('partials', _f32p), ('w_image', _f32p),
-                ('fused_adamw', _f32p), ('skip_pack', ctypes.c_int32),
+        ('fused_adamw', _f32p), ('skip_pack', ctypes.c_int32), ('saved', _f32p),
     ]
 
 
@@ -104,6 +104,7 @@ SYMBOLS = {
                                       _vp, _vp]),
     'p2c_remap_nodes': (ctypes.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _ip, _ip, _vp]),
     'p2c_mlp_workspace_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
+    'p2c_mlp_saved_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
     'p2c_mlp_image_floats': (_i64, [ctypes.POINTER(MlpDesc)]),
     'p2c_mlp_pack': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
     'p2c_mlp_image_index': (_i64, [ctypes.POINTER(MlpDesc), _ip, _i64]),

@@ -68,6 +68,9 @@ struct MlpArgs {
   // ([row][16 samples]) in `factors`; row f_off[l] (+ f_half for G) is the first row of layer l, f_rows = 2 * f_half
   float *factors;
   int32_t f_off[NL + 1], f_half, f_rows;
+  // saved activations (many sample tiles per workgroup): the forward leaves H_1..H_{L-1} of every sample tile in the same
+  // transposed layout (f_half rows of 16 samples), the backward loads them instead of recomputing
+  float *saved;
 };
 
 __host__ __device__ constexpr int pad16(int n) { return (n + 15) & ~15; }
@@ -482,6 +485,66 @@ __device__ __forceinline__ TileRef locate_tile(const int32_t *dims, int t) {
   return r;
 }
 
+// Saved activations of one sample tile <-> the H_1..H_{L-1} rows in LDS. With a static shape the next tile's rows wait in
+// registers (at most two float4 per layer and thread); the generic shape copies without look-ahead.
+constexpr int ACT_C = (4 * (MAXW - 1) + NTH - 1) / NTH;
+struct ActRegs {
+  f32x4 v[NL][ACT_C];
+};
+template <class S>
+__device__ __forceinline__ void acts_issue(const S &sh, const MlpArgs &a, int64_t tile, int64_t n_tiles, ActRegs &r) {
+  if (tile >= n_tiles) return;
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(a.saved) + (size_t)tile * a.f_half * 4;
+  for_layers(sh, 1, sh.n_layers(), [&](int l) {
+    const int rows4 = sh.dims(l) * 4;
+#pragma unroll
+    for (int c = 0; c < ACT_C; ++c) {
+      const int i = threadIdx.x + c * NTH;
+      if (c * NTH < rows4 && i < rows4) r.v[l][c] = src[a.f_off[l] * 4 + i];
+    }
+  });
+}
+template <class S>
+__device__ __forceinline__ void acts_commit(const S &sh, const ActRegs &r, float *H) {
+  for_layers(sh, 1, sh.n_layers(), [&](int l) {
+    const int rows4 = sh.dims(l) * 4;
+    float *dst = H + sh.h_off(l) * TP;
+#pragma unroll
+    for (int c = 0; c < ACT_C; ++c) {
+      const int i = threadIdx.x + c * NTH;
+      if (c * NTH < rows4 && i < rows4) {
+        const int o = (i >> 2) * TP + (i & 3) * 4;
+        dst[o] = r.v[l][c][0], dst[o + 1] = r.v[l][c][1], dst[o + 2] = r.v[l][c][2], dst[o + 3] = r.v[l][c][3];
+      }
+    }
+  });
+}
+template <class S>
+__device__ __forceinline__ void acts_copy(const S &sh, const MlpArgs &a, int64_t tile, float *H) {   // no look-ahead
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(a.saved) + (size_t)tile * a.f_half * 4;
+  for_layers(sh, 1, sh.n_layers(), [&](int l) {
+    float *dst = H + sh.h_off(l) * TP;
+    for (int i = threadIdx.x; i < sh.dims(l) * 4; i += NTH) {
+      const f32x4 v = src[a.f_off[l] * 4 + i];
+      const int o = (i >> 2) * TP + (i & 3) * 4;
+      dst[o] = v[0], dst[o + 1] = v[1], dst[o + 2] = v[2], dst[o + 3] = v[3];
+    }
+  });
+}
+// LDS rows of H_l (l = 1..L-1) -> the transposed HBM block of one sample tile (forward: saved activations; backward with
+// the split weight gradient: the H half of the factors)
+template <class S>
+__device__ __forceinline__ void acts_store(const S &sh, const MlpArgs &a, const float *H, f32x4 *dst_tile) {
+  for_layers(sh, 1, sh.n_layers(), [&](int l) {
+    const float *src = H + sh.h_off(l) * TP;
+    f32x4 *hd = dst_tile + a.f_off[l] * 4;
+    for (int i = threadIdx.x; i < sh.dims(l) * 4; i += NTH) {
+      const int o = (i >> 2) * TP + (i & 3) * 4;
+      hd[i] = (f32x4){src[o], src[o + 1], src[o + 2], src[o + 3]};
+    }
+  });
+}
+
 template <class S>
 __host__ __device__ constexpr int issue_mark(int slot) {
   constexpr int nl = static_layers<S>();
@@ -539,6 +602,9 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
                     a.vec_y != 0);
     });
     TR(0, 12);
+    // saved activations for the backward: every H_l is complete (the last layer's barrier came after H_{L-1} was written)
+    // and stays untouched until the next tile's layer 0 has passed its barrier
+    if (a.saved) acts_store(sh, a, H, reinterpret_cast<f32x4 *>(a.saved) + (size_t)tile * a.f_half * 4);
     // the next tile's x rows overwrite H_0 only after every wave has passed layer 0's barrier chain: the barrier of
     // layer 1 (or, for a single layer, the one below) orders them
     if (nl == 1) lds_barrier();
@@ -550,7 +616,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
 
 // ---- backward --------------------------------------------------------------------------------------------------------
 // LDS: [weight images | H_0 .. H_{L-1} | G_1 .. G_L (G_L = gy tile)]
-template <class S, bool FACTORS = false>
+template <class S, bool FACTORS = false, bool SAVED = false>
 __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
   const S sh(a);
@@ -565,10 +631,18 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   TileRegs xr, gr;
   ImageRegs wr;
   tile_issue(a.x, (int64_t)blockIdx.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // needed first; the image in layer
-  if constexpr (S::kStatic) stage_issue(a, total4, wr, 0, 0, issue_mark<S>(1));    // order behind it; gy (first read by
-  else stage_issue(a, total4, wr);                                                 // the dgrad chain) last
-  if constexpr (static_layers<S>() < 4)
+  if constexpr (S::kStatic && !SAVED) stage_issue(a, total4, wr, 0, 0, issue_mark<S>(1));   // order behind it; gy (first
+  else stage_issue(a, total4, wr);                                                // read by the dgrad chain) last
+  if constexpr (static_layers<S>() < 4 || SAVED)
     tile_issue(a.gy, (int64_t)blockIdx.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr);
+  ActRegs ar;
+  if constexpr (SAVED) {
+    if constexpr (S::kStatic) acts_issue(sh, a, blockIdx.x, (a.N + TS - 1) / TS, ar);
+    // rows the saved activations never overwrite: the constant-one row behind each H_l and the zero rows of the k rounding
+    for_layers(sh, 1, nl, [&](int l) {
+      init_rows(H, sh.h_off(l) + sh.dims(l), sh.h_off(l) + act_rows_of(sh.dims(l)), sh.h_off(l) + sh.dims(l));
+    });
+  }
   init_rows(H, sh.h_off(0) + sh.dims(0), sh.h_off(0) + k_rows(sh.dims(0)), sh.h_off(0) + sh.dims(0));
   init_rows(G, sh.h_off(nl) + sh.dims(nl), sh.h_off(nl) + pad16(sh.dims(nl)), -1);
   if constexpr (!S::kStatic) {
@@ -590,24 +664,36 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
     lds_barrier();                         // previous tile's dW phase has consumed H and G
     tile_commit(sh.dims(0), a.vec_x != 0, xr, H + sh.h_off(0) * TP);
     tile_issue(a.x, row0 + (int64_t)gridDim.x * TS, a.N, sh.dims(0), a.vec_x != 0, xr);   // prefetch this block's next tile
-    // ---- phase F: activations H_1 .. H_{L-1}
-    TR(1, 2);
-    for_layers(sh, 0, nl - 1, [&](int l) {
-      if constexpr (S::kStatic) {   // the image rounds this layer reads, as late as possible
-        if constexpr (first) stage_commit(total4, wr, lds, 0, l == 0 ? 0 : rounds_upto<S>(l - 1), rounds_upto<S>(l));
+    if constexpr (SAVED) {
+      // ---- phase F replaced: H_1 .. H_{L-1} as the forward left them (bit-identical to a recomputation)
+      TR(1, 2);
+      if constexpr (S::kStatic) {
+        acts_commit(sh, ar, H);
+        acts_issue(sh, a, tile + gridDim.x, n_tiles, ar);
+        if constexpr (first) stage_commit(total4, wr, lds);
+      } else {
+        acts_copy(sh, a, tile, H);
       }
-      lds_barrier();
-      if constexpr (S::kStatic && first) {
-        stage_issue(a, total4, wr, 0, issue_mark<S>(l + 1), issue_mark<S>(l + 2));
-        if (static_layers<S>() >= 4 && l == 2) tile_issue(a.gy, row0, a.N, sh.dims(nl), a.vec_gy != 0, gr);   // behind the image
+    } else {
+      // ---- phase F: activations H_1 .. H_{L-1}
+      TR(1, 2);
+      for_layers(sh, 0, nl - 1, [&](int l) {
+        if constexpr (S::kStatic) {   // the image rounds this layer reads, as late as possible
+          if constexpr (first) stage_commit(total4, wr, lds, 0, l == 0 ? 0 : rounds_upto<S>(l - 1), rounds_upto<S>(l));
+        }
+        lds_barrier();
+        if constexpr (S::kStatic && first) {
+          stage_issue(a, total4, wr, 0, issue_mark<S>(l + 1), issue_mark<S>(l + 2));
+          if (static_layers<S>() >= 4 && l == 2) tile_issue(a.gy, row0, a.N, sh.dims(nl), a.vec_gy != 0, gr);   // behind the image
+        }
+        TR(1, 3 + l);
+        layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), true, H + sh.h_off(l) * TP,
+                      H + sh.h_off(l + 1) * TP, nullptr, false, false);
+      });
+      // the last layer's image (first use: the head of the dgrad chain) and the gy tile arrive behind the recomputation
+      if constexpr (S::kStatic) {
+        if constexpr (first) stage_commit(total4, wr, lds, 0, nl >= 2 ? rounds_upto<S>(nl - 2) : 0, STAGE_U);
       }
-      TR(1, 3 + l);
-      layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), true, H + sh.h_off(l) * TP,
-                    H + sh.h_off(l + 1) * TP, nullptr, false, false);
-    });
-    // the last layer's image (first use: the head of the dgrad chain) and the gy tile arrive behind the recomputation
-    if constexpr (S::kStatic) {
-      if constexpr (first) stage_commit(total4, wr, lds, 0, nl >= 2 ? rounds_upto<S>(nl - 2) : 0, STAGE_U);
     }
     tile_commit(sh.dims(nl), a.vec_gy != 0, gr, G + sh.h_off(nl) * TP);
     tile_issue(a.gy, row0 + (int64_t)gridDim.x * TS, a.N, sh.dims(nl), a.vec_gy != 0, gr);
@@ -906,7 +992,7 @@ static int fill(MlpArgs &a, const p2c_mlp_desc *d) {
   a = MlpArgs{};
   a.n_layers = d->n_layers;
   a.N = d->N;
-  a.x = d->x, a.y = d->y, a.gy = d->gy, a.partials = d->partials, a.w_image = d->w_image;
+  a.x = d->x, a.y = d->y, a.gy = d->gy, a.partials = d->partials, a.w_image = d->w_image, a.saved = d->saved;
   int rows = 0, tiles = 0, params = 0, wtot = 0;
   for (int l = 0; l <= d->n_layers; ++l) {
     if (d->dims[l] < 1 || d->dims[l] > MAXW - 1) return P2C_E_SHAPE;
@@ -974,6 +1060,7 @@ template <class S>
 static void allow_big_lds_for() {
   (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 static void allow_big_lds() {
@@ -986,17 +1073,18 @@ static void allow_big_lds() {
   done = true;
 }
 template <class S>
-static mlp_kernel_t pick_of(bool bwd, bool factors) {
+static mlp_kernel_t pick_of(bool bwd, bool factors, bool saved) {
   if (!bwd) return mlp_fwd_kernel<S>;
-  return factors ? mlp_bwd_kernel<S, true> : mlp_bwd_kernel<S, false>;
+  if (factors) return mlp_bwd_kernel<S, true>;
+  return saved ? mlp_bwd_kernel<S, false, true> : mlp_bwd_kernel<S, false>;
 }
-static mlp_kernel_t pick(const MlpArgs &a, bool bwd, bool factors = false) {
+static mlp_kernel_t pick(const MlpArgs &a, bool bwd, bool factors = false, bool saved = false) {
   if (!force_generic()) {
-    if (LinearAE156::matches(a)) return pick_of<LinearAE156>(bwd, factors);
-    if (LinearAE78::matches(a)) return pick_of<LinearAE78>(bwd, factors);
-    if (LinearAE52::matches(a)) return pick_of<LinearAE52>(bwd, factors);
+    if (LinearAE156::matches(a)) return pick_of<LinearAE156>(bwd, factors, saved);
+    if (LinearAE78::matches(a)) return pick_of<LinearAE78>(bwd, factors, saved);
+    if (LinearAE52::matches(a)) return pick_of<LinearAE52>(bwd, factors, saved);
   }
-  return pick_of<DynShape>(bwd, factors);
+  return pick_of<DynShape>(bwd, factors, saved);
 }
 
 static int max_blocks() {
@@ -1077,6 +1165,26 @@ extern "C" int64_t p2c_mlp_image_index(const p2c_mlp_desc *d, int32_t *index, in
   return n;
 }
 
+// Saved activations pay once a workgroup walks two or more sample tiles: the recomputation is ~1/3 of a tile's backward,
+// the 10 KB per tile of extra traffic each way hides behind the persistent loop's look-ahead. (With one tile per workgroup
+// the recomputation is what hides the weight-image staging, and the split weight gradient leaves its own factors.)
+// P2C_MLP_SAVE=0|1 overrides.
+static bool save_activations(const MlpArgs &a) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("P2C_MLP_SAVE");
+    mode = !e ? 0 : (atoi(e) ? 1 : 2);
+  }
+  if (a.n_layers < 2 || a.N < 1 || split_wgrad(a.N) || mode == 2) return false;
+  if (mode == 1) return true;
+  return (a.N + TS - 1) / TS >= 2 * (int64_t)n_blocks(a.N);
+}
+extern "C" int64_t p2c_mlp_saved_floats(const p2c_mlp_desc *d) {
+  MlpArgs a;
+  if (fill(a, d) || !save_activations(a)) return 0;
+  return ((a.N + TS - 1) / TS) * (int64_t)a.f_half * 16;
+}
+
 extern "C" int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *d) {
   MlpArgs a;
   if (fill(a, d)) return 0;
@@ -1090,6 +1198,7 @@ extern "C" int p2c_mlp_fwd(const p2c_mlp_desc *d, void *stream_) {
   if (rc) return rc;
   if (!a.y || !a.w_image) return P2C_E_NULL;
   if (a.N == 0) return 0;
+  if (a.saved && !save_activations(a)) a.saved = nullptr;      // same rule on both sides of the autograd edge
   const size_t lds = lds_fwd(a);
   if (lds > 160 * 1024) return P2C_E_SHAPE;
   allow_big_lds();
@@ -1124,7 +1233,8 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
                        d->fused_adamw ? coefs : nullptr);
     blocks = WGRAD_KS;                                                   // what the reduction adds up
   } else {
-    hipLaunchKernelGGL(pick(a, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+    const bool saved = a.saved && save_activations(a);
+    hipLaunchKernelGGL(pick(a, true, false, saved), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
   }
   const dim3 rgrid(a.n_tiles_w * (64 / RL)), rblock(RL * RG), sgrid((a.n_tiles_w * 64 + 255) / 256);
   if (d->fused_adamw) {

@@ -522,9 +522,17 @@ class FusedMLPFunction(torch.autograd.Function):
         elif image.numel() != n_image or image.device != x.device or image.dtype != torch.float32:
             raise RuntimeError('packed weight image of the wrong size / device')
         desc.y, desc.w_image, desc.skip_pack = y.data_ptr(), image.data_ptr(), int(bool(skip_pack))
+        # many sample tiles per workgroup: the forward leaves its hidden activations for the backward (0 = recompute)
+        saved = None
+        if any(ctx.needs_input_grad):           # (grad mode is off inside Function.forward: ask the autograd context)
+            n_saved = lib.p2c_mlp_saved_floats(ctypes.byref(desc))
+            if n_saved > 0:
+                saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
+                desc.saved = saved.data_ptr()
         with torch.cuda.device(x.device):
             _lib.check(lib.p2c_mlp_fwd(ctypes.byref(desc), _stream()), 'p2c_mlp_fwd')
         ctx.save_for_backward(x, image, *weights, *biases)
+        ctx.saved_acts = saved
         ctx.n_layers, ctx.sinks = n_layers, sinks
         ctx.fused_opt = fused_opt if sinks is not None else None
         return y
@@ -538,6 +546,8 @@ class FusedMLPFunction(torch.autograd.Function):
         gy = _require_device(gy, 'grad')
         desc = _mlp_desc(x, weights, biases)
         desc.gy, desc.w_image = gy.data_ptr(), image.data_ptr()
+        if ctx.saved_acts is not None:
+            desc.saved = ctx.saved_acts.data_ptr()
         if ctx.sinks is not None:
             gws, gbs = ctx.sinks[0::2], ctx.sinks[1::2]
         else:
