@@ -71,6 +71,7 @@ struct MlpArgs {
   // saved activations (many sample tiles per workgroup): the forward leaves H_1..H_{L-1} of every sample tile in the same
   // transposed layout (f_half rows of 16 samples), the backward loads them instead of recomputing
   float *saved;
+  int32_t fw_rows_a, fw_rows_b;    // wave-per-tile forward: rows of the two ping-pong activation buffers of a wave
 };
 
 __host__ __device__ constexpr int pad16(int n) { return (n + 15) & ~15; }
@@ -347,7 +348,7 @@ __device__ __forceinline__ void init_rows(float *area, int row0, int row1, int o
 __device__ __forceinline__ int k_rows(int n_in) { return ((((n_in + 1 + 3) >> 2) + 3) & ~3) * 4; }   // rows the k loop reads
 
 // out^T[n][s] = act( sum_k Waug[n][k] in^T_aug[k][s] ) for NT output tiles of this wave (nt0, nt0 + WAVES)
-template <int NT>
+template <int NT, int STRIDE = WAVES>
 __device__ __forceinline__ void layer_forward_nt(const Lane &L, const float *wl, int ld, int ksteps, int nt0, int n_out,
                                                  bool relu, const float *in, float *out, float *y_row, bool row_ok,
                                                  bool vec_y) {
@@ -356,7 +357,7 @@ __device__ __forceinline__ void layer_forward_nt(const Lane &L, const float *wl,
 #pragma unroll
   for (int h = 0; h < NT; ++h) {
     acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    ap[h] = wl + ((nt0 + h * WAVES) * 16 + L.c) * ld + L.g;
+    ap[h] = wl + ((nt0 + h * STRIDE) * 16 + L.c) * ld + L.g;
   }
   const float *bp = in + L.g * TP + L.c;
   // Ping-pong software pipeline: the operands of k-group s+1 are in flight while the MFMAs of group s run (ksteps is a
@@ -393,7 +394,7 @@ __device__ __forceinline__ void layer_forward_nt(const Lane &L, const float *wl,
 #pragma unroll
   for (int h = 0; h < NT; ++h) {
     f32x4 v = acc[h];
-    const int nb = (nt0 + h * WAVES) * 16 + 4 * L.g;   // first of this lane's 4 output rows
+    const int nb = (nt0 + h * STRIDE) * 16 + 4 * L.g;   // first of this lane's 4 output rows
     if (relu) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -612,6 +613,103 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
   if ((int64_t)blockIdx.x < n_tiles) one_tile(blockIdx.x, std::true_type{});
   for (int64_t tile = (int64_t)blockIdx.x + gridDim.x; tile < n_tiles; tile += gridDim.x) one_tile(tile, std::false_type{});
   TR(0, 39);
+}
+
+// ---- forward, many sample tiles (wave-per-tile) -----------------------------------------------------------------------
+// The cooperative kernel above splits ONE 16-sample tile over eight waves: right for a handful of tiles per CU, where the
+// dependent MFMA chain of a tile is the critical path, but it spends a barrier per layer and leaves most waves idle in
+// the narrow layers (fp32 MFMA utilisation ~35 %). With many tiles per CU the throughput form is the opposite one: every
+// wave walks its OWN tile through all layers -- no workgroup barrier at all after the weight image is staged, activations
+// ping-pong between two wave-private LDS buffers, two output tiles of a layer in flight per wave so that the MFMA pipe
+// issues back to back. Four waves per workgroup: 84 KB image + 4 x 12 KB of activations (six waves fit the LDS but run slower).
+// fp32 MFMA utilisation 35 % -> 50 % at 131 072 frames; what is left is the latency at the head of every output-tile pair with
+// one wave per SIMD.
+#ifndef P2C_FW_WAVES
+#define P2C_FW_WAVES 4
+#endif
+constexpr int FW_WAVES = P2C_FW_WAVES;
+constexpr int FW_XU = (TS * (MAXW - 1) + 63) / 64;   // x-tile floats per lane (static shapes use dims(0) * 16 / 64 of them)
+template <class S>
+__global__ __launch_bounds__(64 * FW_WAVES) void mlp_fwd_wave_kernel(const MlpArgs a) {
+  extern __shared__ float lds[];
+  const S sh(a);
+  Lane L;
+  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4, L.wave = 0;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nl = sh.n_layers(), n0 = sh.dims(0);
+  {
+    f32x4 *dst = reinterpret_cast<f32x4 *>(lds);
+    const f32x4 *src = reinterpret_cast<const f32x4 *>(a.w_image);
+    const int total4 = sh.w_total() >> 2;
+    constexpr int NT4 = 64 * FW_WAVES, BATCH = 8;             // eight 16-byte loads of a thread in flight per round
+    for (int i0 = threadIdx.x; i0 < total4; i0 += NT4 * BATCH) {
+      f32x4 v[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) v[u] = (i0 + u * NT4 < total4) ? src[i0 + u * NT4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u)
+        if (i0 + u * NT4 < total4) dst[i0 + u * NT4] = v[u];
+    }
+  }
+  float *bufA = lds + sh.w_total() + wave * (a.fw_rows_a + a.fw_rows_b) * TP, *bufB = bufA + a.fw_rows_a * TP;
+  for (int i = L.lane; i < (a.fw_rows_a + a.fw_rows_b) * TP; i += 64) bufA[i] = 0.f;
+  __syncthreads();                                           // the only workgroup barrier: the image is in place
+  const int64_t n_tiles = (a.N + TS - 1) / TS;
+  const int per = TS * n0;                                   // floats of one x tile
+  const int64_t tstep = (int64_t)gridDim.x * FW_WAVES;
+  // the next tile's x rows wait in registers while this one is computed (one wave per SIMD: nothing else hides HBM latency)
+  float xr[FW_XU];
+  auto x_issue = [&](int64_t tile) {
+    const int64_t row0 = tile * TS, left = a.N - row0;
+    const int valid = left <= 0 ? 0 : (int)(left < TS ? left : TS) * n0;
+    const float *xp = a.x + row0 * n0;
+#pragma unroll
+    for (int u = 0; u < FW_XU; ++u) {
+      const int e = L.lane + 64 * u;
+      if (64 * u < per) xr[u] = e < valid ? xp[e] : 0.f;
+    }
+  };
+  x_issue((int64_t)blockIdx.x * FW_WAVES + wave);
+  for (int64_t tile = (int64_t)blockIdx.x * FW_WAVES + wave; tile < n_tiles; tile += tstep) {
+    const int64_t row0 = tile * TS, row = row0 + L.c;
+    const bool row_ok = row < a.N;
+#pragma unroll
+    for (int u = 0; u < FW_XU; ++u) {                         // transposed LDS write of the x tile
+      const int e = L.lane + 64 * u;
+      if (64 * u < per && e < per) {
+        const int sidx = e / n0, k = e - sidx * n0;
+        bufA[k * TP + sidx] = xr[u];
+      }
+    }
+    x_issue(tile + tstep);
+    for (int i = n0 * TP + L.lane; i < k_rows(n0) * TP; i += 64) bufA[i] = (i / TP == n0) ? 1.f : 0.f;   // ones row, k rounding
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for_layers(sh, 0, nl, [&](int l) {
+      const bool last = (l == nl - 1);
+      const float *in = (l & 1) ? bufB : bufA;
+      float *out = (l & 1) ? bufA : bufB;
+      const int n_in = sh.dims(l), n_out = sh.dims(l + 1);
+      const int ksteps = (((n_in + 1 + 3) >> 2) + 3) & ~3, ntiles = (n_out + 16) >> 4;
+      const float *wl = lds + sh.w_off(l);
+      float *y_row = last ? a.y + row * n_out : nullptr;
+      for (int nt = 0; nt < ntiles; nt += 2) {
+        if (nt + 1 < ntiles)
+          layer_forward_nt<2, 1>(L, wl, sh.ld(l), ksteps, nt, n_out, !last, in, last ? nullptr : out, y_row, row_ok, a.vec_y != 0);
+        else
+          layer_forward_nt<1, 1>(L, wl, sh.ld(l), ksteps, nt, n_out, !last, in, last ? nullptr : out, y_row, row_ok, a.vec_y != 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (!last && a.saved) {                                // saved activations of this tile (see acts_store)
+        f32x4 *hd = reinterpret_cast<f32x4 *>(a.saved) + ((size_t)tile * a.f_half + a.f_off[l + 1]) * 4;
+        for (int i = L.lane; i < n_out * 4; i += 64) {
+          const int o = (i >> 2) * TP + (i & 3) * 4;
+          hd[i] = (f32x4){out[o], out[o + 1], out[o + 2], out[o + 3]};
+        }
+      }
+    });
+  }
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
@@ -1017,6 +1115,10 @@ static int fill(MlpArgs &a, const p2c_mlp_desc *d) {
     a.f_half = r;
   }
   a.f_rows = 2 * a.f_half;
+  for (int l = 0; l < d->n_layers; ++l) {            // wave-per-tile forward: H_l lives in buffer l & 1
+    int32_t &r = (l & 1) ? a.fw_rows_b : a.fw_rows_a;
+    if (act_rows_of(a.dims[l]) > r) r = act_rows_of(a.dims[l]);
+  }
   a.n_tiles_w = tiles;
   a.n_params = params;
   a.w_total = (wtot + 3) & ~3;
@@ -1071,6 +1173,40 @@ static void allow_big_lds() {
   allow_big_lds_for<LinearAE78>();
   allow_big_lds_for<LinearAE52>();
   done = true;
+}
+static int max_blocks();
+static size_t lds_fwd_wave(const MlpArgs &a) {
+  return ((size_t)a.w_total + (size_t)FW_WAVES * (a.fw_rows_a + a.fw_rows_b) * TP) * sizeof(float);
+}
+// Forward strategy: wave-per-tile once every wave of the grid has a tile of its own, i.e. four sample tiles per CU (measured,
+// forward at N = 8 192 / 16 384 / 32 768 / 65 536 / 131 072 frames: cooperative 13.8 / 21.0 / 34.4 / 58.8 / 108 us,
+// wave-per-tile 17.2 / 19.2 / 27.7 / 42.8 / 75 us). P2C_MLP_FWD=wave|coop overrides.
+static bool wave_forward(const MlpArgs &a) {
+  static int mode = -1;
+  if (mode < 0) {
+    const char *e = getenv("P2C_MLP_FWD");
+    mode = !e ? 0 : (e[0] == 'w' ? 1 : 2);
+  }
+  if (a.N < 1 || lds_fwd_wave(a) > 160 * 1024 || mode == 2) return false;
+  if (mode == 1) return true;
+  return (a.N + TS - 1) / TS >= (int64_t)FW_WAVES * max_blocks();
+}
+template <class S>
+static mlp_kernel_t pick_wave_of() {
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void *)mlp_fwd_wave_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done = true;
+  }
+  return mlp_fwd_wave_kernel<S>;
+}
+static mlp_kernel_t pick_wave(const MlpArgs &a) {
+  if (!force_generic()) {
+    if (LinearAE156::matches(a)) return pick_wave_of<LinearAE156>();
+    if (LinearAE78::matches(a)) return pick_wave_of<LinearAE78>();
+    if (LinearAE52::matches(a)) return pick_wave_of<LinearAE52>();
+  }
+  return pick_wave_of<DynShape>();
 }
 template <class S>
 static mlp_kernel_t pick_of(bool bwd, bool factors, bool saved) {
@@ -1204,7 +1340,14 @@ extern "C" int p2c_mlp_fwd(const p2c_mlp_desc *d, void *stream_) {
   allow_big_lds();
   if (!d->skip_pack)
     hipLaunchKernelGGL(mlp_pack_kernel, dim3((a.w_total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
-  hipLaunchKernelGGL(pick(a, false), dim3(n_blocks(a.N)), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+  if (wave_forward(a)) {
+    const int64_t groups = ((a.N + TS - 1) / TS + FW_WAVES - 1) / FW_WAVES;
+    const int cap = max_blocks();
+    hipLaunchKernelGGL(pick_wave(a), dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * FW_WAVES), lds_fwd_wave(a),
+                       (hipStream_t)stream_, a);
+  } else {
+    hipLaunchKernelGGL(pick(a, false), dim3(n_blocks(a.N)), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

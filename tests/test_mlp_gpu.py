@@ -224,3 +224,38 @@ def test_every_mlp_test_also_passes_with_saved_activations_forced():
                           '-p', 'no:cacheprovider', '-k', 'not forced and not bit_for_bit'], env=env, cwd=root,
                          capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def test_every_mlp_test_also_passes_with_the_wave_per_tile_forward_forced():
+    """P2C_MLP_FWD=wave at every batch size (ragged tails, one-tile batches, generic shapes, saved activations), child pytest."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, P2C_MLP_FWD='wave', P2C_MLP_SAVE='1', P2C_MLP_WGRAD='fused')
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_mlp_gpu.py'), '-q', '-x', '-m', 'gpu',
+                          '-p', 'no:cacheprovider', '-k', 'not forced and not bit_for_bit'], env=env, cwd=root,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def test_wave_per_tile_forward_equals_the_cooperative_forward_bit_for_bit():
+    """Same MFMA chains in the same k order, only distributed differently over waves: outputs and (through the saved
+    activations) gradients must be identical."""
+    import os, subprocess, sys, tempfile
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from pedestrians_video_2_carla_amd import ops\n"
+        "d = torch.device('cuda:0'); torch.manual_seed(5)\n"
+        "dims = [52, 26, 13, 6, 39, 78, 156]\n"
+        "Ws = [(torch.randn(o, i, device=d) * 0.2).requires_grad_(True) for i, o in zip(dims[:-1], dims[1:])]\n"
+        "bs = [(torch.randn(o, device=d) * 0.2).requires_grad_(True) for o in dims[1:]]\n"
+        "x = torch.randn(9001, 52, device=d)\n"
+        "y = ops.fused_mlp(x, Ws, bs); y.square().sum().backward()\n"
+        "out = torch.cat([y.detach().reshape(-1)] + [p.grad.reshape(-1) for p in Ws + bs])\n"
+        "torch.save(out.cpu(), sys.argv[1])\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for fwd in ('wave', 'coop'):
+        with tempfile.NamedTemporaryFile(suffix='.pt') as f:
+            subprocess.run([sys.executable, '-c', code, f.name], check=True, env=dict(os.environ, P2C_MLP_FWD=fwd), timeout=300)
+            outs.append(torch.load(f.name))
+    assert torch.equal(outs[0], outs[1])
