@@ -21,6 +21,12 @@
 //   * backward recomputes the activations (no HBM round trip), runs the dgrad chain, then the waves split the 16x16
 //     tiles of dW_aug = G^T [H | 1] and keep them in MFMA accumulators across the persistent tile loop; per-workgroup
 //     partials are reduced in fixed order (bitwise reproducible, no atomics).
+// Regime-specific variants of the same arithmetic (all bit-identical where they overlap, selected by the row count):
+//   * about one sample tile per CU: split weight gradient -- the backward leaves factors, mlp_wgrad_kernel contracts them
+//     with an XCD-local K split, mlp_reduce_small_kernel adds the 8 partials and applies AdamW (split_wgrad());
+//   * two or more tiles per workgroup: the forward saves its hidden activations, the backward loads them instead of
+//     recomputing (save_activations());
+//   * four or more tiles per CU: wave-per-tile forward without workgroup barriers (mlp_fwd_wave_kernel, wave_forward()).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <stdint.h>
