@@ -308,6 +308,7 @@ def main():
                                f'{args.batch_size}/GPU (BASELINE.json metric config; configs[1]/[3] = --batch-size 1024)',
                    'global_batch': global_batch, 'per_gpu_batch': args.batch_size, 'parallelism': f'dp{world}',
                    'hip_graph': not args.no_graph, 'lean_train_outputs': not args.full_outputs,
+                   'deferred_loss_finalize': os.environ.get('P2C_DEFER_FINALIZE', '1') != '0',
                    'grad_allreduce_bytes': trainer.flat.nbytes(), 'final_loss': final_loss},
     }
     traffic = load_traffic()

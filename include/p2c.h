@@ -102,6 +102,10 @@ typedef struct p2c_pose_head_desc {
   float *out_absolute_pose_rot; /* (B,T,26,3,3) */
   float *out_world_loc;         /* (B,T,3) */
   float *out_world_rot;         /* (B,T,3,3) */
+  /* 1 = the caller guarantees that p2c_pose_head_bwd follows with the same desc before anyone reads `losses` / `loss_sums`
+   * (a captured train step): for the time-parallel 6-D kernels the forward then skips the one-workgroup finalize launch
+   * and the backward kernel finishes the loss reduction itself (same values to fp32 rounding). Ignored elsewhere. */
+  int32_t defer_loss_finalize;
 } p2c_pose_head_desc;
 
 /* library / build identification: "p2c-hip <version> gfx950" */

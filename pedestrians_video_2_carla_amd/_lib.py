@@ -34,7 +34,7 @@ class PoseHeadDesc(ctypes.Structure):
         ('out_pose_changes', _f32p), ('out_projection_2d', _f32p), ('out_projection_2d_transformed', _f32p),
         ('out_shift', _f32p), ('out_scale', _f32p), ('out_relative_pose_loc', _f32p),
         ('out_relative_pose_rot', _f32p), ('out_absolute_pose_loc', _f32p), ('out_absolute_pose_rot', _f32p),
-        ('out_world_loc', _f32p), ('out_world_rot', _f32p),
+        ('out_world_loc', _f32p), ('out_world_rot', _f32p), ('defer_loss_finalize', _i32),
     ]
 
 

@@ -541,6 +541,14 @@ __device__ __forceinline__ void world_store(const p2c_pose_head_desc &d, const L
 struct GradLosses {
   const float *p[3];
 };
+__device__ __forceinline__ void loss_coefs_n(const p2c_pose_head_desc &d, const GradLosses &gl, float n2, float n3,
+                                             float &coef2, float &coef3) {
+  if (!gl.p[0] && !gl.p[1] && !gl.p[2]) return;
+  const float u0 = gl.p[0] ? *gl.p[0] : 0.f, u1 = gl.p[1] ? *gl.p[1] : 0.f, u2 = gl.p[2] ? *gl.p[2] : 0.f;
+  float g2 = u0 + u2, g3 = u1 + u2;
+  coef2 = (d.gt2d && n2 > 0.f) ? g2 / n2 : 0.f;
+  coef3 = (d.gt3d && n3 > 0.f) ? 2.f * g3 / n3 : 0.f;
+}
 __device__ __forceinline__ void loss_coefs(const p2c_pose_head_desc &d, const GradLosses &gl, float &coef2, float &coef3) {
   if (!gl.p[0] && !gl.p[1] && !gl.p[2]) return;
   float n2 = d.loss_sums[1], n3 = d.loss_sums[3];
@@ -1055,6 +1063,50 @@ __global__ __launch_bounds__(1024) void pose_head_rot_fwd_tp(const p2c_pose_head
   }
 }
 
+// Deferred loss finalize (p2c_pose_head_desc.defer_loss_finalize, time-parallel kernels: one partial per clip).
+// Every workgroup of the backward needs the number of unmasked 2-D pairs: a sum of small integers held in floats -- exact
+// in any order. Workgroup 0 also does what loss_finalize does (fp64 accumulators, fixed order) and publishes the losses.
+__device__ __forceinline__ float n3_elems(const p2c_pose_head_desc &d) {
+  return (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
+}
+__device__ __forceinline__ float deferred_count(const p2c_pose_head_desc &d, float *sh) {   // sh: >= 16 floats
+  float c = 0.f;
+  for (int i = threadIdx.x; i < d.B; i += blockDim.x) c += d.partials[i * 4 + 1];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  float n2 = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) n2 += sh[w];
+  return n2;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ void deferred_finalize(const p2c_pose_head_desc &d, double *sh) {   // sh: >= 48 doubles
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < d.B; i += blockDim.x) {
+    a += (double)d.partials[i * 4 + 0];
+    b += (double)d.partials[i * 4 + 1];
+    c += (double)d.partials[i * 4 + 2];
+  }
+  a = wave_sum_f64(a), b = wave_sum_f64(b), c = wave_sum_f64(c);
+  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[wave] = a, sh[16 + wave] = b, sh[32 + wave] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s2 = 0.0, n2 = 0.0, s3 = 0.0;
+    for (int w = 0; w < n_waves; ++w) s2 += sh[w], n2 += sh[16 + w], s3 += sh[32 + w];
+    const float n3 = n3_elems(d);
+    d.loss_sums[0] = (float)s2, d.loss_sums[1] = (float)n2, d.loss_sums[2] = (float)s3, d.loss_sums[3] = n3;
+    const float nan = __builtin_nanf("");
+    const float l2 = d.gt2d ? (float)(s2 / (2.0 * n2)) : nan, l3 = d.gt3d ? (float)(s3 / (double)n3) : nan;
+    d.losses[0] = l2, d.losses[1] = l3, d.losses[2] = l2 + l3;
+  }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_pose_head_desc d, const GradLosses grad_losses,
                                                                      const float *g_abs_ext, const float *g_projt_ext,
@@ -1080,11 +1132,17 @@ __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_p
     }
   }
   float coef2 = 0.f, coef3 = 0.f;
-  loss_coefs(d, grad_losses, coef2, coef3);
-
   FrameIn<6> cur;
   FramePtrs ptrs = frame_ptrs<6>(d, L, t);
   load_frame<6, 1>(L, ptrs, cur);
+  if (d.defer_loss_finalize) {          // the forward skipped loss_finalize: count from the per-clip partials
+    __shared__ float cnt_sh[16];
+    __shared__ double fin_sh[48];
+    loss_coefs_n(d, grad_losses, deferred_count(d, cnt_sh), n3_elems(d), coef2, coef3);
+    if (blockIdx.x == 0) deferred_finalize(d, fin_sh);
+  } else {
+    loss_coefs(d, grad_losses, coef2, coef3);
+  }
   SixD s;
   const M3 c = rot6d_fwd(cur.y, s);
   M3 R = c;
@@ -1398,6 +1456,8 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
 #undef P2C_LAUNCH_ROT_FWD
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  if (d.defer_loss_finalize && tp && !mat && !pkd && (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D))
+    return 0;                            // p2c_pose_head_bwd's time-parallel kernel finishes the reduction
   int n_waves = tp ? d.B : (int)((pkd ? pk_grid.x : grid.x) * (kBlock / 64));
   float n3 = (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
   hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, n_waves, n3,
@@ -1412,7 +1472,10 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
   int rc = validate(desc);
   if (rc) return rc;
   if (!grad_y) return P2C_E_NULL;
-  const p2c_pose_head_desc d = *desc;
+  p2c_pose_head_desc d = *desc;
+  // the forward skipped its finalize launch only for the lean time-parallel 6-D kernels (same rule as p2c_pose_head_fwd)
+  if (!(use_tp(d) && !use_pk(d) && (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D)))
+    d.defer_loss_finalize = 0;
   hipStream_t stream = (hipStream_t)stream_;
   dim3 grid(grid_for(d.B)), block(kBlock);
   GradLosses grad_losses{{nullptr, nullptr, nullptr}};

@@ -184,6 +184,25 @@ class PoseLosses:
     loc_2d_3d = property(lambda self: self.scalars[2])
 
 
+_DEFER_LOSS_FINALIZE = False
+
+
+class deferred_loss_finalize:
+    """Context manager for a train step whose backward is GUARANTEED to follow the forward before anyone reads the loss
+    values (the trainer's captured step): the lean pose-head forward skips its one-workgroup finalize launch and the
+    backward kernel finishes the loss reduction (p2c_pose_head_desc.defer_loss_finalize). Outside of it nothing changes."""
+
+    def __enter__(self):
+        global _DEFER_LOSS_FINALIZE
+        self._prev, _DEFER_LOSS_FINALIZE = _DEFER_LOSS_FINALIZE, True
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER_LOSS_FINALIZE
+        _DEFER_LOSS_FINALIZE = self._prev
+        return False
+
+
 class PoseHeadFunction(torch.autograd.Function):
     """(losses (3,), loc_2d, loc_3d, loc_2d_3d [, materialised tensors]) = f(model output y)."""
 
@@ -213,6 +232,10 @@ class PoseHeadFunction(torch.autograd.Function):
             full = torch.zeros if (k.startswith('projection_2d_') and (t0, t1) != (0, T)) else torch.empty
             outs[k] = full((B, T) + _OUT_SHAPES[k], **f32)
         desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, outs)
+        # lean training forward inside deferred_loss_finalize(): the backward publishes the loss values
+        ctx.deferred = bool(_DEFER_LOSS_FINALIZE and not want and ctx.needs_input_grad[0]
+                            and spec.kind in ('pose_changes_6d', 'relative_rot_6d'))
+        desc.defer_loss_finalize = int(ctx.deferred)
         with torch.cuda.device(dev):
             _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), _stream()), 'p2c_pose_head_fwd')
         ctx.spec, ctx.want = spec, want
@@ -256,6 +279,7 @@ class PoseHeadFunction(torch.autograd.Function):
         else:
             gl = _lib.grad_loss_pointers(*[_ptr(g) for g in scalars])
         desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, {})
+        desc.defer_loss_finalize = int(ctx.deferred)
         grad_y = torch.empty_like(y)
         with torch.cuda.device(y.device):
             _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), gl, _ptr(g_abs), _ptr(g_projt), _ptr(g_rot),

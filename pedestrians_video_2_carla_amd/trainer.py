@@ -9,6 +9,7 @@ Two execution modes:
     microseconds each) is exactly what hipGraphs are for. With more than one rank the gradient all-reduce stays outside
     the graphs (capture A: zero-grad + forward + backward; eager RCCL all-reduce; capture B: optimizer).
 """
+import contextlib
 import os
 from typing import Dict, Iterable, List, Optional
 
@@ -113,12 +114,19 @@ class Trainer:
 
     def _forward_backward(self, flow, batch, batch_idx):
         self._zero_grad()
-        flow.on_train_batch_start(batch, batch_idx)
-        out = flow.training_step(batch, batch_idx)
-        loss = out['loss']
-        if self._unit is None or self._unit.shape != loss.shape or self._unit.device != loss.device:
-            self._unit = torch.ones_like(loss)       # root gradient, made once (backward() would fill one per step)
-        loss.backward(gradient=self._unit)
+        # forward and backward happen back to back in here and nothing reads a loss VALUE in between (the reference's
+        # per-loss isnan check is off unless strict_nan_check): the pose head may leave the last stage of its loss
+        # reduction to the backward kernel -- one launch less per step (P2C_DEFER_FINALIZE=0 keeps the launch)
+        defer = (batch[0].is_cuda and not getattr(flow, 'strict_nan_check', False)
+                 and os.environ.get('P2C_DEFER_FINALIZE', '1') != '0')
+        from pedestrians_video_2_carla_amd import ops
+        with (ops.deferred_loss_finalize() if defer else contextlib.nullcontext()):
+            flow.on_train_batch_start(batch, batch_idx)
+            out = flow.training_step(batch, batch_idx)
+            loss = out['loss']
+            if self._unit is None or self._unit.shape != loss.shape or self._unit.device != loss.device:
+                self._unit = torch.ones_like(loss)   # root gradient, made once (backward() would fill one per step)
+            loss.backward(gradient=self._unit)
         return loss.detach()
 
     def _optimizer_step(self):

@@ -331,3 +331,32 @@ def test_rotation_gradient_is_refused_for_matrix_kinds():
     _, outs = ops.pose_head(y, ops.PoseHeadSpec(kind='pose_changes'), torch.zeros(2, dtype=torch.int32, device=d),
                             want=('absolute_pose_rot',))
     assert not outs['absolute_pose_rot'].requires_grad          # no tangent-space path for matrix inputs: not differentiable
+
+
+@pytest.mark.parametrize('kind', ['pose_changes_6d', 'relative_rot_6d'])
+@pytest.mark.parametrize('B,T', [(1, 1), (37, 7), (256, 16), (300, 30)])
+def test_deferred_loss_finalize_equals_the_separate_launch(kind, B, T):
+    """ops.deferred_loss_finalize(): the lean forward skips loss_finalize, the time-parallel backward kernel counts the
+    unmasked pairs itself (exact: small integers) and workgroup 0 publishes the losses. grad_y must be bit-identical, the
+    loss values equal to fp32 rounding (fp64 accumulation in both, different summation trees); with materialised outputs
+    requested the flag must not apply."""
+    from pedestrians_video_2_carla_amd import ops
+    y, st, gt2, gt3, _ = _random_case(B, T, seed=B + T)
+    spec = ops.PoseHeadSpec(kind=kind)
+    ref_l, _, ref_g = run_hip(y, spec, st, gt2d=gt2, gt3d=gt3, want=())
+    ref_vec = ref_l.vector.clone()
+    d = dev()
+    mat_l, _ = ops.pose_head(y.float().to(d), spec, st.to(d).int(), None, None, gt2.to(d), gt3.to(d), ('projection_2d_transformed',))
+    mat_vec = mat_l.vector.clone()
+    with ops.deferred_loss_finalize():
+        yd = y.float().to(d).requires_grad_(True)
+        losses, _ = ops.pose_head(yd, spec, st.to(d).int(), None, None, gt2.to(d), gt3.to(d), ())
+        losses[2].backward()
+        torch.cuda.synchronize()
+        got_vec, got_g = losses.vector.clone(), yd.grad.clone()
+        # materialising call inside the context: finalize in the forward as usual, values valid right away
+        l2, outs = ops.pose_head(y.float().to(d), spec, st.to(d).int(), None, None, gt2.to(d), gt3.to(d),
+                                 ('projection_2d_transformed',))
+        assert torch.equal(l2.vector, mat_vec)
+    assert torch.equal(got_g, ref_g)
+    torch.testing.assert_close(got_vec, ref_vec, rtol=1e-6, atol=0)
