@@ -104,7 +104,9 @@ typedef struct p2c_pose_head_desc {
   float *out_world_rot;         /* (B,T,3,3) */
   /* 1 = the caller guarantees that p2c_pose_head_bwd follows with the same desc before anyone reads `losses` / `loss_sums`
    * (a captured train step): for the time-parallel 6-D kernels the forward then skips the one-workgroup finalize launch
-   * and the backward kernel finishes the loss reduction itself (same values to fp32 rounding). Ignored elsewhere. */
+   * and the backward kernel finishes the loss reduction itself (same values to fp32 rounding). 2 = same guarantee, and
+   * the forward call only counts the unmasked target pairs: the backward kernel, which recomputes the pose head anyway,
+   * produces the losses as well as grad_y (+ the finalize launch). Ignored for every other kernel family. */
   int32_t defer_loss_finalize;
 } p2c_pose_head_desc;
 

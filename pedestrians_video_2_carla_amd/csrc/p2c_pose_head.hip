@@ -296,13 +296,14 @@ struct HeadAcc {
   float sum2, cnt2, sum3;
 };
 
-enum { MODE_FWD = 0, MODE_FWD_MATERIALIZE = 1, MODE_BWD = 2 };
+enum { MODE_FWD = 0, MODE_FWD_MATERIALIZE = 1, MODE_BWD = 2, MODE_TRAIN = 3 };   // TRAIN = BWD that also sums the losses
 
 template <int MODE>
 __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const LaneCtx &L, int t, V3 x, const World &W,
                                          HeadAcc &acc, float coef2, float coef3, const float *g_abs_ext,
                                          const float *g_projt_ext, const float *gt2v, const float *gt3v) {
-  constexpr bool BWD = (MODE == MODE_BWD);
+  constexpr bool BWD = (MODE == MODE_BWD || MODE == MODE_TRAIN);
+  constexpr bool SUMS = !BWD || MODE == MODE_TRAIN;
   constexpr bool MAT = (MODE == MODE_FWD_MATERIALIZE);
   const bool in_slice = (t >= d.t0) && (t < d.t1);
   const size_t frame = (size_t)L.clip * d.T + t;
@@ -413,10 +414,11 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
       bool m = !d.mask_missing_joints || L.never_masked || ((g0 != 0.f) && (g1 != 0.f));  // tensors.py:29-40
       if (m) {
         float e0 = nu - g0, e1 = nv - g1;
-        if (!BWD) {
+        if (SUMS) {
           acc.sum2 += fmaf(e0, e0, e1 * e1);
           acc.cnt2 += 1.f;
-        } else {
+        }
+        if (BWD) {
           dnu = coef2 * e0;
           dnv = coef2 * e1;
         }
@@ -424,10 +426,8 @@ __device__ __forceinline__ V3 frame_head(const p2c_pose_head_desc &d, const Lane
     }
     if (L.has3) {
       float e0 = x.x - gt3v[0], e1 = x.y - gt3v[1], e2 = x.z - gt3v[2];
-      if (!BWD)
-        acc.sum3 += fmaf(e0, e0, fmaf(e1, e1, e2 * e2));
-      else
-        gx = v3(coef3 * e0, coef3 * e1, coef3 * e2);
+      if (SUMS) acc.sum3 += fmaf(e0, e0, fmaf(e1, e1, e2 * e2));
+      if (BWD) gx = v3(coef3 * e0, coef3 * e1, coef3 * e2);
     }
   }
   if (!BWD) return gx;
@@ -1063,15 +1063,37 @@ __global__ __launch_bounds__(1024) void pose_head_rot_fwd_tp(const p2c_pose_head
   }
 }
 
+// defer_loss_finalize == 2 ("train"): the forward call does not run the pose head at all -- the backward kernel recomputes
+// it anyway -- but only counts, per clip, the gt pairs the 2-D loss will not mask (a property of the targets alone:
+// utils/tensors.py:29-40) into slot 3 of the clip's partial; the backward kernel then computes losses AND gradients.
+__global__ __launch_bounds__(1024) void pose_head_count_tp(const p2c_pose_head_desc d) {
+  __shared__ float sh[16];
+  int t;
+  const LaneCtx L = make_lane_tp(d, t);
+  float c = 0.f;
+  if (t >= d.t0 && t < d.t1 && L.has2) {
+    const float *g = d.gt2d + (((size_t)L.clip * d.T + t) * d.gt2d_joints + L.gm2) * d.gt2d_channels;
+    c = (!d.mask_missing_joints || L.never_masked || ((g[0] != 0.f) && (g[1] != 0.f))) ? 1.f : 0.f;
+  }
+  c = wave_sum(c);
+  if (L.lane == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float n = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) n += sh[w];
+    d.partials[(size_t)L.clip * 4 + 3] = n;
+  }
+}
+
 // Deferred loss finalize (p2c_pose_head_desc.defer_loss_finalize, time-parallel kernels: one partial per clip).
 // Every workgroup of the backward needs the number of unmasked 2-D pairs: a sum of small integers held in floats -- exact
 // in any order. Workgroup 0 also does what loss_finalize does (fp64 accumulators, fixed order) and publishes the losses.
 __device__ __forceinline__ float n3_elems(const p2c_pose_head_desc &d) {
   return (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
 }
-__device__ __forceinline__ float deferred_count(const p2c_pose_head_desc &d, float *sh) {   // sh: >= 16 floats
+__device__ __forceinline__ float deferred_count(const p2c_pose_head_desc &d, float *sh, int slot = 1) {   // sh: >= 16 floats
   float c = 0.f;
-  for (int i = threadIdx.x; i < d.B; i += blockDim.x) c += d.partials[i * 4 + 1];
+  for (int i = threadIdx.x; i < d.B; i += blockDim.x) c += d.partials[i * 4 + slot];
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
@@ -1107,7 +1129,7 @@ __device__ __forceinline__ void deferred_finalize(const p2c_pose_head_desc &d, d
   }
 }
 
-template <int KIND>
+template <int KIND, bool TRAIN = false>
 __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_pose_head_desc d, const GradLosses grad_losses,
                                                                      const float *g_abs_ext, const float *g_projt_ext,
                                                                      const float *g_rot_ext, float *grad_y) {
@@ -1135,8 +1157,10 @@ __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_p
   FrameIn<6> cur;
   FramePtrs ptrs = frame_ptrs<6>(d, L, t);
   load_frame<6, 1>(L, ptrs, cur);
-  if (d.defer_loss_finalize) {          // the forward skipped loss_finalize: count from the per-clip partials
-    __shared__ float cnt_sh[16];
+  __shared__ float cnt_sh[16];
+  if (TRAIN) {                          // the forward only counted the unmasked pairs (slot 3 of every clip's partial)
+    loss_coefs_n(d, grad_losses, deferred_count(d, cnt_sh, 3), n3_elems(d), coef2, coef3);
+  } else if (d.defer_loss_finalize) {   // the forward skipped loss_finalize: count from the per-clip partials
     __shared__ double fin_sh[48];
     loss_coefs_n(d, grad_losses, deferred_count(d, cnt_sh), n3_elems(d), coef2, coef3);
     if (blockIdx.x == 0) deferred_finalize(d, fin_sh);
@@ -1152,7 +1176,19 @@ __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_p
   fk_doubling(L, A, x);
   const World W = world_at(d, L, t);
   HeadAcc acc{0.f, 0.f, 0.f};
-  V3 F = frame_head<MODE_BWD>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
+  V3 F = frame_head<TRAIN ? MODE_TRAIN : MODE_BWD>(d, L, t, x, W, acc, coef2, coef3, g_abs_ext, g_projt_ext, cur.g2, cur.g3);
+  if (TRAIN) {                          // this clip's loss sums (same reduction as pose_head_rot_fwd_tp)
+    const float s2 = wave_sum(acc.sum2), c2 = wave_sum(acc.cnt2), s3 = wave_sum(acc.sum3);
+    __shared__ float red_sh[16 * 3];
+    if (L.lane == 0) red_sh[(threadIdx.x >> 6) * 3 + 0] = s2, red_sh[(threadIdx.x >> 6) * 3 + 1] = c2, red_sh[(threadIdx.x >> 6) * 3 + 2] = s3;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a = 0.f, b = 0.f, cc = 0.f;
+      for (int w = 0; w < n_waves; ++w) a += red_sh[w * 3], b += red_sh[w * 3 + 1], cc += red_sh[w * 3 + 2];
+      float *p = d.partials + (size_t)L.clip * 4;
+      p[0] = a, p[1] = b, p[2] = cc;
+    }
+  }
   // subtree sums of F and F x x through prefix sums over the DFS-ordered lanes
   V3 FX = cross(F, x);
   V3 PF = v3(group_prefix(F.x), group_prefix(F.y), group_prefix(F.z));
@@ -1405,6 +1441,9 @@ static inline unsigned grid_pk(int B) {
   const int waves = (B + 3) / 4;
   return (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
 }
+static inline float n3_elems_host(const p2c_pose_head_desc &d) {
+  return (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
+}
 static inline unsigned tp_threads(int T) { return 64u * (unsigned)((T + 1) / 2); }
 static inline size_t tp_lds_bytes(int T) {
   const size_t waves = (size_t)(T + 1) / 2;
@@ -1429,6 +1468,12 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
   if ((d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_POSE_CHANGES_MAT) && !d.final_rel_rot) return P2C_E_NULL;
   const bool tp = !mat && use_tp(d);
   const bool pkd = !mat && use_pk(d);
+  const bool sixd = d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D;
+  if (d.defer_loss_finalize == 2 && tp && !pkd && sixd) {     // "train": the backward call does all of it
+    hipLaunchKernelGGL(pose_head_count_tp, dim3((unsigned)d.B), dim3(tp_threads(d.T)), 0, stream, d);
+    hipError_t e0 = hipGetLastError();
+    return e0 == hipSuccess ? 0 : (int)e0;
+  }
   const dim3 tp_grid((unsigned)d.B), tp_block(tp_threads(d.T)), pk_grid(grid_pk(d.B));
 #define P2C_LAUNCH_ROT_FWD(KIND)                                                                                \
   if (mat) hipLaunchKernelGGL((pose_head_rot_fwd<KIND, true>), grid, block, 0, stream, d);                      \
@@ -1490,6 +1535,9 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
       if (use_pk(d) && !ga && !gp && !gr)
         hipLaunchKernelGGL(pk::pose_head_rot_bwd_tangent_pk<P2C_KIND_POSE_CHANGES_6D>, dim3(grid_pk(d.B)), block, 0, stream, d,
                            grad_losses, grad_y);
+      else if (use_tp(d) && d.defer_loss_finalize == 2)
+        hipLaunchKernelGGL((pose_head_rot_bwd_tangent_tp<P2C_KIND_POSE_CHANGES_6D, true>), dim3((unsigned)d.B),
+                           dim3(tp_threads(d.T)), tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, gr, grad_y);
       else if (use_tp(d))
         hipLaunchKernelGGL(pose_head_rot_bwd_tangent_tp<P2C_KIND_POSE_CHANGES_6D>, dim3((unsigned)d.B), dim3(tp_threads(d.T)),
                            tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, gr, grad_y);
@@ -1504,6 +1552,9 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
       if (use_pk(d) && !ga && !gp && !gr)
         hipLaunchKernelGGL(pk::pose_head_rot_bwd_tangent_pk<P2C_KIND_RELATIVE_ROT_6D>, dim3(grid_pk(d.B)), block, 0, stream, d,
                            grad_losses, grad_y);
+      else if (use_tp(d) && d.defer_loss_finalize == 2)
+        hipLaunchKernelGGL((pose_head_rot_bwd_tangent_tp<P2C_KIND_RELATIVE_ROT_6D, true>), dim3((unsigned)d.B),
+                           dim3(tp_threads(d.T)), tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, gr, grad_y);
       else if (use_tp(d))
         hipLaunchKernelGGL(pose_head_rot_bwd_tangent_tp<P2C_KIND_RELATIVE_ROT_6D>, dim3((unsigned)d.B), dim3(tp_threads(d.T)),
                            tp_lds_bytes(d.T), stream, d, grad_losses, ga, gp, gr, grad_y);
@@ -1517,5 +1568,11 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
       hipLaunchKernelGGL((pose_head_absloc<MODE_BWD>), grid, block, 0, stream, d, grad_losses, ga, gp, grad_y);
   }
   hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  if (d.defer_loss_finalize == 2) {      // the kernel above left one (sum_sq_2d, n, sum_sq_3d) per clip
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, d.B, n3_elems_host(d),
+                       d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
+    e = hipGetLastError();
+  }
   return e == hipSuccess ? 0 : (int)e;
 }

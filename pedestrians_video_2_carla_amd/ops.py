@@ -184,17 +184,22 @@ class PoseLosses:
     loc_2d_3d = property(lambda self: self.scalars[2])
 
 
-_DEFER_LOSS_FINALIZE = False
+_DEFER_LOSS_FINALIZE = 0
 
 
 class deferred_loss_finalize:
     """Context manager for a train step whose backward is GUARANTEED to follow the forward before anyone reads the loss
-    values (the trainer's captured step): the lean pose-head forward skips its one-workgroup finalize launch and the
-    backward kernel finishes the loss reduction (p2c_pose_head_desc.defer_loss_finalize). Outside of it nothing changes."""
+    values (the trainer's step). mode 1: the lean pose-head forward skips its one-workgroup finalize launch and the backward
+    kernel finishes the loss reduction. mode 2 (default): the forward call only counts the unmasked target pairs and the
+    backward kernel -- which recomputes the pose head anyway -- produces the losses as well as grad_y: the training step
+    runs the pose head ONCE (p2c_pose_head_desc.defer_loss_finalize). Outside of the context nothing changes."""
+
+    def __init__(self, mode: int = 2):
+        self.mode = mode
 
     def __enter__(self):
         global _DEFER_LOSS_FINALIZE
-        self._prev, _DEFER_LOSS_FINALIZE = _DEFER_LOSS_FINALIZE, True
+        self._prev, _DEFER_LOSS_FINALIZE = _DEFER_LOSS_FINALIZE, self.mode
         return self
 
     def __exit__(self, *exc):
@@ -233,8 +238,8 @@ class PoseHeadFunction(torch.autograd.Function):
             outs[k] = full((B, T) + _OUT_SHAPES[k], **f32)
         desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, outs)
         # lean training forward inside deferred_loss_finalize(): the backward publishes the loss values
-        ctx.deferred = bool(_DEFER_LOSS_FINALIZE and not want and ctx.needs_input_grad[0]
-                            and spec.kind in ('pose_changes_6d', 'relative_rot_6d'))
+        ctx.deferred = (_DEFER_LOSS_FINALIZE if (not want and ctx.needs_input_grad[0]
+                                                 and spec.kind in ('pose_changes_6d', 'relative_rot_6d')) else 0)
         desc.defer_loss_finalize = int(ctx.deferred)
         with torch.cuda.device(dev):
             _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), _stream()), 'p2c_pose_head_fwd')

@@ -333,13 +333,15 @@ def test_rotation_gradient_is_refused_for_matrix_kinds():
     assert not outs['absolute_pose_rot'].requires_grad          # no tangent-space path for matrix inputs: not differentiable
 
 
+@pytest.mark.parametrize('mode', [1, 2])
 @pytest.mark.parametrize('kind', ['pose_changes_6d', 'relative_rot_6d'])
 @pytest.mark.parametrize('B,T', [(1, 1), (37, 7), (256, 16), (300, 30)])
-def test_deferred_loss_finalize_equals_the_separate_launch(kind, B, T):
+def test_deferred_loss_finalize_equals_the_separate_launch(kind, B, T, mode):
     """ops.deferred_loss_finalize(): the lean forward skips loss_finalize, the time-parallel backward kernel counts the
     unmasked pairs itself (exact: small integers) and workgroup 0 publishes the losses. grad_y must be bit-identical, the
     loss values equal to fp32 rounding (fp64 accumulation in both, different summation trees); with materialised outputs
-    requested the flag must not apply."""
+    requested the flag must not apply. mode 2: the forward call only counts target pairs, the backward kernel produces the
+    losses too (the pose head runs once)."""
     from pedestrians_video_2_carla_amd import ops
     y, st, gt2, gt3, _ = _random_case(B, T, seed=B + T)
     spec = ops.PoseHeadSpec(kind=kind)
@@ -348,7 +350,7 @@ def test_deferred_loss_finalize_equals_the_separate_launch(kind, B, T):
     d = dev()
     mat_l, _ = ops.pose_head(y.float().to(d), spec, st.to(d).int(), None, None, gt2.to(d), gt3.to(d), ('projection_2d_transformed',))
     mat_vec = mat_l.vector.clone()
-    with ops.deferred_loss_finalize():
+    with ops.deferred_loss_finalize(mode):
         yd = y.float().to(d).requires_grad_(True)
         losses, _ = ops.pose_head(yd, spec, st.to(d).int(), None, None, gt2.to(d), gt3.to(d), ())
         losses[2].backward()
