@@ -259,3 +259,37 @@ def test_wave_per_tile_forward_equals_the_cooperative_forward_bit_for_bit():
             subprocess.run([sys.executable, '-c', code, f.name], check=True, env=dict(os.environ, P2C_MLP_FWD=fwd), timeout=300)
             outs.append(torch.load(f.name))
     assert torch.equal(outs[0], outs[1])
+
+
+def test_full_size_properties_of_the_fused_mlp():
+    """BASELINE configs[3] size (8 192 clips x 16 frames = 131 072 rows: wave-per-tile forward, saved activations, fused
+    weight gradient over 32 sample tiles per workgroup), checked through size-independent properties instead of an oracle:
+    run-to-run determinism (bitwise), shard consistency (the gradient of the whole batch equals the sum over two halves),
+    linearity of the weight gradient in the upstream gradient."""
+    from pedestrians_video_2_carla_amd import ops
+    d = torch.device('cuda:0')
+    dims = [52, 26, 13, 6, 39, 78, 156]
+    torch.manual_seed(21)
+    Ws = [(torch.randn(o, i, device=d) * 0.2).requires_grad_(True) for i, o in zip(dims[:-1], dims[1:])]
+    bs = [(torch.randn(o, device=d) * 0.2).requires_grad_(True) for o in dims[1:]]
+    N = 8192 * 16
+    x, gy = torch.randn(N, 52, device=d), torch.randn(N, 156, device=d)
+
+    def grads(xs, gs):
+        for p in Ws + bs:
+            p.grad = None
+        y = ops.fused_mlp(xs, Ws, bs)
+        y.backward(gs)
+        return y.detach(), torch.cat([p.grad.reshape(-1) for p in Ws + bs])
+
+    y1, g1 = grads(x, gy)
+    y2, g2 = grads(x, gy)
+    assert torch.equal(y1, y2) and torch.equal(g1, g2)
+    half = N // 2
+    ya, ga = grads(x[:half], gy[:half])
+    yb, gb = grads(x[half:], gy[half:])
+    assert torch.equal(torch.cat((ya, yb)), y1)                      # rows are independent
+    scale = float(g1.abs().max())
+    assert float((ga + gb - g1).abs().max()) <= 2e-5 * scale
+    _, g3 = grads(x, 3.0 * gy)
+    assert float((g3 - 3.0 * g1).abs().max()) <= 2e-5 * 3.0 * scale
