@@ -175,7 +175,8 @@ def test_every_mlp_test_also_passes_with_the_split_weight_gradient_forced():
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
 
 
-def test_saved_activations_equal_the_recomputation_bit_for_bit():
+@pytest.mark.parametrize('rows', [12283, 4096, 3333])     # fused weight gradient / split weight gradient (+ ragged)
+def test_saved_activations_equal_the_recomputation_bit_for_bit(rows):
     """Many sample tiles per workgroup (N = 12 288 frames): the forward leaves its hidden activations and the backward loads
     them instead of recomputing. Same values by construction, so the gradients must be IDENTICAL to the recomputing
     backward (P2C_MLP_SAVE=0, read once per process -> child process), and both match fp64."""
@@ -187,7 +188,7 @@ def test_saved_activations_equal_the_recomputation_bit_for_bit():
         "dims = [52, 26, 13, 6, 39, 78, 156]\n"
         "Ws = [(torch.randn(o, i, device=d) * 0.2).requires_grad_(True) for i, o in zip(dims[:-1], dims[1:])]\n"
         "bs = [(torch.randn(o, device=d) * 0.2).requires_grad_(True) for o in dims[1:]]\n"
-        "x = torch.randn(12283, 52, device=d)\n"
+        "x = torch.randn(int(sys.argv[2]), 52, device=d)\n"
         "y = ops.fused_mlp(x, Ws, bs); y.square().sum().backward()\n"
         "out = torch.cat([y.detach().reshape(-1)] + [p.grad.reshape(-1) for p in Ws + bs])\n"
         "torch.save(out.cpu(), sys.argv[1])\n"
@@ -195,7 +196,8 @@ def test_saved_activations_equal_the_recomputation_bit_for_bit():
     outs = []
     for save in ('1', '0'):
         with tempfile.NamedTemporaryFile(suffix='.pt') as f:
-            subprocess.run([sys.executable, '-c', code, f.name], check=True, env=dict(os.environ, P2C_MLP_SAVE=save), timeout=300)
+            subprocess.run([sys.executable, '-c', code, f.name, str(rows)], check=True, env=dict(os.environ, P2C_MLP_SAVE=save),
+                           timeout=300)
             outs.append(torch.load(f.name))
     assert torch.equal(outs[0], outs[1])
     # and the default choice at this size (saved) against fp64
@@ -206,7 +208,7 @@ def test_saved_activations_equal_the_recomputation_bit_for_bit():
     layers = [torch.nn.Linear(i, o) for i, o in zip(dims[:-1], dims[1:])]
     seq = torch.nn.Sequential(*[m for l in layers for m in (l, torch.nn.ReLU())][:-1]).to(d)
     ref = copy.deepcopy(seq).double()
-    x, w = torch.randn(12283, dims[0], device=d), torch.randn(12283, dims[-1], device=d)
+    x, w = torch.randn(rows, dims[0], device=d), torch.randn(rows, dims[-1], device=d)
     lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
     y = ops.fused_mlp(x, [m.weight for m in lin], [m.bias for m in lin])
     (y * w).sum().backward()
