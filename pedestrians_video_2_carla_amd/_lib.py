@@ -122,6 +122,8 @@ SYMBOLS = {
     'p2c_embed_workspace_floats': (_i64, [ctypes.c_int32] * 5),
     'p2c_embed_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp] + [ctypes.c_int32] * 6 + [_vp]),
     'p2c_embed_bwd': (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + [_vp]),
+    'p2c_atb_workspace_floats': (_i64, [_i64, _i32, _i32, _i32]),
+    'p2c_atb': (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     'p2c_mlp_fwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
     'p2c_mlp_bwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
 }

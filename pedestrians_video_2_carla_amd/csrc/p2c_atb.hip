@@ -1,0 +1,138 @@
+// p2c_atb.hip -- C (+)= A^T [B | 1] for tall operands (K rows >> M, N <= a few hundred columns), fp32 MFMA, gfx950.
+//
+// The weight and bias gradients of every dense layer around the Seq2Seq recurrences (reference
+// modules/movements/seq2seq/seq2seq.py:36-94: nn.LSTM input / hidden projections, Decoder.fc_out) are contractions over
+// all T*B rows of a (T*B, 4H) gradient with a (T*B, in) activation: 256 x 64 outputs from K = 8 192 rows at cfg3. The BLAS
+// libraries run that shape as a split-K GEMM plus a post-pass (rocBLAS 21.7 + 5 us, hipBLASLt 60 us for 268 MFLOP) and the
+// bias gradient as a separate column reduction. Here: workgroup (16x16 output tile, K slice) -- enough slices that the
+// grid fills the chip, the operand loads are 64-byte row segments and only memory parallelism hides their latency -- its
+// eight waves split the slice and add up through LDS in wave order; a second launch adds the slices in order (bitwise
+// reproducible) and writes C and the bias gradient (= the extra column of ones). Both operands are read row-major as
+// they are (no transpose copy).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/p2c.h"
+
+namespace p2c_atb_impl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int WAVES = 8;
+
+struct Args {
+  const float *A, *B;
+  float *C, *bias, *ws;
+  int64_t lda, ldb, ldc, K;
+  int32_t M, N, ones, accumulate, ks, tiles;
+};
+
+// One wave accumulates a 32x32 block of C as 2x2 MFMA tiles; lane (r, kk) loads the column PAIRS 2r, 2r+1 of row kk of
+// A and of B as one 8-byte access each (a whole 128-byte line per row and operand), so tile (h, g) of the block is the
+// interleaved set of rows m0 + 2i + h and columns n0 + 2j + g: two loads feed four MFMAs.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64 * WAVES) void atb_kernel(const Args a) {
+  __shared__ f32x4 red[WAVES][4][64];
+  const int lane = threadIdx.x & 63, r = lane & 15, kk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nb_count = (a.N + a.ones + 31) >> 5;
+  const int blk = blockIdx.x % a.tiles, slice = blockIdx.x / a.tiles;
+  const int mb = blk / nb_count, nb = blk - mb * nb_count;
+  const int m = mb * 32 + 2 * r, n = nb * 32 + 2 * r;          // first column of this lane's pair
+  const bool vec_a = (m + 1 < a.M) && ((a.lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 7) == 0);
+  const bool vec_b = (n + 1 < a.N) && ((a.ldb & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 7) == 0);
+  const int64_t per_slice = ((a.K + (int64_t)a.ks * WAVES * 4 - 1) / ((int64_t)a.ks * WAVES * 4)) * WAVES * 4;
+  const int64_t s0 = slice * per_slice, chunk = per_slice / WAVES;             // rows per wave: a multiple of the MFMA k
+  const int64_t k0 = s0 + wave * chunk, kend = (k0 + chunk < a.K) ? k0 + chunk : a.K;
+  const float *ap = a.A + m, *bp = a.B + n;
+  auto col = [&](const float *p, int64_t off, int c, int limit, bool one_ok) -> float {   // scalar edge path
+    return c < limit ? p[off] : ((one_ok && c == limit) ? 1.f : 0.f);
+  };
+  f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  constexpr int U = 4;
+  for (int64_t k = k0; k < kend; k += 4 * U) {
+    f32x2 av[U], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = k + 4 * u + kk;
+      const bool ok = row < kend;
+      av[u] = (f32x2){0.f, 0.f}, bv[u] = (f32x2){0.f, 0.f};
+      if (ok) {
+        if (vec_a) av[u] = *reinterpret_cast<const f32x2 *>(ap + row * a.lda);
+        else av[u] = (f32x2){col(ap, row * a.lda, m, a.M, false), col(ap, row * a.lda + 1, m + 1, a.M, false)};
+        if (vec_b) bv[u] = *reinterpret_cast<const f32x2 *>(bp + row * a.ldb);
+        else bv[u] = (f32x2){col(bp, row * a.ldb, n, a.N, a.ones != 0), col(bp, row * a.ldb + 1, n + 1, a.N, a.ones != 0)};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          acc[h][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][h], bv[u][g], acc[h][g], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) red[wave][h * 2 + g][lane] = acc[h][g];
+  __syncthreads();
+  // waves 0..3 each finish one of the four tiles (slices of K added in wave order)
+  if (wave >= 4) return;
+  f32x4 s = red[0][wave][lane];
+#pragma unroll
+  for (int w = 1; w < WAVES; ++w) s += red[w][wave][lane];
+  reinterpret_cast<f32x4 *>(a.ws)[(((size_t)slice * a.tiles + blk) * 4 + wave) * 64 + lane] = s;
+}
+
+// slices added in order, one thread per (block, tile, lane)
+__global__ __launch_bounds__(256) void atb_finish_kernel(const Args a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x, lane = idx & 63, tile = (idx >> 6) & 3, blk = idx >> 8;
+  if (blk >= a.tiles) return;
+  const f32x4 *p = reinterpret_cast<const f32x4 *>(a.ws) + ((size_t)blk * 4 + tile) * 64 + lane;
+  f32x4 s = p[0];
+  for (int k = 1; k < a.ks; ++k) s += p[(size_t)k * a.tiles * 256];
+  const int nb_count = (a.N + a.ones + 31) >> 5;
+  const int mb = blk / nb_count, nb = blk - mb * nb_count, h = tile >> 1, g = tile & 1;
+  const int col = nb * 32 + 2 * (lane & 15) + g;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = mb * 32 + 2 * (4 * (lane >> 4) + i) + h;
+    if (row >= a.M) continue;
+    if (col < a.N) {
+      float *c = a.C + (int64_t)row * a.ldc + col;
+      *c = a.accumulate ? *c + s[i] : s[i];
+    } else if (a.ones && col == a.N && a.bias) {
+      a.bias[row] = a.accumulate ? a.bias[row] + s[i] : s[i];
+    }
+  }
+}
+
+}  // namespace p2c_atb_impl
+
+static inline int slices_for(int tiles, int64_t K) {
+  int ks = 1024 / (tiles < 1 ? 1 : tiles);                     // ~1024 workgroups: four per CU
+  const int64_t max_ks = (K + 255) / 256;                      // at least 256 rows per slice
+  if (ks > max_ks) ks = (int)max_ks;
+  return ks < 1 ? 1 : (ks > 64 ? 64 : ks);
+}
+
+extern "C" int64_t p2c_atb_workspace_floats(int64_t K, int32_t M, int32_t N, int32_t with_bias) {
+  if (K < 0 || M < 1 || N < 1) return 0;
+  const int blocks = ((M + 31) / 32) * ((N + (with_bias ? 1 : 0) + 31) / 32);
+  return (int64_t)slices_for(blocks, K) * blocks * 1024;
+}
+
+extern "C" int p2c_atb(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int32_t M, int32_t N, float *C,
+                       int64_t ldc, float *bias_out, int32_t accumulate, float *workspace, void *stream) {
+  using namespace p2c_atb_impl;
+  if (!A || !B || !C || !workspace) return P2C_E_NULL;
+  if (K < 0 || M < 1 || N < 1 || lda < M || ldb < N || ldc < N) return P2C_E_SHAPE;
+  Args a{A, B, C, bias_out, workspace, lda, ldb, ldc, K, M, N, bias_out ? 1 : 0, accumulate ? 1 : 0, 1, 0};
+  a.tiles = ((M + 31) / 32) * ((N + a.ones + 31) / 32);      // 32x32 blocks of C
+  a.ks = slices_for(a.tiles, K);
+  hipLaunchKernelGGL(atb_kernel, dim3((unsigned)(a.tiles * a.ks)), dim3(64 * WAVES), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(atb_finish_kernel, dim3((unsigned)a.tiles), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

@@ -778,9 +778,9 @@ class LSTMRecurrenceFunction(torch.autograd.Function):
             _lib.check(lib.p2c_lstm_rec_bwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_bwd')
         g_w = None
         if ctx.needs_input_grad[3]:       # dW_hh = sum_t dgates[t]^T h[t-1]: two dense library GEMMs over all (t, b)
-            g_w = g_gx[0].t() @ h0
+            g_w = atb(g_gx[0], h0)[0]     # the t = 0 term meets the initial state, the rest the outputs one step earlier
             if T > 1:
-                g_w = torch.addmm(g_w, g_gx[1:].reshape(-1, 4 * H).t(), out[:-1].reshape(-1, H))
+                atb(g_gx[1:].reshape(-1, 4 * H), out[:-1].reshape(-1, H), out=g_w, accumulate=True)
         return g_gx, g_h0, g_c0, g_w
 
 
@@ -810,8 +810,56 @@ def lstm_layer(x: Tensor, h0: Tensor, c0: Tensor, w_ih: Tensor, w_hh: Tensor, b_
     _prefer_rocblas_once()
     T, B, I = x.shape
     bias = None if b_ih is None else (b_ih + b_hh if b_hh is not None else b_ih)
-    gx = torch.nn.functional.linear(x.reshape(T * B, I), w_ih, bias).view(T, B, -1)
+    gx = dense(x.reshape(T * B, I), w_ih, bias).view(T, B, -1)
     return LSTMRecurrenceFunction.apply(gx, h0, c0, w_hh)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# weight / bias gradient of a dense layer over many rows (K12)
+# ----------------------------------------------------------------------------------------------------------------------
+def atb(a: Tensor, b: Tensor, bias: bool = False, out: Optional[Tensor] = None, bias_out: Optional[Tensor] = None,
+        accumulate: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """(a^T b, column sums of a) for a (K, M), b (K, N) -- the dW / db of ``y = x W^T + b`` from dY = a and X = b -- in one
+    launch (p2c_atb). Rows may be strided views (row pitch = stride(0), unit column stride)."""
+    lib = _lib.lib()
+    a, b = (t if (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1) else _require_device(t, 'operand') for t in (a, b))
+    K, M, N = a.shape[0], a.shape[1], b.shape[1]
+    if b.shape[0] != K:
+        raise RuntimeError('atb: row counts differ')
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if bias and bias_out is None:
+        bias_out = torch.empty(M, dtype=torch.float32, device=a.device)
+    ws = torch.empty(lib.p2c_atb_workspace_floats(K, M, N, int(bias)), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.p2c_atb(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), K, M, N, out.data_ptr(), out.stride(0),
+                               _ptr(bias_out) if bias else None, int(accumulate), ws.data_ptr(), _stream()), 'p2c_atb')
+    return out, (bias_out if bias else None)
+
+
+class DenseFunction(torch.autograd.Function):
+    """y = x W^T + b over (rows, in) with the library GEMM forward and p2c_atb for the weight + bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gw, gb = atb(gy, x, bias=ctx.has_bias)
+        return gx, gw, gb
+
+
+def dense(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """``torch.nn.functional.linear`` for 2-D x whose backward runs p2c_atb (rows >> features)."""
+    if x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] >= 1024:
+        return DenseFunction.apply(x, w, b)
+    return torch.nn.functional.linear(x, w, b)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -876,10 +924,10 @@ class DecoderLoopFunction(torch.autograd.Function):
             _lib.check(lib.p2c_decoder_bwd(ctypes.byref(d), _stream()), 'p2c_decoder_bwd')
         # weight gradients: dense reductions over all (t, b) at once -- library GEMMs
         g0 = gg0.view(T * B, 4 * H)
-        g_w_ih0 = g0[B:].t() @ out[:-1].reshape(-1, O) if T > 1 else torch.zeros_like(w_ih0)   # x_0 = <sos> = 0
-        g_w_ih1 = gg1.view(T * B, 4 * H).t() @ h0d.view(T * B, H)
-        g_w_fc = gtot.view(T * B, O).t() @ h1.view(T * B, H)
-        return (gg0.sum(0), gc0, gg1.sum(0), gc1, g_w_ih0, g_w_ih1, g_w_fc, gtot.sum((0, 1)), None, None)
+        g_w_ih0 = atb(g0[B:], out[:-1].reshape(-1, O))[0] if T > 1 else torch.zeros_like(w_ih0)   # x_0 = <sos> = 0
+        g_w_ih1 = atb(gg1.view(T * B, 4 * H), h0d.view(T * B, H))[0]
+        g_w_fc, g_b_fc = atb(gtot.view(T * B, O), h1.view(T * B, H), bias=True)
+        return (gg0.sum(0), gc0, gg1.sum(0), gc1, g_w_ih0, g_w_ih1, g_w_fc, g_b_fc, None, None)
 
 
 def decoder_loop(k0: Tensor, c0: Tensor, k1: Tensor, c1: Tensor, w_ih0: Tensor, w_ih1: Tensor, w_fc: Tensor, b_fc: Tensor,

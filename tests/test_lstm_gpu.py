@@ -174,3 +174,24 @@ def test_residual_seq2seq_variants_on_the_gpu_match_cpu(variant):
     close(y, yr, 'model output', rtol=2e-4)
     for (n, pg), (_, pc) in zip(gpu.named_parameters(), cpu.named_parameters()):
         close(pg.grad, pc.grad, 'grad ' + n, rtol=5e-4)
+
+
+@pytest.mark.parametrize('K,M,N', [(8192, 256, 64), (8192, 256, 52), (8001, 52, 64), (5, 7, 3), (1, 16, 16), (300, 159, 100)])
+def test_atb_matches_fp64(K, M, N):
+    """p2c_atb: C = A^T B and the column sums of A (weight + bias gradient of a dense layer), overwrite and accumulate,
+    contiguous and row-strided operands, vs fp64."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    torch.manual_seed(K + M + N)
+    a, b = torch.randn(K, M, device=d), torch.randn(K, N, device=d)
+    c, cb = ops.atb(a, b, bias=True)
+    ref, refb = a.double().t() @ b.double(), a.double().sum(0)
+    close(c, ref, 'A^T B', rtol=2e-6 * max(1.0, K ** 0.5))
+    close(cb, refb, 'column sums', rtol=2e-6 * max(1.0, K ** 0.5))
+    c2 = c.clone()
+    ops.atb(a, b, out=c2, accumulate=True)
+    close(c2, 2 * ref, 'accumulate', rtol=2e-6 * max(1.0, K ** 0.5))
+    wide_a, wide_b = torch.randn(K, M + 5, device=d), torch.randn(K, N + 9, device=d)
+    c3, _ = ops.atb(wide_a[:, 2:2 + M], wide_b[:, 4:4 + N])
+    close(c3, wide_a[:, 2:2 + M].double().t() @ wide_b[:, 4:4 + N].double(), 'strided', rtol=2e-6 * max(1.0, K ** 0.5))
+    assert torch.equal(ops.atb(a, b)[0], ops.atb(a, b)[0])              # fixed summation order
