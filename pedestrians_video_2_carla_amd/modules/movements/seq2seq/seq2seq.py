@@ -49,14 +49,14 @@ def _run_stack(rnn: nn.LSTM, x: Tensor, hidden: Tensor = None, cell: Tensor = No
     B, H = x.shape[1], rnn.hidden_size
     hs, cs = [], []
     for k in range(rnn.num_layers):
-        h0 = hidden[k] if hidden is not None else x.new_zeros(B, H)
-        c0 = cell[k] if cell is not None else x.new_zeros(B, H)
+        h0 = hidden[k].contiguous() if hidden is not None else None        # None = nn.LSTM's zero initial state: the kernel
+        c0 = cell[k].contiguous() if cell is not None else None            # reads nothing and no gradient is produced for it
         b_ih = getattr(rnn, f'bias_ih_l{k}', None) if rnn.bias else None
         b_hh = getattr(rnn, f'bias_hh_l{k}', None) if rnn.bias else None
         w_ih = getattr(rnn, f'weight_ih_l{k}')
         if k == 0 and input_map is not None:
             w_ih, b_ih, b_hh = input_map[0], input_map[1], None
-        x, hT, cT = ops.lstm_layer(x, h0.contiguous(), c0.contiguous(), w_ih, getattr(rnn, f'weight_hh_l{k}'), b_ih, b_hh)
+        x, hT, cT = ops.lstm_layer(x, h0, c0, w_ih, getattr(rnn, f'weight_hh_l{k}'), b_ih, b_hh)
         hs.append(hT), cs.append(cT)
         if rnn.dropout > 0 and rnn.training and k < rnn.num_layers - 1:
             x = torch.nn.functional.dropout(x, rnn.dropout, True)

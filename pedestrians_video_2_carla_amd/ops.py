@@ -741,10 +741,15 @@ class LSTMRecurrenceFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, h0, c0, w_hh):
         lib = _lib.lib()
-        gx, h0, c0, w_hh = (_require_device(t, n) for t, n in ((gx, 'gx'), (h0, 'h0'), (c0, 'c0'), (w_hh, 'weight_hh')))
+        gx, w_hh = _require_device(gx, 'gx'), _require_device(w_hh, 'weight_hh')
+        ctx.zero_state = h0 is None and c0 is None           # nn.LSTM's default initial state: nothing to read or to return
         T, B, G = gx.shape
         H = w_hh.shape[1]
-        if G != 4 * H or w_hh.shape[0] != 4 * H or h0.shape != (B, H) or c0.shape != (B, H):
+        if ctx.zero_state:
+            h0 = c0 = gx.new_empty(0)
+        else:
+            h0, c0 = _require_device(h0, 'h0'), _require_device(c0, 'c0')
+        if G != 4 * H or w_hh.shape[0] != 4 * H or (not ctx.zero_state and (h0.shape != (B, H) or c0.shape != (B, H))):
             raise RuntimeError(f'inconsistent LSTM shapes: gx {tuple(gx.shape)}, w_hh {tuple(w_hh.shape)}, h0 {tuple(h0.shape)}')
         if not lstm_supported(H):
             raise RuntimeError(f'hidden size {H} is not supported by the HIP recurrence (16, 32, 48 or 64)')
@@ -753,7 +758,9 @@ class LSTMRecurrenceFunction(torch.autograd.Function):
         acts, cs = torch.empty(T, B, 4 * H, **f32), torch.empty(T, B, H, **f32)
         d = _lib.LstmDesc()
         d.T, d.B, d.H = T, B, H
-        d.gx, d.h0, d.c0, d.w_hh = gx.data_ptr(), h0.data_ptr(), c0.data_ptr(), w_hh.data_ptr()
+        d.gx, d.w_hh = gx.data_ptr(), w_hh.data_ptr()
+        if not ctx.zero_state:
+            d.h0, d.c0 = h0.data_ptr(), c0.data_ptr()
         d.out, d.hT, d.cT, d.acts, d.cs = out.data_ptr(), hT.data_ptr(), cT.data_ptr(), acts.data_ptr(), cs.data_ptr()
         with torch.cuda.device(gx.device):
             _lib.check(lib.p2c_lstm_rec_fwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_fwd')
@@ -766,21 +773,29 @@ class LSTMRecurrenceFunction(torch.autograd.Function):
         h0, c0, w_hh, out, acts, cs = ctx.saved_tensors
         T, B, H = out.shape
         f32 = dict(dtype=torch.float32, device=out.device)
-        g_gx, g_h0, g_c0 = torch.empty(T, B, 4 * H, **f32), torch.empty(B, H, **f32), torch.empty(B, H, **f32)
+        zero = ctx.zero_state
+        g_gx = torch.empty(T, B, 4 * H, **f32)
+        g_h0 = g_c0 = None
         d = _lib.LstmDesc()
         d.T, d.B, d.H = T, B, H
-        d.c0, d.w_hh, d.acts, d.cs = c0.data_ptr(), w_hh.data_ptr(), acts.data_ptr(), cs.data_ptr()
+        d.w_hh, d.acts, d.cs = w_hh.data_ptr(), acts.data_ptr(), cs.data_ptr()
+        if not zero:
+            g_h0, g_c0 = torch.empty(B, H, **f32), torch.empty(B, H, **f32)
+            d.c0, d.g_h0, d.g_c0 = c0.data_ptr(), g_h0.data_ptr(), g_c0.data_ptr()
         d.g_out = _ptr(None if g_out is None else _require_device(g_out, 'grad out'))
         d.g_hT = _ptr(None if g_hT is None else _require_device(g_hT, 'grad hT'))
         d.g_cT = _ptr(None if g_cT is None else _require_device(g_cT, 'grad cT'))
-        d.g_gx, d.g_h0, d.g_c0 = g_gx.data_ptr(), g_h0.data_ptr(), g_c0.data_ptr()
+        d.g_gx = g_gx.data_ptr()
         with torch.cuda.device(out.device):
             _lib.check(lib.p2c_lstm_rec_bwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_bwd')
         g_w = None
-        if ctx.needs_input_grad[3]:       # dW_hh = sum_t dgates[t]^T h[t-1]: two dense library GEMMs over all (t, b)
-            g_w = atb(g_gx[0], h0)[0]     # the t = 0 term meets the initial state, the rest the outputs one step earlier
+        if ctx.needs_input_grad[3]:       # dW_hh = sum_t dgates[t]^T h[t-1] over all (t, b) (K12)
             if T > 1:
-                atb(g_gx[1:].reshape(-1, 4 * H), out[:-1].reshape(-1, H), out=g_w, accumulate=True)
+                g_w = atb(g_gx[1:].reshape(-1, 4 * H), out[:-1].reshape(-1, H))[0]
+            if not zero:                  # the t = 0 term meets the initial state (zero state: no contribution)
+                g_w = atb(g_gx[0], h0, out=g_w, accumulate=g_w is not None)[0]
+            if g_w is None:
+                g_w = torch.zeros_like(w_hh)
         return g_gx, g_h0, g_c0, g_w
 
 
@@ -803,7 +818,7 @@ def _prefer_rocblas_once():
             pass
 
 
-def lstm_layer(x: Tensor, h0: Tensor, c0: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Optional[Tensor],
+def lstm_layer(x: Tensor, h0: Optional[Tensor], c0: Optional[Tensor], w_ih: Tensor, w_hh: Tensor, b_ih: Optional[Tensor],
                b_hh: Optional[Tensor]) -> Tuple[Tensor, Tensor, Tensor]:
     """One unidirectional torch.nn.LSTM layer: x (T,B,I) -> (out (T,B,H), hT (B,H), cT (B,H)). The input projection for
     all time steps is one dense GEMM (library); the time loop is one HIP launch (p2c_lstm_rec_fwd)."""

@@ -195,3 +195,26 @@ def test_atb_matches_fp64(K, M, N):
     c3, _ = ops.atb(wide_a[:, 2:2 + M], wide_b[:, 4:4 + N])
     close(c3, wide_a[:, 2:2 + M].double().t() @ wide_b[:, 4:4 + N].double(), 'strided', rtol=2e-6 * max(1.0, K ** 0.5))
     assert torch.equal(ops.atb(a, b)[0], ops.atb(a, b)[0])              # fixed summation order
+
+
+@pytest.mark.parametrize('T,B,I,H', [(1, 3, 5, 16), (16, 37, 52, 64), (9, 130, 20, 32)])
+def test_layer_with_the_default_zero_state(T, B, I, H):
+    """h0 = c0 = None (nn.LSTM's default): the kernel reads no initial state, the W_hh gradient has no t = 0 term and no
+    state gradients are produced -- vs torch.nn.LSTM called without a state, fp64."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    torch.manual_seed(T + B + H)
+    ref = torch.nn.LSTM(I, H).double()
+    x = torch.randn(T, B, I, dtype=torch.float64)
+    up, uh, uc = torch.randn(T, B, H, dtype=torch.float64), torch.randn(B, H, dtype=torch.float64), torch.randn(B, H, dtype=torch.float64)
+    xr = x.clone().requires_grad_(True)
+    out_r, (hT_r, cT_r) = ref(xr)
+    ((out_r * up).sum() + (hT_r[0] * uh).sum() + (cT_r[0] * uc).sum()).backward()
+    p = {n: v.detach().float().to(d).requires_grad_(True) for n, v in ref.named_parameters()}
+    xd = x.float().to(d).requires_grad_(True)
+    out, hT, cT = ops.lstm_layer(xd, None, None, p['weight_ih_l0'], p['weight_hh_l0'], p['bias_ih_l0'], p['bias_hh_l0'])
+    ((out * up.float().to(d)).sum() + (hT * uh.float().to(d)).sum() + (cT * uc.float().to(d)).sum()).backward()
+    close(out, out_r, 'out'), close(hT, hT_r[0], 'hT'), close(cT, cT_r[0], 'cT')
+    close(xd.grad, xr.grad, 'grad x')
+    for n, v in ref.named_parameters():
+        close(p[n].grad, v.grad, 'grad ' + n)
