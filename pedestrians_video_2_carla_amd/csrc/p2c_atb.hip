@@ -90,8 +90,17 @@ __global__ __launch_bounds__(256) void atb_finish_kernel(const Args a) {
   const int idx = blockIdx.x * 256 + threadIdx.x, lane = idx & 63, tile = (idx >> 6) & 3, blk = idx >> 8;
   if (blk >= a.tiles) return;
   const f32x4 *p = reinterpret_cast<const f32x4 *>(a.ws) + ((size_t)blk * 4 + tile) * 64 + lane;
-  f32x4 s = p[0];
-  for (int k = 1; k < a.ks; ++k) s += p[(size_t)k * a.tiles * 256];
+  const size_t stride = (size_t)a.tiles * 256;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= a.ks; k += 8) {                              // eight slices in flight, added in slice order
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < a.ks; ++k) s += p[(size_t)k * stride];
   const int nb_count = (a.N + a.ones + 31) >> 5;
   const int mb = blk / nb_count, nb = blk - mb * nb_count, h = tile >> 1, g = tile & 1;
   const int col = nb * 32 + 2 * (lane & 15) + g;
