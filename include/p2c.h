@@ -355,7 +355,7 @@ P2C_API int p2c_collate_fwd(const p2c_collate_desc *desc, void *stream);
  * Replaces, in the backward of the Seq2Seq models (modules/movements/seq2seq/seq2seq.py:36-94: the nn.LSTM projections and
  * Decoder.fc_out under autograd), the split-K library GEMM dW = dY^T X and the column reduction db = sum_rows dY.
  * A (K, M) row-major with row pitch lda (= dY), B (K, N) with pitch ldb (= X), C (M, N) with pitch ldc; bias_out (M) or
- * NULL; accumulate = add to C / bias_out instead of overwriting; workspace = p2c_atb_workspace_floats floats (partial
+ * NULL; accumulate: bit 0 = add to C instead of overwriting, bit 1 = the same for bias_out; workspace = p2c_atb_workspace_floats floats (partial
  * tiles of the K slices). Two launches, fixed summation order (bitwise reproducible). */
 P2C_API int64_t p2c_atb_workspace_floats(int64_t K, int32_t M, int32_t N, int32_t with_bias);
 P2C_API int p2c_atb(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int32_t M, int32_t N, float *C,

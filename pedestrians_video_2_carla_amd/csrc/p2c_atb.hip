@@ -110,9 +110,9 @@ __global__ __launch_bounds__(256) void atb_finish_kernel(const Args a) {
     if (row >= a.M) continue;
     if (col < a.N) {
       float *c = a.C + (int64_t)row * a.ldc + col;
-      *c = a.accumulate ? *c + s[i] : s[i];
+      *c = (a.accumulate & 1) ? *c + s[i] : s[i];
     } else if (a.ones && col == a.N && a.bias) {
-      a.bias[row] = a.accumulate ? a.bias[row] + s[i] : s[i];
+      a.bias[row] = (a.accumulate & 2) ? a.bias[row] + s[i] : s[i];
     }
   }
 }
@@ -137,7 +137,7 @@ extern "C" int p2c_atb(const float *A, int64_t lda, const float *B, int64_t ldb,
   using namespace p2c_atb_impl;
   if (!A || !B || !C || !workspace) return P2C_E_NULL;
   if (K < 0 || M < 1 || N < 1 || lda < M || ldb < N || ldc < N) return P2C_E_SHAPE;
-  Args a{A, B, C, bias_out, workspace, lda, ldb, ldc, K, M, N, bias_out ? 1 : 0, accumulate ? 1 : 0, 1, 0};
+  Args a{A, B, C, bias_out, workspace, lda, ldb, ldc, K, M, N, bias_out ? 1 : 0, accumulate & 3, 1, 0};
   a.tiles = ((M + 31) / 32) * ((N + a.ones + 31) / 32);      // 32x32 blocks of C
   a.ks = slices_for(a.tiles, K);
   hipLaunchKernelGGL(atb_kernel, dim3((unsigned)(a.tiles * a.ks)), dim3(64 * WAVES), 0, (hipStream_t)stream, a);

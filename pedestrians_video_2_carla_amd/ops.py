@@ -790,12 +790,16 @@ class LSTMRecurrenceFunction(torch.autograd.Function):
             _lib.check(lib.p2c_lstm_rec_bwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_bwd')
         g_w = None
         if ctx.needs_input_grad[3]:       # dW_hh = sum_t dgates[t]^T h[t-1] over all (t, b) (K12)
+            sink = _sink(w_hh)
+            g_w, acc = sink, sink is not None
             if T > 1:
-                g_w = atb(g_gx[1:].reshape(-1, 4 * H), out[:-1].reshape(-1, H))[0]
+                g_w, acc = atb(g_gx[1:].reshape(-1, 4 * H), out[:-1].reshape(-1, H), out=g_w, accumulate=acc)[0], True
             if not zero:                  # the t = 0 term meets the initial state (zero state: no contribution)
-                g_w = atb(g_gx[0], h0, out=g_w, accumulate=g_w is not None)[0]
+                g_w = atb(g_gx[0], h0, out=g_w, accumulate=acc)[0]
             if g_w is None:
                 g_w = torch.zeros_like(w_hh)
+            if sink is not None:
+                g_w = None                # already added to w_hh.grad
         return g_gx, g_h0, g_c0, g_w
 
 
@@ -832,6 +836,16 @@ def lstm_layer(x: Tensor, h0: Optional[Tensor], c0: Optional[Tensor], w_ih: Tens
 # ----------------------------------------------------------------------------------------------------------------------
 # weight / bias gradient of a dense layer over many rows (K12)
 # ----------------------------------------------------------------------------------------------------------------------
+GRAD_SINKS = False      # set by the flat trainer: weight gradients may be ADDED straight into an existing ``param.grad``
+
+
+def _sink(p: Tensor) -> Optional[Tensor]:
+    """``p.grad`` if gradients may be accumulated into it directly (same result as returning the gradient to autograd, minus
+    the temporary and the per-parameter accumulate launch; parameter hooks do not fire)."""
+    g = p.grad if GRAD_SINKS else None
+    return g if (g is not None and g.is_cuda and g.dtype == torch.float32 and g.stride(-1) == 1) else None
+
+
 def atb(a: Tensor, b: Tensor, bias: bool = False, out: Optional[Tensor] = None, bias_out: Optional[Tensor] = None,
         accumulate: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
     """(a^T b, column sums of a) for a (K, M), b (K, N) -- the dW / db of ``y = x W^T + b`` from dY = a and X = b -- in one
@@ -843,12 +857,13 @@ def atb(a: Tensor, b: Tensor, bias: bool = False, out: Optional[Tensor] = None, 
         raise RuntimeError('atb: row counts differ')
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    flags = (1 if accumulate else 0) | (2 if (accumulate and bias_out is not None) else 0)   # a fresh bias vector is overwritten
     if bias and bias_out is None:
         bias_out = torch.empty(M, dtype=torch.float32, device=a.device)
     ws = torch.empty(lib.p2c_atb_workspace_floats(K, M, N, int(bias)), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
         _lib.check(lib.p2c_atb(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), K, M, N, out.data_ptr(), out.stride(0),
-                               _ptr(bias_out) if bias else None, int(accumulate), ws.data_ptr(), _stream()), 'p2c_atb')
+                               _ptr(bias_out) if bias else None, flags, ws.data_ptr(), _stream()), 'p2c_atb')
     return out, (bias_out if bias else None)
 
 
@@ -866,8 +881,9 @@ class DenseFunction(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gy @ w if ctx.needs_input_grad[0] else None
-        gw, gb = atb(gy, x, bias=ctx.has_bias)
-        return gx, gw, gb
+        sink = _sink(w)
+        gw, gb = atb(gy, x, bias=ctx.has_bias, out=sink, accumulate=sink is not None)
+        return gx, (None if sink is not None else gw), gb
 
 
 def dense(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
@@ -939,10 +955,16 @@ class DecoderLoopFunction(torch.autograd.Function):
             _lib.check(lib.p2c_decoder_bwd(ctypes.byref(d), _stream()), 'p2c_decoder_bwd')
         # weight gradients: dense reductions over all (t, b) at once -- library GEMMs
         g0 = gg0.view(T * B, 4 * H)
-        g_w_ih0 = atb(g0[B:], out[:-1].reshape(-1, O))[0] if T > 1 else torch.zeros_like(w_ih0)   # x_0 = <sos> = 0
-        g_w_ih1 = atb(gg1.view(T * B, 4 * H), h0d.view(T * B, H))[0]
-        g_w_fc, g_b_fc = atb(gtot.view(T * B, O), h1.view(T * B, H), bias=True)
-        return (gg0.sum(0), gc0, gg1.sum(0), gc1, g_w_ih0, g_w_ih1, g_w_fc, g_b_fc, None, None)
+        s0, s1, sf, sb = _sink(w_ih0), _sink(w_ih1), _sink(w_fc), _sink(b_fc)
+        if sf is None or sb is None:
+            sf = sb = None                # weight and bias of fc_out leave through one launch: both or neither
+        g_w_ih0 = (atb(g0[B:], out[:-1].reshape(-1, O), out=s0, accumulate=s0 is not None)[0] if T > 1
+                   else torch.zeros_like(w_ih0))                                            # x_0 = <sos> = 0
+        g_w_ih1 = atb(gg1.view(T * B, 4 * H), h0d.view(T * B, H), out=s1, accumulate=s1 is not None)[0]
+        g_w_fc, g_b_fc = atb(gtot.view(T * B, O), h1.view(T * B, H), bias=True, out=sf, bias_out=sb, accumulate=sf is not None)
+        return (gg0.sum(0), gc0, gg1.sum(0), gc1, None if (s0 is not None and T > 1) else g_w_ih0,
+                None if s1 is not None else g_w_ih1, None if sf is not None else g_w_fc, None if sb is not None else g_b_fc,
+                None, None)
 
 
 def decoder_loop(k0: Tensor, c0: Tensor, k1: Tensor, c1: Tensor, w_ih0: Tensor, w_ih1: Tensor, w_fc: Tensor, b_fc: Tensor,

@@ -85,6 +85,8 @@ class Trainer:
                 for m in flow.modules():
                     if hasattr(m, 'grad_sink'):
                         m.grad_sink = True
+                from pedestrians_video_2_carla_amd import ops as _ops
+                _ops.GRAD_SINKS = True           # K12 adds weight gradients straight into the flat gradient buffer's views
             if len(configs) != 1:
                 raise ValueError('exactly one trainable plugin expected (ZeroTrajectory has no optimizer)')
             self.optimizers = [self.flat.rebuild_optimizer(configs[0]['optimizer'], **extra)]

@@ -191,6 +191,11 @@ def test_atb_matches_fp64(K, M, N):
     c2 = c.clone()
     ops.atb(a, b, out=c2, accumulate=True)
     close(c2, 2 * ref, 'accumulate', rtol=2e-6 * max(1.0, K ** 0.5))
+    c4, b4 = c.clone(), cb.clone()
+    ops.atb(a, b, bias=True, out=c4, bias_out=b4, accumulate=True)       # both outputs given: both accumulate
+    close(c4, 2 * ref, 'accumulate C', rtol=2e-6 * max(1.0, K ** 0.5)), close(b4, 2 * refb, 'accumulate bias', rtol=2e-6 * max(1.0, K ** 0.5))
+    c5, b5 = ops.atb(a, b, bias=True, out=c.clone(), accumulate=True)    # fresh bias vector: overwritten, not accumulated
+    close(b5, refb, 'fresh bias', rtol=2e-6 * max(1.0, K ** 0.5))
     wide_a, wide_b = torch.randn(K, M + 5, device=d), torch.randn(K, N + 9, device=d)
     c3, _ = ops.atb(wide_a[:, 2:2 + M], wide_b[:, 4:4 + N])
     close(c3, wide_a[:, 2:2 + M].double().t() @ wide_b[:, 4:4 + N].double(), 'strided', rtol=2e-6 * max(1.0, K ** 0.5))
@@ -218,3 +223,34 @@ def test_layer_with_the_default_zero_state(T, B, I, H):
     close(xd.grad, xr.grad, 'grad x')
     for n, v in ref.named_parameters():
         close(p[n].grad, v.grad, 'grad ' + n)
+
+
+def test_weight_gradients_added_straight_into_the_flat_buffer_equal_autograd_accumulation():
+    """Flat trainer (ops.GRAD_SINKS: K12 adds dW into the views of the flat gradient buffer, returns no gradient to autograd)
+    vs the same model with per-parameter gradients through autograd: every gradient of one Seq2SeqEmbeddings train step."""
+    from pedestrians_video_2_carla_amd import ops
+    from pedestrians_video_2_carla_amd.data.carla.carla_recorded_synthetic import SyntheticCarlaRecordedDataModule
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.autoencoder import LitAutoencoderFlow
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2SeqEmbeddings
+    from pedestrians_video_2_carla_amd.trainer import Trainer, seed_everything
+    d = dev()
+    grads = {}
+    for flat in (True, False):
+        seed_everything(12)
+        ops.GRAD_SINKS = False
+        dm = SyntheticCarlaRecordedDataModule(clip_length=16, batch_size=80)      # 1 280 rows: the K12 path (>= 1 024)
+        model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d,
+                                  p_dropout=0.0)
+        flow = LitAutoencoderFlow(movements_model=model, loss_modes=['loc_2d'], transform='hips_neck_bbox')
+        trainer = Trainer(device=d, use_graph=False, flatten=flat).setup(flow, dm)
+        assert ops.GRAD_SINKS == flat
+        batch = dm.generate_batch(d)
+        flow.train()
+        flow.on_train_batch_start(batch, 0)
+        flow.training_step(batch, 0)['loss'].backward()
+        grads[flat] = {n: p.grad.detach().clone() for n, p in flow.named_parameters()}
+    ops.GRAD_SINKS = False
+    for n in grads[True]:
+        close(grads[True][n], grads[False][n], 'grad ' + n, rtol=2e-5)
