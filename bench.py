@@ -101,10 +101,16 @@ def kernel_times(device, B, reps=20):
         def bwd():
             _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, None, gy.data_ptr(), s), 'bwd')
 
+        def train():                # what the trainer's step runs (ops.deferred_loss_finalize mode 2): the forward call only
+            desc.defer_loss_finalize = 2      # counts target pairs, the backward kernel produces losses + gradients, + finalize
+            fwd()
+            bwd()
+            desc.defer_loss_finalize = 0
+
         fwd()
         bwd()
         stream.synchronize()
-        for name, fn in (('fwd', fwd), ('bwd', bwd)):
+        for name, fn in (('fwd', fwd), ('bwd', bwd), ('train', train)):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
                 for _ in range(reps):
@@ -317,7 +323,10 @@ def main():
     per_clip = {'fwd': BYTES_FWD, 'bwd': BYTES_BWD}
     entries = {names[w]: roofline_entry(names[w], args.batch_size, kt[w], per_clip[w],
                                         (traffic.get(f'{names[w]}@B{args.batch_size}') or {}).get('bytes')) for w in ('fwd', 'bwd')}
-    breakdown = {names[w]: round(kt[w], 2) for w in ('fwd', 'bwd')}
+    if int(os.environ.get('P2C_DEFER_FINALIZE', '2')) == 2 and args.batch_size <= 2048:
+        breakdown = {'pose_head_train(count + fwd/bwd in one kernel + finalize)': round(kt['train'], 2)}
+    else:
+        breakdown = {names[w]: round(kt[w], 2) for w in ('fwd', 'bwd')}
     if getattr(flow.movements_model, 'fused_mlp', False):
         mt, flops = mlp_times(device, flow.movements_model, args.batch_size, getattr(trainer, '_opt_in_backward', False))
         breakdown.update({k: round(v, 2) for k, v in mt.items()})
