@@ -127,7 +127,8 @@ P2C_API int p2c_pose_head_set_time_parallel_max_batch(int32_t max_b);
 P2C_API int p2c_pose_head_set_packed_min_batch(int32_t min_b);
 
 /* Forward: fills loss_sums, losses, final_rel_rot and any non-NULL out_* tensor. Two launches on `stream`
- * (pose head + deterministic reduction of the per-wave partial sums). */
+ * (pose head + deterministic reduction of the per-wave partial sums); with desc->defer_loss_finalize = 1 / 2 one launch
+ * (no reduction / only the per-clip count of unmasked target pairs) -- see the field's comment. */
 P2C_API int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream);
 
 /* Backward (recompute): grad_y has the layout of desc->y. `grad_losses` = host array of three device pointers (each
@@ -135,7 +136,8 @@ P2C_API int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream);
  * pass {g, g+1, g+2}; NULL array = all zero. desc->loss_sums and desc->final_rel_rot must hold the forward's values.
  * Optional upstream gradients of materialised outputs (NULL = none): grad_absolute_pose_loc (B,T,26,3),
  * grad_projection_2d_transformed (B,T,26,3) [channel 2 ignored], grad_absolute_pose_rot (B,T,26,3,3) [6-D kinds only:
- * rot_3d-type losses, reference loss/rot_3d.py; P2C_E_ENUM for the matrix kinds]. One launch. */
+ * rot_3d-type losses, reference loss/rot_3d.py; P2C_E_ENUM for the matrix kinds]. One launch (two with
+ * desc->defer_loss_finalize = 2: the kernel that also sums the losses + their final reduction). */
 P2C_API int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *const grad_losses[3],
                       const float *grad_absolute_pose_loc, const float *grad_projection_2d_transformed,
                       const float *grad_absolute_pose_rot, float *grad_y, void *stream);
