@@ -191,7 +191,8 @@ typedef struct p2c_mlp_desc {
                                            read by p2c_mlp_bwd (same weights: call bwd before the optimizer) */
   /* optional, p2c_mlp_bwd only: apply this optimizer step to the MLP's parameters inside the gradient reduction (single-GPU
    * training, no all-reduce in between): gW/gb must be views of fused_adamw->grad, the MLP must be all of its n parameters;
-   * w_image (if set) is refreshed with the new weights. Host pointer, read during the call. */
+   * w_image (if set) is refreshed with the new weights; with fused_adamw->zero_grad set, gW / gb are left ZEROED (as
+   * p2c_adamw_step leaves them) instead of holding the gradient. Host pointer, read during the call. */
   const struct p2c_adamw_desc *fused_adamw;
   int32_t skip_pack;                    /* 1 = w_image is already current (kept so by p2c_mlp_pack + the optimizer's
                                            scatter, see p2c_adamw_desc): p2c_mlp_fwd does not launch the pack kernel */
@@ -209,6 +210,36 @@ P2C_API int64_t p2c_mlp_workspace_floats(const p2c_mlp_desc *desc);
 P2C_API int64_t p2c_mlp_saved_floats(const p2c_mlp_desc *desc);
 P2C_API int p2c_mlp_fwd(const p2c_mlp_desc *desc, void *stream);
 P2C_API int p2c_mlp_bwd(const p2c_mlp_desc *desc, void *stream);
+
+/* ---- K13: the small-batch train step of LitPoseLiftingFlow(LinearAE) in two launches ------------------------------------
+ * Replaces, for one optimisation step on a batch of B clips of T <= 16 frames (one clip = one 16-sample MFMA tile):
+ *   modules/flow/base.py:397-410 (_step) -> modules/flow/pose_lifting.py:121-144 (_inner_step)
+ *     modules/movements/linear_ae/linear_ae.py:50-59 (LinearAE.forward, 6-D rotation output: 52-26-13-6-39-78-156)
+ *     everything p2c_pose_head_fwd / _bwd replace (projection layer, transform_callable, loc_2d / loc_3d / loc_2d_3d)
+ *   the backward of all of it, and -- with mlp.fused_adamw -- torch.optim.AdamW.step (flow/base_model.py:156-158).
+ * Launch 1: one workgroup per clip (LinearAE forward -> pose head forward + backward -> dgrad chain; the model output and
+ * its gradient never leave LDS), leaving per-clip loss sums and weight-gradient factors in `mlp.partials`; launch 2: one
+ * workgroup per 16x16 weight-gradient tile contracts the factors over all clips in a fixed order, writes gW/gb, applies
+ * the optimizer step and refreshes mlp.w_image, and finishes the loss reduction. Same arithmetic, same summation orders
+ * as the separate entry points: results are bitwise reproducible, and bit-identical to p2c_mlp_fwd -> p2c_pose_head_* ->
+ * p2c_mlp_bwd where that path runs its split weight gradient.
+ * head: y / final_rel_rot / out_* unused (out_* must be NULL); kind POSE_CHANGES_6D or RELATIVE_ROT_6D; partials = B*4
+ * floats; losses / loss_sums are written by launch 2. mlp: x (B*T, 52), W / b (for p2c_mlp_pack unless skip_pack),
+ * w_image, gW / gb (written), partials = p2c_train_step_workspace_floats floats, optional fused_adamw; y / gy / saved unused.
+ * pair_counts: (B) floats from p2c_count_target_pairs on the SAME targets (a property of the batch: computed when the batch
+ * is staged, not per step). grad_losses: as p2c_pose_head_bwd. */
+typedef struct p2c_train_step_desc {
+  p2c_pose_head_desc head;
+  p2c_mlp_desc mlp;
+  const float *pair_counts;
+} p2c_train_step_desc;
+P2C_API int p2c_train_step_supported(const p2c_train_step_desc *desc);          /* 1 = shapes / kind the kernels cover */
+P2C_API int64_t p2c_train_step_workspace_floats(const p2c_train_step_desc *desc);
+P2C_API int p2c_train_step(const p2c_train_step_desc *desc, const float *const grad_losses[3], void *stream);
+/* counts[b] = number of (frame, joint) pairs of clip b inside [t0, t1) whose 2-D target the loss does not mask
+ * (utils/tensors.py:29-40 via loss/base_pose_loss.py:36-66): reads only the target-side fields of desc (gt2d, gmap2d,
+ * hips_lane, mask_missing_joints, t0, t1); y / partials / losses may be NULL. One launch. */
+P2C_API int p2c_count_target_pairs(const p2c_pose_head_desc *desc, float *counts, void *stream);
 
 /* ---- grouped per-joint embeddings (K7a) --------------------------------------------------------------------------------
  * Replaces the loop over 26 nn.Linear(2, 64) of Seq2SeqEmbeddings._format_input (modules/movements/seq2seq/

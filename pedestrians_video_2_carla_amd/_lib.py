@@ -51,6 +51,11 @@ class MlpDesc(ctypes.Structure):
     ]
 
 
+class TrainStepDesc(ctypes.Structure):
+    """Mirror of ``p2c_train_step_desc`` (include/p2c.h)."""
+    _fields_ = [('head', PoseHeadDesc), ('mlp', MlpDesc), ('pair_counts', _f32p)]
+
+
 # every symbol include/p2c.h declares: (restype, argtypes)
 _vp, _i64, _ip = ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int32)
 class AdamWDesc(ctypes.Structure):
@@ -126,6 +131,10 @@ SYMBOLS = {
     'p2c_atb': (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     'p2c_mlp_fwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
     'p2c_mlp_bwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
+    'p2c_train_step_supported': (ctypes.c_int, [ctypes.POINTER(TrainStepDesc)]),
+    'p2c_train_step_workspace_floats': (_i64, [ctypes.POINTER(TrainStepDesc)]),
+    'p2c_train_step': (ctypes.c_int, [ctypes.POINTER(TrainStepDesc), ctypes.POINTER(_vp * 3), _vp]),
+    'p2c_count_target_pairs': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp, _vp]),
 }
 
 _lib = None

@@ -34,8 +34,11 @@ __device__ __forceinline__ Coefs coefs(const p2c_adamw_desc &d, float step) {
   return c;
 }
 
+// No FMA contraction in here: the formula is inlined into three kernels (adamw_kernel, the MLP's gradient reductions, the
+// two-launch train step) and must round the same way in each, whatever the surrounding code lets the compiler fuse.
 template <bool ADAMW>
 __device__ __forceinline__ void update(const Coefs &c, float &p, float g, float &m, float &v) {
+#pragma clang fp contract(off)
   g *= c.grad_scale;
   if (ADAMW) p -= c.lr_wd * p;          // decoupled weight decay
   else g += c.wd * p;                   // L2 penalty (Adam)

@@ -1,0 +1,577 @@
+// p2c_train.hip -- the small-batch train step of LitPoseLiftingFlow(LinearAE, 6-D output) in TWO launches (gfx950).
+//
+// What it replaces (reference, paths relative to src/pedestrians_video_2_carla/): modules/flow/base.py:397-410 (_step) ->
+// modules/flow/pose_lifting.py:121-144 (_inner_step: LinearAE.forward, linear_ae.py:50-59 -> ProjectionModule ->
+// transform_callable) -> loss/loc_2d_3d.py:6-17 -> backward -> AdamW (flow/base_model.py:156-158).
+//
+// The separate kernels of this library run that step at B = 256 as seven dependent launches (count, mlp_fwd, pose-head
+// backward, loss_finalize, mlp_bwd, mlp_wgrad, mlp_reduce) whose sum is launch latency, and move the model output y, its
+// gradient and the MLP's factors through HBM in between. Here one clip of T <= 16 frames IS one 16-sample MFMA tile:
+//
+//   train_clip_kernel   one workgroup (8 waves) per clip: LinearAE forward of the clip's 16 frames on fp32 MFMA (activations
+//                       transposed in LDS, the cooperative-tile code of p2c_mlp_dev.h) -> y^T stays in LDS -> the
+//                       time-parallel pose head (one 32-lane group per frame, lane = joint: 6-D -> R, cumulative-rotation
+//                       scan through LDS, FK by pointer doubling, projection, normaliser, loc_2d + loc_3d) and its
+//                       tangent-space backward (p2c_pose_head_dev.h) -> grad_y^T written back into the same LDS rows ->
+//                       the dgrad chain. Leaves: the per-clip loss sums and the clip's weight-gradient FACTORS
+//                       (H_0..H_5, G_1..G_6 transposed, 532 rows x 16 samples = 34 KB).
+//   train_wgrad_kernel  one workgroup (16 waves) per 16x16 tile of dW_aug = G^T [H | 1]: contracts the factors over ALL
+//                       clips in a fixed order, applies AdamW to the tile's parameters in place (p2c_adam_math.h) and
+//                       refreshes the packed weight image; one extra workgroup finishes the loss reduction (fp64, fixed
+//                       order). No atomics on data, bitwise reproducible.
+//
+// Arithmetic and summation orders are those of the separate kernels (mlp_fwd / pose_head_rot_bwd_tangent_tp<TRAIN> /
+// mlp_bwd<FACTORS> / mlp_wgrad + mlp_reduce_small / loss_finalize): at a batch where those run the split weight gradient
+// the two paths produce bit-identical losses, gradients and parameters (tests/test_train_fused_gpu.py).
+// The number of unmasked 2-D target pairs (the loc_2d denominator, utils/tensors.py:29-40) is a property of the targets
+// alone: p2c_count_target_pairs computes it when a batch is staged, not per step.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+#include "../../include/p2c.h"
+#include "p2c_adam_math.h"
+#include "p2c_mlp_dev.h"
+#include "p2c_pose_head_dev.h"
+
+int p2c_internal_validate_pose_head(const p2c_pose_head_desc *d);   // p2c_pose_head.hip
+
+namespace p2c_train {
+
+using namespace p2c_mlp;
+namespace ph = p2c;
+
+using S = LinearAE156;                       // 52 -> 26 -> 13 -> 6 -> 39 -> 78 -> 156 (linear_ae.py:25-40, 6-D output)
+constexpr int NLAY = S::NLAY;
+constexpr int T_MAX = TS;                    // one clip = one sample tile
+constexpr int PLANE = T_MAX * ph::GROUP * 9; // one plane of the cumulative-rotation scan (floats)
+constexpr int H_ROWS = S::h_off(NLAY);       // rows of H_0 .. H_{L-1}
+constexpr int G_ROWS = S::act_rows() - S::h_off(1);   // rows of G_1 .. G_L
+constexpr int ACT_FLOATS = (H_ROWS + G_ROWS) * TP;
+static_assert((S::h_off(NLAY) - S::h_off(1)) * TP >= PLANE, "scan plane 1 aliases the rows of G_1 .. G_{L-1}");
+static_assert(S::dim_at(NLAY) == ph::J * 6, "the last layer is the (26, 6) rotation output");
+constexpr int SCRATCH = 64;
+constexpr int LDS_FLOATS = S::w_total() + ACT_FLOATS + PLANE + SCRATCH;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+// factor block of one clip: rows [H_0 .. H_{L-1} | G_1 .. G_L], 16 samples (64 B) per row
+__host__ __device__ constexpr int f_h_off(int l) {
+  int r = 0;
+  for (int i = 0; i < l; ++i) r += S::dim_at(i);
+  return r;
+}
+constexpr int F_HALF = f_h_off(NLAY);
+__host__ __device__ constexpr int f_g_off(int l) {
+  int r = F_HALF;
+  for (int i = 1; i < l; ++i) r += S::dim_at(i);
+  return r;
+}
+constexpr int F_ROWS = f_g_off(NLAY) + S::dim_at(NLAY);
+
+// geometry of the packed weight image for a layer index known only at run time
+__device__ __forceinline__ int image_w_off(int l) {
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < NLAY; ++i)
+    if (i == l) r = S::w_off(i);
+  return r;
+}
+__device__ __forceinline__ int image_ld(int l) {
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < NLAY; ++i)
+    if (i == l) r = S::ld(i);
+  return r;
+}
+
+// inclusive scan over the frames of the clip, P_t = c_t c_{t-1} ... c_0 (the order of p2c::scan_time), ping-pong planes
+__device__ __forceinline__ ph::M3 scan_time2(ph::M3 P, int t, int j, int T, float *p0, float *p1) {
+  float *cur = p0, *oth = p1;
+  for (int off = 1; off < T; off <<= 1) {
+    float *mine = cur + (t * ph::GROUP + j) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) mine[i] = P.m[i];
+    lds_barrier();
+    if (t >= off) {
+      const float *q = cur + ((t - off) * ph::GROUP + j) * 9;
+      ph::M3 Q;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Q.m[i] = q[i];
+      P = ph::mul(P, Q);
+    }
+    float *tmp = cur;
+    cur = oth, oth = tmp;
+  }
+  return P;
+}
+
+struct ClipArgs {
+  const float *x;          // (B*T, 52) model input
+  const float *w_image;    // packed weight image (p2c_mlp_pack layout), current
+  const float *counts;     // (B) unmasked 2-D target pairs per clip
+  float *factors;          // (B, F_ROWS, 16)
+};
+
+template <int KIND>
+__global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_head_desc d, const ph::GradLosses gl,
+                                                                const ClipArgs m) {
+  using K = ph::KindTraits<KIND>;
+  static_assert(K::SIXD, "the fused step is for the 6-D kinds");
+  extern __shared__ float lds[];
+  const S sh;
+  Lane L;
+  L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4;
+  L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int nl = NLAY;
+  constexpr int total4 = S::w_total() >> 2;
+  float *H = lds + S::w_total();
+  float *G = H + (S::h_off(nl) - S::h_off(1)) * TP;        // G_l lives at row h_off(l) of this base (l = 1..L)
+  float *Y = G + S::h_off(nl) * TP;                        // y^T, later grad_y^T (= G_L)
+  float *plane0 = H + ACT_FLOATS, *plane1 = G + S::h_off(1) * TP;
+  float *scratch = plane0 + PLANE;
+  const int clip = blockIdx.x, T = d.T;
+
+  // ---- loads: x tile, first image rounds, then what the pose head will need (all in flight during the MLP forward) ----
+  TileRegs xr;
+  ImageRegs wr;
+  const int64_t row0 = (int64_t)clip * T;
+  tile_issue(m.x, row0, row0 + T, S::dims(0), true, xr);
+  stage_issue(m.w_image, total4, wr, 0, 0, issue_mark<S>(1));
+  int t;
+  const ph::LaneCtx PL = ph::make_lane_tp(d, t);
+  ph::V3 l = ph::v3(0.f, 0.f, 0.f);
+  ph::M3 Rref = ph::identity();
+  if (PL.j < ph::J) {
+    const int st = d.skel_type[clip];
+    const float *pl = d.ref_rel_loc + ((size_t)st * ph::J + PL.j) * 3;
+    l = ph::v3(pl[0], pl[1], pl[2]);
+    if (K::SCAN) {
+      const float *pr = d.ref_rel_rot + ((size_t)st * ph::J + PL.j) * 9;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rref.m[i] = pr[i];
+    }
+  }
+  float g2[2] = {0.f, 0.f}, g3[3] = {0.f, 0.f, 0.f};
+  {
+    const size_t frame = (size_t)clip * T + t;
+    if (PL.has2) {
+      const float *p = d.gt2d + (frame * d.gt2d_joints + PL.gm2) * d.gt2d_channels;
+      g2[0] = p[0], g2[1] = p[1];
+    }
+    if (PL.has3) {
+      const float *p = d.gt3d + (frame * d.gt3d_joints + PL.gm3) * 3;
+      g3[0] = p[0], g3[1] = p[1], g3[2] = p[2];
+    }
+  }
+  float cnt = 0.f;                            // small integers held in floats: exact in any order
+  for (int i = threadIdx.x; i < d.B; i += blockDim.x) cnt += m.counts[i];
+  init_rows(H, S::h_off(0) + S::dims(0), S::h_off(0) + k_rows(S::dims(0)), S::h_off(0) + S::dims(0));
+
+  // ---- LinearAE forward of the clip's frames (mlp_fwd_kernel's first-tile schedule); the last layer writes y^T to LDS ----
+  tile_commit(S::dims(0), true, xr, H + S::h_off(0) * TP);
+  for_layers(sh, 0, nl, [&](int ll) {
+    stage_commit(total4, wr, lds, 0, ll == 0 ? 0 : rounds_upto<S>(ll - 1), rounds_upto<S>(ll));
+    lds_barrier();
+    stage_issue(m.w_image, total4, wr, 0, issue_mark<S>(ll + 1), issue_mark<S>(ll + 2));
+    const bool last = (ll == nl - 1);
+    layer_forward(L, lds + S::w_off(ll), S::ld(ll), S::dims(ll), S::dims(ll + 1), !last, H + S::h_off(ll) * TP,
+                  last ? Y : H + S::h_off(ll + 1) * TP, nullptr, false, false);
+  });
+  lds_barrier();
+
+  // ---- pose head of frame t (this 32-lane group), forward + backward: pose_head_rot_bwd_tangent_tp<KIND, TRAIN> ----
+  float y6[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};              // identity rotation for idle lanes
+  if (PL.active) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) y6[i] = Y[(PL.j * 6 + i) * TP + t];
+  }
+  float coef2 = 0.f, coef3 = 0.f;
+  {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (L.lane == 0) scratch[L.wave] = cnt;
+  }
+  ph::SixD s;
+  const ph::M3 c = ph::rot6d_fwd(y6, s);
+  ph::M3 R = c;
+  if (K::SCAN) R = ph::mul(scan_time2(c, t, PL.j, T, plane0, plane1), Rref);     // (its barriers also publish scratch[])
+  else lds_barrier();
+  {
+    float n2 = 0.f;
+    for (int w = 0; w < WAVES; ++w) n2 += scratch[w];
+    ph::loss_coefs_n(d, gl, n2, ph::n3_elems(d), coef2, coef3);
+  }
+  ph::M3 A = R;
+  ph::V3 x = l;
+  ph::fk_doubling(PL, A, x);
+  const ph::World W = ph::world_at(d, PL, t);
+  ph::HeadAcc acc{0.f, 0.f, 0.f};
+  ph::V3 F = ph::frame_head<ph::MODE_TRAIN>(d, PL, t, x, W, acc, coef2, coef3, nullptr, nullptr, g2, g3);
+  {   // this clip's loss sums, waves added in frame order
+    const float s2 = ph::wave_sum(acc.sum2), c2 = ph::wave_sum(acc.cnt2), s3 = ph::wave_sum(acc.sum3);
+    float *red = scratch + 16;
+    if (L.lane == 0) red[L.wave * 3 + 0] = s2, red[L.wave * 3 + 1] = c2, red[L.wave * 3 + 2] = s3;
+    lds_barrier();
+    if (threadIdx.x == 0) {
+      float a = 0.f, b = 0.f, cc = 0.f;
+      for (int w = 0; w < WAVES; ++w) a += red[w * 3], b += red[w * 3 + 1], cc += red[w * 3 + 2];
+      float *p = d.partials + (size_t)clip * 4;
+      p[0] = a, p[1] = b, p[2] = cc, p[3] = 0.f;
+    }
+  }
+  ph::V3 FX = ph::cross(F, x);
+  ph::V3 PF = ph::v3(ph::group_prefix(F.x), ph::group_prefix(F.y), ph::group_prefix(F.z));
+  ph::V3 PX = ph::v3(ph::group_prefix(FX.x), ph::group_prefix(FX.y), ph::group_prefix(FX.z));
+  ph::V3 SubF = ph::shfl(PF, PL.base + PL.sub_end) - (PF - F);
+  ph::V3 SubX = ph::shfl(PX, PL.base + PL.sub_end) - (PX - FX);
+  ph::V3 tau = SubX - ph::cross(SubF, x);
+  ph::V3 taup = ph::vmul(ph::vmulT(tau, A), R);   // tau A^T R
+  ph::V3 g = taup;
+  if (K::SCAN) {
+    float *sb = plane0;
+    lds_barrier();    // every group is done reading the scan planes
+    sb[(t * ph::GROUP + PL.j) * 3 + 0] = taup.x, sb[(t * ph::GROUP + PL.j) * 3 + 1] = taup.y, sb[(t * ph::GROUP + PL.j) * 3 + 2] = taup.z;
+    lds_barrier();
+    ph::V3 Ssum = ph::v3(0.f, 0.f, 0.f);
+    for (int tt = T - 1; tt >= t; --tt) {
+      const float *q = sb + (tt * ph::GROUP + PL.j) * 3;
+      Ssum = Ssum + ph::v3(q[0], q[1], q[2]);
+    }
+    const ph::M3 Rprev = (t > 0) ? ph::mulTN(c, R) : Rref;
+    g = ph::vmulT(Ssum, Rprev);
+  }
+  if (PL.j < ph::J) {
+    float gy6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};             // frames beyond T: no gradient
+    if (PL.active) {
+      if (s.c1 && s.c2) {
+        ph::V3 b3 = ph::v3(c.m[6], c.m[7], c.m[8]);
+        float al = ph::dot(g, s.b1), be = ph::dot(g, s.b2), ga = ph::dot(g, b3);
+        float r1 = ph::frcp(s.n1), r2 = ph::frcp(s.n2);
+        float k3 = (be + al * s.d * r2) * r1, k2 = -ga * r1, k5 = -al * r2;
+        gy6[0] = fmaf(k3, b3.x, k2 * s.b2.x), gy6[1] = fmaf(k3, b3.y, k2 * s.b2.y), gy6[2] = fmaf(k3, b3.z, k2 * s.b2.z);
+        gy6[3] = k5 * b3.x, gy6[4] = k5 * b3.y, gy6[5] = k5 * b3.z;
+      } else {
+        ph::M3 Gm;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          ph::V3 ci = ph::v3(c.m[i * 3], c.m[i * 3 + 1], c.m[i * 3 + 2]);
+          ph::V3 h = ph::cross(ci, g) * 0.5f;
+          Gm.m[i * 3] = h.x, Gm.m[i * 3 + 1] = h.y, Gm.m[i * 3 + 2] = h.z;
+        }
+        ph::rot6d_bwd(s, Gm, gy6);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Y[(PL.j * 6 + i) * TP + t] = gy6[i];   // every y^T read happened before the scan's barriers
+  } else if (PL.j == ph::J) {                                          // padding rows of G_L (the dgrad k loop reads them)
+    for (int r = S::dims(nl); r < pad16(S::dims(nl)); ++r) Y[r * TP + t] = 0.f;
+  }
+
+  // ---- dgrad chain G_l = relu'(H_l) .* (W_l^T G_{l+1}), l = L-1 .. 1 ----
+  for_layers_down(sh, nl - 1, 1, [&](int ll) {
+    lds_barrier();
+    layer_dgrad(L, lds + S::w_off(ll), S::ld(ll), S::dims(ll), S::dims(ll + 1), G + S::h_off(ll + 1) * TP, H + S::h_off(ll) * TP,
+                G + S::h_off(ll) * TP);
+  });
+  lds_barrier();
+
+  // ---- the clip's factors, as they sit in LDS (transposed, 16 samples = 64 B per row) ----
+  f32x4 *fdst = reinterpret_cast<f32x4 *>(m.factors) + (size_t)clip * F_ROWS * 4;
+  auto put = [&](const float *src, f32x4 *dst, int rows) {
+    for (int i = threadIdx.x; i < rows * 4; i += NTH) {
+      const int o = (i >> 2) * TP + (i & 3) * 4;
+      dst[i] = (f32x4){src[o], src[o + 1], src[o + 2], src[o + 3]};
+    }
+  };
+  for_layers(sh, 0, nl, [&](int ll) { put(H + S::h_off(ll) * TP, fdst + f_h_off(ll) * 4, S::dims(ll)); });
+  for_layers(sh, 0, nl, [&](int ll) { put(G + S::h_off(ll + 1) * TP, fdst + f_g_off(ll + 1) * 4, S::dims(ll + 1)); });
+}
+
+// ---- second launch: weight gradient over all clips + optimizer + loss reduction ------------------------------------------
+// Workgroup t < n_tiles_w owns dW tile t. The contraction order is the one of mlp_wgrad_kernel (K split in 8 slices q, eight
+// partial sums w per slice: pair (q, w) walks sample tiles q + 8 w, + 64, ...; the partials are added in w order, then the
+// slices in q order) so that the result is bit-identical to the split weight gradient of p2c_mlp.hip; the 64 pairs are dealt
+// to the 16 waves, 4 accumulators each. Workgroup n_tiles_w runs loss_finalize's reduction.
+constexpr int WG_WAVES = 16, KS = 8, KW = 8, PAIRS = KS * KW, PER_WAVE = PAIRS / WG_WAVES;
+struct WgradArgs {
+  const float *factors;
+  int32_t n_stiles, n_tiles_w;
+  float *gW[NLAY], *gb[NLAY];
+  float *w_image;
+  const float *loss_partials;   // (B, 4) from train_clip_kernel
+  float n3_elems;
+  int32_t has2d, has3d;
+  float *loss_sums, *losses;
+};
+
+__device__ __forceinline__ void finalize_losses(const WgradArgs &a, double (*sh)[256]) {   // = p2c::loss_finalize
+  if (threadIdx.x >= 256) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int i = threadIdx.x; i < a.n_stiles; i += 256) {
+    s0 += (double)a.loss_partials[i * 4 + 0];
+    s1 += (double)a.loss_partials[i * 4 + 1];
+    s2 += (double)a.loss_partials[i * 4 + 2];
+  }
+  sh[0][threadIdx.x] = s0, sh[1][threadIdx.x] = s1, sh[2][threadIdx.x] = s2;
+  // (only the first four waves take part: named barrier semantics are not needed, the other waves have returned)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  for (int s = 128; s > 0; s >>= 1) {
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    if ((int)threadIdx.x < s) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
+      sh[2][threadIdx.x] += sh[2][threadIdx.x + s];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  }
+  if (threadIdx.x == 0) {
+    const double q2 = sh[0][0], n2 = sh[1][0], q3 = sh[2][0];
+    a.loss_sums[0] = (float)q2, a.loss_sums[1] = (float)n2, a.loss_sums[2] = (float)q3, a.loss_sums[3] = a.n3_elems;
+    const float nan = __builtin_nanf("");
+    const float l2 = a.has2d ? (float)(q2 / (2.0 * n2)) : nan;
+    const float l3 = a.has3d ? (float)(q3 / (double)a.n3_elems) : nan;
+    a.losses[0] = l2, a.losses[1] = l3, a.losses[2] = l2 + l3;
+  }
+}
+
+template <bool ADAM>
+__global__ __launch_bounds__(64 * WG_WAVES) void train_wgrad_kernel(const WgradArgs a, const p2c_adamw_desc o) {
+  extern __shared__ float lds[];
+  if ((int)blockIdx.x == a.n_tiles_w) {      // the loss reduction rides on this launch
+    if (threadIdx.x >= 256) return;          // (whole waves leave: the barriers below count the remaining four)
+    finalize_losses(a, reinterpret_cast<double(*)[256]>(lds));
+    return;
+  }
+  f32x4 *red = reinterpret_cast<f32x4 *>(lds);                 // [PAIRS][64]
+  f32x4 *qsum = red + PAIRS * 64;                              // [KS][64]
+  p2c_optim::Coefs *sc = reinterpret_cast<p2c_optim::Coefs *>(qsum + KS * 64);
+  const int lane = threadIdx.x & 63, r = lane & 15, k = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int t = blockIdx.x;
+  constexpr int dims[NLAY + 1] = {S::dim_at(0), S::dim_at(1), S::dim_at(2), S::dim_at(3), S::dim_at(4), S::dim_at(5), S::dim_at(6)};
+  int32_t dd[NLAY + 1];
+#pragma unroll
+  for (int i = 0; i <= NLAY; ++i) dd[i] = dims[i];
+  const TileRef tr = locate_tile(dd, t);
+  const int n_in = dd[tr.l], n_out = dd[tr.l + 1];
+  const int n = tr.ntile * 16 + r, mm = tr.mtile * 16 + r;
+  const bool a_ok = n < n_out, b_ok = mm < n_in, b_one = mm == n_in;
+  int g_row = F_HALF, h_row = 0;                               // first factor row of G_{l+1} / H_l
+  for (int i = 1; i <= tr.l; ++i) g_row += dd[i];
+  for (int i = 0; i < tr.l; ++i) h_row += dd[i];
+  const size_t a_off = (size_t)(g_row + n) * 16 + 4 * k, b_off = (size_t)(h_row + mm) * 16 + 4 * k;
+  const size_t f_tile = (size_t)F_ROWS * 16;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, ones = {1.f, 1.f, 1.f, 1.f};
+  float step = 0.f;
+  if (ADAM) step = *o.step + 1.f;            // read before this workgroup draws its completion ticket
+
+  f32x4 acc[PER_WAVE];
+  int st[PER_WAVE];
+#pragma unroll
+  for (int u = 0; u < PER_WAVE; ++u) {
+    const int p = wave + u * WG_WAVES, q = p / KW, w = p % KW;
+    acc[u] = zero;
+    st[u] = q + KS * w;
+  }
+  constexpr int STEP = KS * KW;              // 64 sample tiles between two visits of a pair
+  for (;;) {
+    bool any = false;
+    f32x4 av[PER_WAVE], bv[PER_WAVE];
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+      const bool live = st[u] < a.n_stiles;
+      any |= live;
+      const float *base = a.factors + (size_t)(live ? st[u] : 0) * f_tile;
+      av[u] = (live && a_ok) ? *reinterpret_cast<const f32x4 *>(base + a_off) : zero;
+      bv[u] = !live ? zero : (b_one ? ones : (b_ok ? *reinterpret_cast<const f32x4 *>(base + b_off) : zero));
+    }
+    if (!any) break;
+#pragma unroll
+    for (int u = 0; u < PER_WAVE; ++u) {
+      if (st[u] < a.n_stiles) {              // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][i], acc[u], 0, 0, 0);
+      }
+      st[u] += STEP;
+    }
+  }
+  if (ADAM && threadIdx.x == 64 * WG_WAVES - 1) *sc = p2c_optim::coefs(o, step);   // fp64 arithmetic of one thread
+#pragma unroll
+  for (int u = 0; u < PER_WAVE; ++u) red[(wave + u * WG_WAVES) * 64 + lane] = acc[u];
+  __syncthreads();
+  if (threadIdx.x < KS * 64) {               // slice q: its eight partials in w order
+    const int q = threadIdx.x >> 6;
+    f32x4 s = red[(q * KW) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < KW; ++w) s += red[(q * KW + w) * 64 + lane];
+    qsum[q * 64 + lane] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {                    // the slices in q order, then the update (= mlp_reduce_small_kernel)
+    f32x4 s = qsum[lane];
+#pragma unroll
+    for (int q = 1; q < KS; ++q) s += qsum[q * 64 + lane];
+    const int m = tr.mtile * 16 + (lane & 15);
+    p2c_optim::Coefs c;
+    if (ADAM) c = *sc;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int nn = tr.ntile * 16 + 4 * (lane >> 4) + rr;
+      if (!(nn < n_out && m <= n_in)) continue;
+      float *gp = (m < n_in) ? a.gW[tr.l] + nn * n_in + m : a.gb[tr.l] + nn;
+      *gp = (ADAM && o.zero_grad) ? 0.f : s[rr];   // zero_grad: the optimizer leaves the gradient buffer zeroed
+      if (ADAM) {
+        const ptrdiff_t off = gp - o.grad;
+        float pv = o.param[off], mv = o.exp_avg[off], vv = o.exp_avg_sq[off];
+        if (o.adamw) p2c_optim::update<true>(c, pv, s[rr], mv, vv);
+        else p2c_optim::update<false>(c, pv, s[rr], mv, vv);
+        o.param[off] = pv, o.exp_avg[off] = mv, o.exp_avg_sq[off] = vv;
+        if (a.w_image) a.w_image[image_w_off(tr.l) + nn * image_ld(tr.l) + m] = pv;    // bias sits in column n_in == m
+      }
+    }
+  }
+  if (ADAM) {                                // the last dW-tile workgroup to finish publishes the new step count
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(o.ticket, 1) == a.n_tiles_w - 1) {
+      *o.step = step;
+      *o.ticket = 0;
+    }
+  }
+}
+
+// per-clip count of the 2-D target pairs the loss will not mask (utils/tensors.py:29-40, loss/loc_2d.py:69-89): a property
+// of the targets alone, computed once per batch
+__global__ __launch_bounds__(256) void count_pairs_kernel(const p2c_pose_head_desc d, float *counts) {
+  __shared__ float sh[4];
+  const int clip = blockIdx.x;
+  float c = 0.f;
+  for (int i = threadIdx.x; i < d.T * ph::J; i += 256) {
+    const int t = i / ph::J, j = i - t * ph::J;
+    const int gm = d.gmap2d[j];
+    if (t < d.t0 || t >= d.t1 || gm < 0 || !d.gt2d) continue;
+    const float *g = d.gt2d + (((size_t)clip * d.T + t) * d.gt2d_joints + gm) * d.gt2d_channels;
+    c += (!d.mask_missing_joints || j == d.hips_lane || ((g[0] != 0.f) && (g[1] != 0.f))) ? 1.f : 0.f;
+  }
+  c = ph::wave_sum(c);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[clip] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+}  // namespace p2c_train
+
+using namespace p2c_train;
+
+static bool shape_is_linear_ae156(const p2c_mlp_desc &m) {
+  if (m.n_layers != NLAY) return false;
+  for (int l = 0; l <= NLAY; ++l)
+    if (m.dims[l] != S::dim_at(l)) return false;
+  return true;
+}
+
+extern "C" int p2c_train_step_supported(const p2c_train_step_desc *d) {
+  if (!d) return 0;
+  const p2c_pose_head_desc &h = d->head;
+  if (h.kind != P2C_KIND_POSE_CHANGES_6D && h.kind != P2C_KIND_RELATIVE_ROT_6D) return 0;
+  if (h.T < 1 || h.T > T_MAX || h.B < 1) return 0;
+  if (!shape_is_linear_ae156(d->mlp) || d->mlp.N != (int64_t)h.B * h.T) return 0;
+  return 1;
+}
+
+extern "C" int64_t p2c_train_step_workspace_floats(const p2c_train_step_desc *d) {
+  if (!p2c_train_step_supported(d)) return 0;
+  return (int64_t)d->head.B * F_ROWS * 16;
+}
+
+extern "C" int p2c_count_target_pairs(const p2c_pose_head_desc *desc, float *counts, void *stream_) {
+  if (!desc || !counts) return P2C_E_NULL;
+  p2c_pose_head_desc d = *desc;
+  if (!d.y) d.y = reinterpret_cast<const float *>(counts);        // not read: only the target-side fields matter here
+  float dummy = 0.f;
+  if (!d.partials) d.partials = &dummy;
+  if (!d.loss_sums) d.loss_sums = &dummy;
+  if (!d.losses) d.losses = &dummy;
+  int rc = p2c_internal_validate_pose_head(&d);
+  if (rc) return rc;
+  hipLaunchKernelGGL(count_pairs_kernel, dim3((unsigned)d.B), dim3(256), 0, (hipStream_t)stream_, d, counts);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int p2c_train_step(const p2c_train_step_desc *desc, const float *const grad_losses_[3], void *stream_) {
+  if (!desc) return P2C_E_NULL;
+  if (!p2c_train_step_supported(desc)) return P2C_E_SHAPE;
+  p2c_pose_head_desc d = desc->head;
+  const p2c_mlp_desc &m = desc->mlp;
+  if (!m.x || !m.w_image || !m.partials || !desc->pair_counts) return P2C_E_NULL;
+  d.y = m.x;                                                      // (validation wants a model output; the kernel never reads it)
+  if (d.out_pose_changes || d.out_projection_2d || d.out_projection_2d_transformed || d.out_shift || d.out_scale ||
+      d.out_relative_pose_loc || d.out_relative_pose_rot || d.out_absolute_pose_loc || d.out_absolute_pose_rot ||
+      d.out_world_loc || d.out_world_rot)
+    return P2C_E_ENUM;                                            // lean outputs only
+  int rc = p2c_internal_validate_pose_head(&d);
+  if (rc) return rc;
+  if ((reinterpret_cast<uintptr_t>(m.x) & 15) || (reinterpret_cast<uintptr_t>(m.w_image) & 15) ||
+      (reinterpret_cast<uintptr_t>(m.partials) & 15))
+    return P2C_E_SHAPE;
+  for (int l = 0; l < NLAY; ++l)
+    if (!m.gW[l] || !m.gb[l] || !m.W[l] || !m.b[l]) return P2C_E_NULL;
+  const bool adam = m.fused_adamw != nullptr;
+  p2c_adamw_desc o{};
+  if (adam) {
+    o = *m.fused_adamw;
+    if (!o.param || !o.grad || !o.exp_avg || !o.exp_avg_sq || !o.step || !o.ticket || !o.hyper) return P2C_E_NULL;
+    int64_t n_params = 0;
+    for (int l = 0; l < NLAY; ++l) {
+      const float *lo = o.grad, *hi = o.grad + o.n;
+      if (m.gW[l] < lo || m.gW[l] + (size_t)m.dims[l + 1] * m.dims[l] > hi || m.gb[l] < lo || m.gb[l] + m.dims[l + 1] > hi)
+        return P2C_E_INDEX;
+      n_params += (int64_t)m.dims[l + 1] * (m.dims[l] + 1);
+    }
+    if (n_params != o.n) return P2C_E_SHAPE;                      // the MLP must be ALL the optimizer optimises (step counter)
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void *)train_clip_kernel<P2C_KIND_POSE_CHANGES_6D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)train_clip_kernel<P2C_KIND_RELATIVE_ROT_6D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)train_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)train_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  if (!m.skip_pack) {
+    rc = p2c_mlp_pack(&m, stream_);
+    if (rc) return rc;
+  }
+  ph::GradLosses gl{{nullptr, nullptr, nullptr}};
+  if (grad_losses_)
+    for (int i = 0; i < 3; ++i) gl.p[i] = grad_losses_[i];
+  ClipArgs ca{m.x, m.w_image, desc->pair_counts, m.partials};
+  const size_t lds_a = (size_t)LDS_FLOATS * sizeof(float);
+  if (d.kind == P2C_KIND_POSE_CHANGES_6D)
+    hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_POSE_CHANGES_6D>, dim3((unsigned)d.B), dim3(64 * WAVES), lds_a, stream, d, gl, ca);
+  else
+    hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_RELATIVE_ROT_6D>, dim3((unsigned)d.B), dim3(64 * WAVES), lds_a, stream, d, gl, ca);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+
+  WgradArgs wa{};
+  wa.factors = m.partials, wa.n_stiles = d.B;
+  int tiles = 0;
+  for (int l = 0; l < NLAY; ++l) {
+    wa.gW[l] = m.gW[l], wa.gb[l] = m.gb[l];
+    tiles += ((m.dims[l + 1] + 15) / 16) * ((m.dims[l] + 1 + 15) / 16);
+  }
+  wa.n_tiles_w = tiles;
+  wa.w_image = adam ? m.w_image : nullptr;
+  wa.loss_partials = d.partials;
+  wa.n3_elems = (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
+  wa.has2d = d.gt2d ? 1 : 0, wa.has3d = d.gt3d ? 1 : 0;
+  wa.loss_sums = d.loss_sums, wa.losses = d.losses;
+  const size_t lds_b = (size_t)(PAIRS + KS) * 64 * sizeof(f32x4) + 256;
+  if (adam) hipLaunchKernelGGL(train_wgrad_kernel<true>, dim3((unsigned)tiles + 1), dim3(64 * WG_WAVES), lds_b, stream, wa, o);
+  else hipLaunchKernelGGL(train_wgrad_kernel<false>, dim3((unsigned)tiles + 1), dim3(64 * WG_WAVES), lds_b, stream, wa, o);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

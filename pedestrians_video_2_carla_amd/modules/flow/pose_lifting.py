@@ -19,7 +19,7 @@ from pedestrians_video_2_carla_amd.data.base.skeleton import get_common_indices
 from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
 from pedestrians_video_2_carla_amd.loss.fused import FusedLosses
 from pedestrians_video_2_carla_amd.modules.flow.base import LitBaseFlow
-from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType
+from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType, TrajectoryModelOutputType
 from pedestrians_video_2_carla_amd.modules.layers.projection import ProjectionModule
 from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE, LinearAEResidual, LinearAEResidualLeaky
 from pedestrians_video_2_carla_amd.modules.movements.seq2seq import (Seq2Seq, Seq2SeqEmbeddings, Seq2SeqResidualA, Seq2SeqResidualB,
@@ -87,6 +87,18 @@ class LitPoseLiftingFlow(LitBaseFlow):
 
     def _on_batch_start(self, batch, batch_idx):
         self.projection.on_batch_start(batch, batch_idx)
+        # per-batch state of the two-launch train step: the number of unmasked 2-D target pairs is a property of the targets
+        # alone (the reference's on_batch_start is where per-batch constants are derived too, projection.py:52-71)
+        self._pair_counts = None
+        plan = self._fused_train_plan(batch[0], batch[1]) if self.training else None
+        if plan is not None:
+            from pedestrians_video_2_carla_amd import ops
+            spec, gt2d, _gt3d = plan
+            # one persistent buffer: a captured step reads this address for every batch staged later
+            buf = getattr(self, '_pair_counts_buf', None)
+            if buf is None or buf.shape[0] != len(batch[0]) or buf.device != batch[0].device:
+                buf = self._pair_counts_buf = torch.zeros(len(batch[0]), dtype=torch.float32, device=batch[0].device)
+            self._pair_counts = ops.count_target_pairs(spec, gt2d, out=buf) if gt2d is not None else buf.zero_()
 
     # ---- fused-path configuration -----------------------------------------------------------------------------------
     def _fusable(self, transform_callable) -> bool:
@@ -126,8 +138,85 @@ class LitPoseLiftingFlow(LitBaseFlow):
                 return k
         return None
 
+    # ---- two-launch train step (csrc/p2c_train.hip) -----------------------------------------------------------------
+    def _fused_train_plan(self, frames, targets):
+        """(PoseHeadSpec, gt2d, gt3d) when this batch can take ``ops.fused_train_step`` -- LinearAE with the 6-D rotation
+        output on CARLA nodes, built-in transform, fusable losses, lean outputs, one clip per 16-sample tile, a small
+        batch (``P2C_FUSED_TRAIN_MAX_B``, default 512: beyond it the persistent kernels win) -- else None.
+        ``P2C_FUSED_TRAIN=0`` turns the path off."""
+        import os
+        from pedestrians_video_2_carla_amd import ops
+        model = self.movements_model
+        if os.environ.get('P2C_FUSED_TRAIN', '1') == '0' or type(model) is not LinearAE or not self.lean_train_outputs:
+            return None
+        if not (frames.is_cuda and frames.dtype == torch.float32 and frames.ndim == 4):
+            return None
+        B, T = frames.shape[0], frames.shape[1]
+        if B > int(os.environ.get('P2C_FUSED_TRAIN_MAX_B', '512')) or model.input_nodes is not CARLA_SKELETON:
+            return None
+        if model.output_type not in (MovementsModelOutputType.pose_changes, MovementsModelOutputType.relative_rot) \
+                or getattr(model, 'rotation_output_format', None) != 'rotation_6d':
+            return None
+        fa = model.fused_args(frames.device)
+        if fa is None or not ops.train_step_supported(fa['dims'], T):
+            return None
+        transform_callable = self.datamodule.transform_callable
+        if not self._fusable(transform_callable):
+            return None
+        names = {name for (name, *_r) in self._losses_to_calculate}
+        gt2d_key = self._gt2d_key(targets) if 'loc_2d' in names else None
+        gt2d = targets[gt2d_key] if gt2d_key else None
+        gt3d = targets.get('absolute_pose_loc') if 'loc_3d' in names else None
+        kind = 'pose_changes_6d' if model.output_type == MovementsModelOutputType.pose_changes else 'relative_rot_6d'
+        absolute = (self.trajectory_model.output_type == TrajectoryModelOutputType.loc_rot
+                    and not bool(getattr(self.trajectory_model, 'is_identity', False)))
+        spec = ops.PoseHeadSpec(kind=kind, world_absolute=absolute, **self._spec_kwargs(transform_callable, targets))
+        return spec, gt2d, gt3d
+
+    def _fused_train_step(self, frames, targets, stage):
+        """The whole train step as one autograd node, or None when the separate kernels have to run."""
+        from pedestrians_video_2_carla_amd import ops
+        counts = getattr(self, '_pair_counts', None)
+        if (stage != 'train' or counts is None or not torch.is_grad_enabled() or ops._DEFER_LOSS_FINALIZE != 2
+                or counts.shape[0] != frames.shape[0]):
+            return None
+        plan = self._fused_train_plan(frames, targets)
+        if plan is None:
+            return None
+        spec, gt2d, gt3d = plan
+        model, traj = self.movements_model, self.trajectory_model
+        self.projection._check_ready(frames)
+        if bool(getattr(traj, 'is_identity', False)):
+            dloc = drot = None
+        else:
+            dloc, drot = traj(frames, targets if self.training and traj.needs_targets else None)
+        fa = model.fused_args(frames.device)
+        losses = ops.fused_train_step(frames, fa['weights'], fa['biases'], spec, self.projection._skel_type, counts,
+                                      dloc=dloc, drot=drot, gt2d=gt2d, gt3d=gt3d, sinks=fa['sinks'], image=fa['image'],
+                                      image_is_current=fa['image_is_current'], fused_optimizer=fa['fused_optimizer'])
+        eval_slice = (slice(None), model.eval_slice)
+        sliced = {'_fused': FusedLosses(losses, model.input_nodes, model.output_nodes, bool(self.mask_missing_joints),
+                                        gt2d is not None, gt3d is not None),
+                  'projection_2d': None, 'pose_inputs': None,
+                  'world_loc_inputs': dloc[eval_slice] if dloc is not None else None,
+                  'world_rot_inputs': drot[eval_slice] if drot is not None else None,
+                  'inputs': frames[eval_slice], 'targets': {k: v[eval_slice] for k, v in targets.items()}}
+        if self.datamodule.transform_callable is not None:
+            sliced['projection_2d_transformed'] = None
+        for k in set(list(_PROJECTION_KEYS) + self._crucial_keys):
+            sliced.setdefault(k, None)
+        if 'world_loc_changes' in targets and 'world_rot_changes' in targets:      # pose_lifting.py:186-194
+            target_world_loc, target_world_rot = calculate_world_from_changes(
+                frames.shape, frames.device, targets['world_loc_changes'], targets['world_rot_changes'])
+            sliced['targets']['world_loc'] = target_world_loc[eval_slice]
+            sliced['targets']['world_rot'] = target_world_rot[eval_slice]
+        return sliced
+
     # ---- the step ---------------------------------------------------------------------------------------------------
     def _inner_step(self, frames, targets, edge_index=None, batch_vector=None, stage='train'):
+        fused = self._fused_train_step(frames, targets, stage)
+        if fused is not None:
+            return fused
         model, traj = self.movements_model, self.trajectory_model
         pose_inputs = model(frames, targets if self.training and model.needs_targets else None,
                             edge_index=None, batch_vector=None)

@@ -90,21 +90,31 @@ class LinearAE(MovementsModelOutputTypeMixin, MovementsModel):
             layers = self._linears()
             ops.mlp_pack([m.weight for m in layers], [m.bias for m in layers], self._image)
 
+    def fused_args(self, device):
+        """What ``ops.fused_mlp`` / ``ops.fused_train_step`` need from this module in its current state (weights, gradient
+        sinks, packed image, optimizer riding on the backward), or None when the ATen path has to run."""
+        from pedestrians_video_2_carla_amd import ops
+        layers = self._linears()
+        dims = [self.__in] + [m.out_features for m in layers]
+        if not (self.fused_mlp and ops.mlp_supported(dims)):
+            return None
+        sinks = None
+        if self.grad_sink and torch.is_grad_enabled() and all(m.weight.grad is not None for m in layers):
+            sinks = [g for m in layers for g in (m.weight.grad, m.bias.grad)]
+        managed = self._image_managed and self._image is not None and self._image.device == device
+        fused_opt = self.fused_optimizer if (sinks is not None and self.training) else None
+        return dict(dims=dims, weights=[m.weight for m in layers], biases=[m.bias for m in layers], sinks=sinks,
+                    image=self._image if managed else None, image_is_current=managed, fused_optimizer=fused_opt)
+
     def forward(self, x, *args, **kwargs):
         lead = x.shape[0:2]
         flat = x.reshape((-1, self.__in))
         if self.fused_mlp and flat.is_cuda and flat.dtype == torch.float32:
             from pedestrians_video_2_carla_amd import ops
-            layers = self._linears()
-            if ops.mlp_supported([self.__in] + [m.out_features for m in layers]):
-                sinks = None
-                if self.grad_sink and torch.is_grad_enabled() and all(m.weight.grad is not None for m in layers):
-                    sinks = [g for m in layers for g in (m.weight.grad, m.bias.grad)]
-                managed = self._image_managed and self._image is not None and self._image.device == flat.device
-                fused_opt = self.fused_optimizer if (sinks is not None and self.training) else None
-                h = ops.fused_mlp(flat, [m.weight for m in layers], [m.bias for m in layers], sinks,
-                                  image=self._image if managed else None, image_is_current=managed,
-                                  fused_optimizer=fused_opt)
+            fa = self.fused_args(flat.device)
+            if fa is not None:
+                h = ops.fused_mlp(flat, fa['weights'], fa['biases'], fa['sinks'], image=fa['image'],
+                                  image_is_current=fa['image_is_current'], fused_optimizer=fa['fused_optimizer'])
                 return self._format_output(h.view(*lead, self.__n_out, self.output_features))
         h = self.__decoder(self.__encoder(flat))
         return self._format_output(h.view(*lead, self.__n_out, self.output_features))

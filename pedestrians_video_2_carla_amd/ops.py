@@ -592,6 +592,8 @@ class FusedMLPFunction(torch.autograd.Function):
             desc.fused_adamw = ctypes.addressof(opt_desc)
         with torch.cuda.device(x.device):
             _lib.check(lib.p2c_mlp_bwd(ctypes.byref(desc), _stream()), 'p2c_mlp_bwd')
+        if ctx.fused_opt is not None:
+            ctx.fused_opt.fused_steps_applied += 1       # the trainer checks that its deferred step really happened
         if ctx.sinks is not None:
             return (None, None, None, None, None, None) + (None,) * (2 * n)
         return (None, None, None, None, None, None, *gws, *gbs)
@@ -640,6 +642,169 @@ def mlp_pack(weights: Sequence[Tensor], biases: Sequence[Tensor], image: Tensor)
     desc.w_image = image.data_ptr()
     with torch.cuda.device(image.device):
         _lib.check(lib.p2c_mlp_pack(ctypes.byref(desc), _stream()), 'p2c_mlp_pack')
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the whole small-batch train step of LitPoseLiftingFlow(LinearAE) in two launches (K13, csrc/p2c_train.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+LINEAR_AE_6D_DIMS = (52, 26, 13, 6, 39, 78, 156)
+FUSED_TRAIN_MAX_T = 16
+
+
+def count_target_pairs(spec: PoseHeadSpec, gt2d: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """(B,) float: per clip, the (frame, joint) pairs inside the eval slice whose 2-D target the loss does not mask
+    (utils/tensors.py:29-40). A property of the targets alone: computed once when a batch is staged. ``out``: write into
+    this (B,) buffer (a captured train step keeps reading the SAME address for every later batch)."""
+    lib = _lib.lib()
+    gt2d = _require_device(gt2d, 'gt2d')
+    if gt2d.ndim != 4 or gt2d.shape[3] < 2:
+        raise RuntimeError(f'gt2d should have shape (B, T, joints, >= 2), got {tuple(gt2d.shape)}')
+    B, T = gt2d.shape[0], gt2d.shape[1]
+    if max(spec.gmap2d) >= gt2d.shape[2]:
+        raise RuntimeError(f'gt2d has {gt2d.shape[2]} joints but the joint map needs index {max(spec.gmap2d)}')
+    d = PoseHeadDesc()
+    d.B, d.T = B, T
+    d.kind, d.transform = KIND[spec.kind], TRANSFORM[spec.transform]
+    d.t0, d.t1 = spec.frames(T)
+    d.mask_missing_joints, d.hips_lane = int(spec.mask_missing_joints), spec.hips_lane
+    d.n_hips = d.n_neck = 1
+    d.hips_idx[0], d.neck_idx[0] = spec.hips_idx[0], spec.neck_idx[0]
+    d.gmap2d[:] = spec.gmap2d
+    d.gmap3d[:] = spec.gmap3d
+    d.n_common2d = sum(1 for v in spec.gmap2d if v >= 0)
+    d.n_common3d = sum(1 for v in spec.gmap3d if v >= 0)
+    d.gt2d, d.gt2d_joints, d.gt2d_channels = gt2d.data_ptr(), gt2d.shape[2], gt2d.shape[3]
+    if out is not None and (tuple(out.shape) != (B,) or out.dtype != torch.float32 or out.device != gt2d.device
+                            or not out.is_contiguous()):
+        raise RuntimeError(f'out should be a contiguous float32 ({B},) tensor on {gt2d.device}')
+    counts = out if out is not None else torch.empty(B, dtype=torch.float32, device=gt2d.device)
+    d.skel_type = counts.data_ptr()                       # not read by the count kernel; validation wants non-NULL tables
+    d.ref_rel_loc = d.ref_rel_rot = d.ref_hn_shift = d.ref_hn_scale = counts.data_ptr()
+    with torch.cuda.device(gt2d.device):
+        _lib.check(lib.p2c_count_target_pairs(ctypes.byref(d), counts.data_ptr(), _stream()), 'p2c_count_target_pairs')
+    return counts
+
+
+class FusedTrainStepFunction(torch.autograd.Function):
+    """(losses (3,), loc_2d, loc_3d, loc_2d_3d) = step(frames; LinearAE parameters): the forward launches NOTHING, the
+    backward runs p2c_train_step (LinearAE forward + pose head forward / backward + dgrad per clip, then weight gradient
+    + optional optimizer step + loss reduction) and FILLS the loss tensor. Only valid where the backward is guaranteed to
+    follow before anyone reads a loss value: inside ``deferred_loss_finalize(2)`` (the trainer's step).
+    ``sinks`` / ``image`` / ``fused_opt``: as FusedMLPFunction."""
+
+    @staticmethod
+    def forward(ctx, x, spec: PoseHeadSpec, skel_type, dloc, drot, gt2d, gt3d, counts, sinks, image, skip_pack,
+                fused_opt, n_layers, *params):
+        lib = _lib.lib()
+        x = _require_device(x, 'frames')
+        skel_type = _require_device(skel_type, 'skel_type', torch.int32)
+        dloc = None if dloc is None else _require_device(dloc, 'world_loc_change_batch')
+        drot = None if drot is None else _require_device(drot, 'world_rot_change_batch')
+        gt2d = None if gt2d is None else _require_device(gt2d, 'gt2d')
+        gt3d = None if gt3d is None else _require_device(gt3d, 'gt3d')
+        counts = _require_device(counts, 'pair counts')
+        if x.ndim != 4 or x.shape[2] * x.shape[3] != LINEAR_AE_6D_DIMS[0]:
+            raise RuntimeError(f'frames should have shape (B, T, 26, 2), got {tuple(x.shape)}')
+        B, T = x.shape[0], x.shape[1]
+        y_like = x.new_empty((B, T, J, 6), device='meta')
+        _check_shapes(spec, y_like, skel_type, dloc, drot, gt2d, gt3d)
+        if tuple(counts.shape) != (B,):
+            raise RuntimeError(f'pair counts should have shape ({B},), got {tuple(counts.shape)}')
+        weights = [_require_device(p, 'weight') for p in params[:n_layers]]
+        biases = [_require_device(p, 'bias') for p in params[n_layers:]]
+        f32 = dict(dtype=torch.float32, device=x.device)
+        ctx.bufs = {'partials': torch.empty(B * 4, **f32), 'loss_sums': torch.empty(4, **f32),
+                    'losses': torch.empty(3, **f32)}
+        ctx.spec, ctx.n_layers, ctx.sinks = spec, n_layers, sinks
+        ctx.image, ctx.skip_pack = image, bool(skip_pack)
+        ctx.fused_opt = fused_opt if sinks is not None else None
+        ctx.save_for_backward(x, skel_type, dloc, drot, gt2d, gt3d, counts, *weights, *biases)
+        ctx.set_materialize_grads(False)
+        vec = ctx.bufs['losses']
+        return vec, vec[0], vec[1], vec[2]
+
+    @staticmethod
+    def backward(ctx, g_losses, g0, g1, g2):
+        lib = _lib.lib()
+        n = ctx.n_layers
+        x, skel_type, dloc, drot, gt2d, gt3d, counts, *rest = ctx.saved_tensors
+        weights, biases = rest[:n], rest[n:]
+        spec = ctx.spec
+        B, T = x.shape[0], x.shape[1]
+        scalars = [None if g is None else _require_device(g, 'grad loss') for g in (g0, g1, g2)]
+        if g_losses is not None:
+            g_losses = _require_device(g_losses, 'grad losses')
+            if any(g is not None for g in scalars):
+                g_losses = g_losses + torch.stack([torch.zeros_like(g_losses[0]) if g is None else g for g in scalars])
+            gl = _lib.grad_loss_pointers(vector=g_losses.data_ptr())
+        else:
+            gl = _lib.grad_loss_pointers(*[_ptr(g) for g in scalars])
+        desc = _lib.TrainStepDesc()
+        head = _fill_desc(spec, _MetaPtr((B, T, J, 6), x.device), skel_type, dloc, drot, gt2d, gt3d, ctx.bufs, {})
+        head.y = None
+        desc.head = head
+        m = _mlp_desc(x.reshape(B * T, -1), weights, biases)
+        n_image = lib.p2c_mlp_image_floats(ctypes.byref(m))
+        image, skip_pack = ctx.image, ctx.skip_pack
+        if image is None:
+            image, skip_pack = torch.empty(n_image, dtype=torch.float32, device=x.device), False
+        elif image.numel() != n_image or image.device != x.device or image.dtype != torch.float32:
+            raise RuntimeError('packed weight image of the wrong size / device')
+        m.w_image, m.skip_pack = image.data_ptr(), int(skip_pack)
+        if ctx.sinks is not None:
+            gws, gbs = ctx.sinks[0::2], ctx.sinks[1::2]
+        else:
+            gws = [torch.empty_like(w) for w in weights]
+            gbs = [torch.empty_like(b) for b in biases]
+        for l in range(n):
+            m.gW[l], m.gb[l] = gws[l].data_ptr(), gbs[l].data_ptr()
+        desc.mlp = m
+        desc.pair_counts = counts.data_ptr()
+        if not lib.p2c_train_step_supported(ctypes.byref(desc)):
+            raise _lib.P2CError('p2c_train_step does not cover this shape (LinearAE 52-26-13-6-39-78-156, T <= 16)')
+        ws = torch.empty(lib.p2c_train_step_workspace_floats(ctypes.byref(desc)), dtype=torch.float32, device=x.device)
+        desc.mlp.partials = ws.data_ptr()
+        opt_desc = None
+        if ctx.fused_opt is not None:
+            opt_desc = ctx.fused_opt.descriptor_for_fusion()
+            desc.mlp.fused_adamw = ctypes.addressof(opt_desc)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.p2c_train_step(ctypes.byref(desc), gl, _stream()), 'p2c_train_step')
+        if ctx.fused_opt is not None:
+            ctx.fused_opt.fused_steps_applied += 1
+        head_none = (None,) * 13
+        if ctx.sinks is not None:
+            return head_none + (None,) * (2 * n)
+        return head_none + (*gws, *gbs)
+
+
+class _MetaPtr:
+    """Shape carrier for _fill_desc where the model output never exists in memory (fused train step)."""
+
+    def __init__(self, shape, device):
+        self.shape, self.device = tuple(shape), device
+
+    def data_ptr(self):
+        return 0
+
+
+def train_step_supported(dims: Sequence[int], T: int) -> bool:
+    return tuple(dims) == LINEAR_AE_6D_DIMS and 1 <= T <= FUSED_TRAIN_MAX_T
+
+
+def fused_train_step(frames: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor], spec: PoseHeadSpec,
+                     skel_type: Tensor, counts: Tensor, dloc: Optional[Tensor] = None, drot: Optional[Tensor] = None,
+                     gt2d: Optional[Tensor] = None, gt3d: Optional[Tensor] = None,
+                     sinks: Optional[Sequence[Tensor]] = None, image: Optional[Tensor] = None,
+                     image_is_current: bool = False, fused_optimizer=None) -> 'PoseLosses':
+    """LinearAE + pose head + losses as ONE autograd node whose backward is the two-launch train step (p2c_train_step).
+    Call only inside ``deferred_loss_finalize(2)``: the returned loss tensors are filled by the backward."""
+    if _DEFER_LOSS_FINALIZE != 2:
+        raise _lib.P2CError('fused_train_step needs the deferred_loss_finalize(2) context: its forward computes nothing')
+    res = FusedTrainStepFunction.apply(frames, spec, skel_type, dloc, drot, gt2d, gt3d, counts,
+                                       None if sinks is None else list(sinks), image, image_is_current, fused_optimizer,
+                                       len(weights), *weights, *biases)
+    return PoseLosses(res[0], res[1:4])
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -836,7 +1001,28 @@ def lstm_layer(x: Tensor, h0: Optional[Tensor], c0: Optional[Tensor], w_ih: Tens
 # ----------------------------------------------------------------------------------------------------------------------
 # weight / bias gradient of a dense layer over many rows (K12)
 # ----------------------------------------------------------------------------------------------------------------------
-GRAD_SINKS = False      # set by the flat trainer: weight gradients may be ADDED straight into an existing ``param.grad``
+GRAD_SINKS = False      # inside ``grad_sinks(True)`` (the flat trainer's step): weight gradients may be ADDED straight into an
+                        # existing ``param.grad``
+
+
+class grad_sinks:
+    """Context of one trainer's step: while it is active ``DenseFunction`` / the LSTM ops add their weight gradients
+    straight into ``param.grad`` (views of the trainer's flat gradient buffer) and return none to autograd. Outside of it
+    -- other models in the process, ``torch.autograd.grad``, parameter hooks -- autograd receives the gradients as usual."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global GRAD_SINKS
+        self._prev, GRAD_SINKS = GRAD_SINKS, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global GRAD_SINKS
+        GRAD_SINKS = self._prev
+        return False
+
 
 
 def _sink(p: Tensor) -> Optional[Tensor]:

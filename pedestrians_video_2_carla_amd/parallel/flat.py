@@ -82,6 +82,15 @@ class GradientExchange:
         if self.enabled:
             dist.broadcast(self.flat.flat_param.data, src=src, group=self.group)
 
+    def broadcast_buffers(self, module: torch.nn.Module, src: int = 0):
+        """Module buffers (BatchNorm running statistics of LinearAEResidual ...) from rank ``src``: what Lightning's DDP
+        wrapper does at wrap time (``broadcast_buffers=True``). Per-step re-synchronisation is NOT done: with identical
+        initial buffers the ranks' statistics differ only by their own shards' batches, as under SyncBatchNorm-less DDP
+        between two forward passes."""
+        if self.enabled:
+            for b in module.buffers():
+                dist.broadcast(b, src=src, group=self.group)
+
     def all_reduce_gradients(self):
         if self.enabled:
             dist.all_reduce(self.flat.flat_grad, op=dist.ReduceOp.SUM, group=self.group)

@@ -30,6 +30,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.decoupled = bool(decoupled)
         self.zero_grad_in_step = bool(zero_grad_in_step)
         self.grad_scale = 1.0
+        self.fused_steps_applied = 0              # bumped by every backward that applied this optimizer's step itself
         self._uploaded = None
         self._scatter = None                      # (int32 index per parameter, destination buffer) or None
         self._hyper = torch.zeros(6, dtype=torch.float32, device=p.device)

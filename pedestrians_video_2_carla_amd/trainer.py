@@ -5,9 +5,12 @@ Hook order per step is Lightning's: ``on_train_batch_start`` -> ``training_step`
 Two execution modes:
   * eager: every launch issued from Python;
   * ``use_graph=True``: the step (model forward, HIP pose head forward/backward, optimizer) is captured once into a
-    HIP graph on static batch buffers and replayed -- the launch-bound regime at B=256 (about 50 kernels of a few
-    microseconds each) is exactly what hipGraphs are for. With more than one rank the gradient all-reduce stays outside
-    the graphs (capture A: zero-grad + forward + backward; eager RCCL all-reduce; capture B: optimizer).
+    HIP graph on STATIC batch buffers owned by the trainer and replayed. Every new batch is *staged* first -- copied
+    into the static buffers (one multi-tensor copy) and handed to ``flow.on_train_batch_start`` (per-batch constants:
+    skeleton-type index, target-pair counts) -- outside the graph; passing the same batch object again (a resident
+    batch, as bench.py does) stages nothing. With more than one rank the gradient all-reduce is captured into the
+    step graph when every rank can do so, otherwise it stays outside (capture A: forward + backward; eager RCCL
+    all-reduce; optimizer launch).
 """
 import contextlib
 import os
@@ -45,25 +48,45 @@ def init_distributed(backend: Optional[str] = None) -> Dict[str, int]:
     return {'world_size': world, 'rank': rank, 'local_rank': local_rank}
 
 
+def ranks_agree(ok: bool, device, checksum: Optional[torch.Tensor] = None, group=None) -> bool:
+    """Eager agreement of all ranks on a local outcome: True only if EVERY rank passed ``ok`` and -- when given -- every
+    rank holds the same finite ``checksum`` (a 0-dim float64 tensor). Two small all-reduces (MIN / MAX); every rank must
+    call it the same number of times, whatever happened locally."""
+    chk = checksum.detach().to(device=device, dtype=torch.float64).reshape(()) if (checksum is not None and ok) \
+        else torch.zeros((), dtype=torch.float64, device=device)
+    votes = torch.stack((torch.tensor(1.0 if ok else 0.0, dtype=torch.float64, device=device), chk))
+    lo, hi = votes.clone(), votes.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return bool(lo[0] > 0.5) and bool(torch.isfinite(lo[1])) and bool(torch.isfinite(hi[1])) and float(hi[1]) == float(lo[1])
+
+
 class Trainer:
     def __init__(self, max_steps: int = 100, use_graph: bool = False, device: Optional[torch.device] = None,
-                 flatten: bool = True, log_every_n_steps: int = 0):
+                 flatten: bool = True, log_every_n_steps: int = 0, steps_per_epoch: Optional[int] = None):
         self.max_steps = max_steps
         self.use_graph = use_graph
         self.device = device
         self.flatten = flatten
         self.log_every_n_steps = log_every_n_steps
+        self.steps_per_epoch = steps_per_epoch
         self.datamodule = None
         self.loggers: List = []
         self.global_step = 0
+        self.current_epoch = 0
         self.flat: Optional[FlatParameters] = None
         self.exchange: Optional[GradientExchange] = None
         self.optimizers: List[torch.optim.Optimizer] = []
+        self.lr_schedulers: List[dict] = []
         self._graphs = None
         self._static_loss = None
+        self._static_batch = None
+        self._staged_src = None
         self._unit = None
         self._packed = []
         self._opt_in_backward = False
+        self._fused_seen = 0
+        self._grad_sinks = False
 
     # ------------------------------------------------------------------------------------------------------------
     def setup(self, flow, datamodule):
@@ -77,6 +100,7 @@ class Trainer:
             self.flat = FlatParameters(flow.parameters())
             self.exchange = GradientExchange(self.flat)
             self.exchange.broadcast_parameters(0)
+            self.exchange.broadcast_buffers(flow, 0)      # DDP broadcasts module buffers (BatchNorm statistics) at wrap time
             extra = {}
             if self.flat.flat_param.is_cuda:
                 extra['fused'] = True              # one kernel for the whole (flat) parameter
@@ -85,8 +109,7 @@ class Trainer:
                 for m in flow.modules():
                     if hasattr(m, 'grad_sink'):
                         m.grad_sink = True
-                from pedestrians_video_2_carla_amd import ops as _ops
-                _ops.GRAD_SINKS = True           # K12 adds weight gradients straight into the flat gradient buffer's views
+                self._grad_sinks = True          # K12 adds weight gradients straight into the flat gradient buffer's views
             if len(configs) != 1:
                 raise ValueError('exactly one trainable plugin expected (ZeroTrajectory has no optimizer)')
             self.optimizers = [self.flat.rebuild_optimizer(configs[0]['optimizer'], **extra)]
@@ -98,12 +121,46 @@ class Trainer:
             self._opt_in_backward = (not self.exchange.enabled and os.environ.get('P2C_FUSED_UPDATE', '1') == '1'
                                      and any(m.accept_fused_optimizer(opt, self.flat.flat_param) for m in self._packed
                                              if hasattr(m, 'accept_fused_optimizer')))
+            self._fused_seen = getattr(opt, 'fused_steps_applied', 0)
             if hasattr(opt, 'grad_scale') and self.exchange.enabled:    # FlatAdamW folds the DP averaging into its pass
                 opt.grad_scale = 1.0 / self.exchange.world
                 self.exchange.average_here = False
         else:
             self.optimizers = [c['optimizer'] for c in configs]
+        # LR schedulers (base_model.py:159-199) were built on the plugin's own optimizer: re-bind them to the one that steps
+        self.lr_schedulers = []
+        for c, opt in zip(configs, self.optimizers):
+            sched = c.get('lr_scheduler')
+            if sched is None:
+                continue
+            sched = dict(sched) if isinstance(sched, dict) else {'scheduler': sched}
+            sched.setdefault('interval', 'epoch')        # Lightning's defaults
+            sched.setdefault('frequency', 1)
+            s = sched['scheduler']
+            if s.optimizer is not opt:
+                for g_new, g_old in zip(opt.param_groups, s.optimizer.param_groups):
+                    g_new.setdefault('initial_lr', g_old.get('initial_lr', g_old['lr']))
+                    g_new['lr'] = g_old['lr']
+                s.optimizer = opt
+            self.lr_schedulers.append(sched)
         return self
+
+    def step_lr_schedulers(self, interval: str = 'epoch', monitor: Optional[Dict[str, float]] = None):
+        """What Lightning does at the end of an epoch / step for the configured schedulers. ``monitor``: logged values for
+        ReduceLROnPlateau (``{'val_loss/primary': ...}``); a plateau scheduler whose key is missing is skipped, as Lightning
+        would raise only in strict mode. The captured optimizer launch reads the LR from device memory
+        (FlatAdamW.sync_hyper), so the change reaches graph replays."""
+        count = self.current_epoch if interval == 'epoch' else self.global_step
+        for sched in self.lr_schedulers:
+            if sched['interval'] != interval or count % sched['frequency'] != 0:
+                continue
+            s = sched['scheduler']
+            if isinstance(s, torch.optim.lr_scheduler.ReduceLROnPlateau):
+                value = (monitor or {}).get(sched.get('monitor'))
+                if value is not None:
+                    s.step(value)
+            else:
+                s.step()
 
     def _zero_grad(self):
         if self.flat is not None:
@@ -114,7 +171,7 @@ class Trainer:
             for o in self.optimizers:
                 o.zero_grad(set_to_none=True)
 
-    def _forward_backward(self, flow, batch, batch_idx):
+    def _forward_backward(self, flow, batch, batch_idx, batch_start: bool = True):
         self._zero_grad()
         # forward and backward happen back to back in here and nothing reads a loss VALUE in between (the reference's
         # per-loss isnan check is off unless strict_nan_check): the pose head may leave the last stage of its loss
@@ -123,8 +180,9 @@ class Trainer:
         mode = int(os.environ.get('P2C_DEFER_FINALIZE', '2'))      # 2: the pose head runs once per step, in the backward
         defer = batch[0].is_cuda and not getattr(flow, 'strict_nan_check', False) and mode != 0
         from pedestrians_video_2_carla_amd import ops
-        with (ops.deferred_loss_finalize(mode) if defer else contextlib.nullcontext()):
-            flow.on_train_batch_start(batch, batch_idx)
+        with (ops.deferred_loss_finalize(mode) if defer else contextlib.nullcontext()), ops.grad_sinks(self._grad_sinks):
+            if batch_start:
+                flow.on_train_batch_start(batch, batch_idx)
             out = flow.training_step(batch, batch_idx)
             loss = out['loss']
             if self._unit is None or self._unit.shape != loss.shape or self._unit.device != loss.device:
@@ -133,10 +191,58 @@ class Trainer:
         return loss.detach()
 
     def _optimizer_step(self):
-        if self._opt_in_backward:       # already applied by the backward launch of the module that owns the parameters
-            return
+        if self._opt_in_backward:
+            # normally applied by the backward launch of the module that owns the parameters -- but only if that launch
+            # really ran this step (module in eval(), host tensors, detached .grad views ... take other paths)
+            applied = self.optimizers[0].fused_steps_applied
+            if applied != self._fused_seen:
+                self._fused_seen = applied
+                return
         for o in self.optimizers:
             o.step()
+
+    # ---- static batch (graph mode) -----------------------------------------------------------------------------------
+    @staticmethod
+    def _batch_tensors(batch):
+        frames, targets, meta = batch
+        out = [('frames', frames)]
+        out += [('targets/' + k, v) for k, v in sorted(targets.items()) if isinstance(v, torch.Tensor)]
+        out += [('meta/' + k, v) for k, v in sorted(meta.items()) if isinstance(v, torch.Tensor)]
+        return out
+
+    def _with_skel_type(self, batch):
+        """meta['skel_type'] as a device tensor (data/carla/reference.py:skeleton_types_from_meta): inside a captured step
+        the per-clip (age, gender) strings cannot be looked at again."""
+        frames, targets, meta = batch
+        if isinstance(meta.get('skel_type'), torch.Tensor) or not ('age' in meta and 'gender' in meta):
+            return batch
+        from pedestrians_video_2_carla_amd.data.carla import reference as ref
+        meta = dict(meta)
+        meta['skel_type'] = ref.skeleton_types_from_meta(meta, batch_size=len(frames), strict=True, device=frames.device)
+        return frames, targets, meta
+
+    def stage_batch(self, flow, batch, batch_idx: int = 0):
+        """Make ``batch`` the content of the static buffers the captured step reads (no-op for the batch OBJECT staged
+        last: a resident batch), then run the flow's per-batch hook on them. Returns the static batch."""
+        if self._static_batch is not None and batch is self._staged_src:
+            return self._static_batch
+        key, batch = batch, self._with_skel_type(batch)
+        if self._static_batch is None:
+            frames, targets, meta = batch
+            clone = lambda d: {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}   # noqa: E731
+            self._static_batch = (frames.clone(), clone(targets), clone(meta))
+        else:
+            src, dst = self._batch_tensors(batch), self._batch_tensors(self._static_batch)
+            if [(k, v.shape, v.dtype) for k, v in src] != [(k, v.shape, v.dtype) for k, v in dst]:
+                raise RuntimeError('graph mode needs batches of one fixed structure: got keys/shapes '
+                                   f'{[(k, tuple(v.shape)) for k, v in src]} after {[(k, tuple(v.shape)) for k, v in dst]}')
+            torch._foreach_copy_([v for _, v in dst], [v for _, v in src])
+            for k, v in batch[2].items():                 # lists of strings etc. travel by reference
+                if not isinstance(v, torch.Tensor):
+                    self._static_batch[2][k] = v
+        self._staged_src = key
+        flow.on_train_batch_start(self._static_batch, batch_idx)
+        return self._static_batch
 
     # ------------------------------------------------------------------------------------------------------------
     def train_step(self, flow, batch, batch_idx: int = 0) -> torch.Tensor:
@@ -147,8 +253,9 @@ class Trainer:
                 self.exchange.all_reduce_gradients()
             self._optimizer_step()
         else:
+            static = self.stage_batch(flow, batch, batch_idx)      # copies only when a NEW batch object arrives
             if self._graphs is None:
-                self._capture(flow, batch, batch_idx)
+                self._capture(flow, static, batch_idx)
             g_fb, g_opt = self._graphs
             for o in self.optimizers:
                 if hasattr(o, 'sync_hyper'):
@@ -163,10 +270,12 @@ class Trainer:
             loss = self._static_loss
         self.global_step += 1
         flow.global_step = self.global_step
+        if self.lr_schedulers:
+            self.step_lr_schedulers('step')
         return loss
 
     def _capture(self, flow, batch, batch_idx):
-        """Capture on the given batch: its tensors become the static input buffers (copy new data into them)."""
+        """Capture on the trainer's static batch (``stage_batch`` fills it; the flow's batch-start hook already ran)."""
         distributed = self.exchange is not None and self.exchange.enabled
         # the warm-up iterations below are real optimisation steps: snapshot parameters + optimizer state and restore
         # them IN PLACE afterwards (the graphs hold the addresses), so that replay #1 is training step #1
@@ -175,7 +284,7 @@ class Trainer:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up outside capture (allocator, lazy inits, autotuning)
             for _ in range(3):
-                self._forward_backward(flow, batch, batch_idx)
+                self._forward_backward(flow, batch, batch_idx, batch_start=False)
                 if distributed:
                     self.exchange.all_reduce_gradients()
                 self._optimizer_step()
@@ -192,7 +301,7 @@ class Trainer:
             g_fb = torch.cuda.CUDAGraph()
         if distributed:
             with torch.cuda.graph(g_fb):
-                self._static_loss = self._forward_backward(flow, batch, batch_idx)
+                self._static_loss = self._forward_backward(flow, batch, batch_idx, batch_start=False)
             if all(hasattr(o, '_descriptor') for o in self.optimizers):
                 g_opt = 'eager'          # FlatAdamW is a single kernel: a direct launch has less latency than a 1-node graph
             else:
@@ -202,32 +311,38 @@ class Trainer:
         else:
             g_opt = None
             with torch.cuda.graph(g_fb):
-                self._static_loss = self._forward_backward(flow, batch, batch_idx)
+                self._static_loss = self._forward_backward(flow, batch, batch_idx, batch_start=False)
                 self._optimizer_step()
         self._graphs = (g_fb, g_opt)
         self._restore(flow, snapshot)
 
     def _capture_with_allreduce(self, flow, batch, batch_idx, graph, snapshot, strict: bool) -> bool:
-        import torch.distributed as dist
+        """Capture forward + backward + all-reduce + optimizer as one graph. The ranks VOTE before anything that carries a
+        collective is replayed: a rank whose capture raised never meets a healthy rank's in-graph all-reduce with its own
+        eager one (collectives of different sizes pair up and the job hangs). Only when every rank captured does the
+        verification replay run, followed by a second agreement on bit-identical parameters."""
         ok, err = True, None
+        fail_rank = os.environ.get('P2C_TEST_FAIL_CAPTURE_RANK')        # tests: make one rank's capture fail
         try:
+            if fail_rank is not None and int(fail_rank) == dist.get_rank():
+                raise RuntimeError('capture failure requested by P2C_TEST_FAIL_CAPTURE_RANK')
             with torch.cuda.graph(graph):
-                self._static_loss = self._forward_backward(flow, batch, batch_idx)
+                self._static_loss = self._forward_backward(flow, batch, batch_idx, batch_start=False)
                 self.exchange.all_reduce_gradients()
                 self._optimizer_step()
-            graph.replay()                      # one real step: every rank must come out with the same parameters
-            torch.cuda.synchronize()
         except Exception as e:                  # noqa: BLE001 -- any failure means "use the eager collective"
             ok, err = False, e
+        torch.cuda.synchronize()                # a capture that aborted mid-way leaves nothing in flight behind it
         device = self.flat.flat_param.device if self.flat is not None else next(flow.parameters()).device
-        params = self.flat.flat_param.data if self.flat is not None else torch.cat([p.data.reshape(-1) for p in flow.parameters()])
-        chk = params.double().sum() if ok else torch.zeros((), dtype=torch.float64, device=device)
-        votes = torch.stack((torch.tensor(1.0 if ok else 0.0, dtype=torch.float64, device=device), -chk, chk))
-        lo = votes.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)           # eager collectives: agreement on the outcome
-        hi = votes.clone()
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        agreed = bool(lo[0] > 0.5) and bool(torch.isfinite(chk)) and float(hi[2]) == float(lo[2])
+        agreed = ranks_agree(ok, device)        # eager collectives on the (non-capturing) current stream
+        if agreed:
+            try:
+                graph.replay()                  # one real step: every rank must come out with the same parameters
+                torch.cuda.synchronize()
+            except Exception as e:              # noqa: BLE001
+                ok, err = False, e
+            params = self.flat.flat_param.data if self.flat is not None else torch.cat([p.data.reshape(-1) for p in flow.parameters()])
+            agreed = ranks_agree(ok, device, params.double().sum())
         self._restore(flow, snapshot)
         if agreed:
             self._graphs = (graph, None)
@@ -259,6 +374,8 @@ class Trainer:
                 t.copy_(s)
             for t in tensors[len(snapshot):]:            # optimizer state created during warm-up: back to step 0
                 t.zero_()
+            if self.flat is not None:
+                self.flat.zero_grad()                    # whatever the warm-up steps left in the gradient buffer
         for m in getattr(self, '_packed', []):           # the parameters were rewritten behind the optimizer's back
             m.repack()
         torch.cuda.synchronize()
@@ -276,4 +393,8 @@ class Trainer:
             losses.append(self.train_step(flow, batch, i))
             if self.log_every_n_steps and (i + 1) % self.log_every_n_steps == 0:
                 flow.check_finite('train')
+            if self.steps_per_epoch and (i + 1) % self.steps_per_epoch == 0:
+                self.current_epoch += 1
+                self.step_lr_schedulers('epoch', {k: float(v) for k, v in getattr(flow, 'logged', {}).items()
+                                                  if isinstance(v, (float, int)) or (isinstance(v, torch.Tensor) and v.ndim == 0)})
         return losses

@@ -29,9 +29,11 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 def test_descriptor_layout_matches_the_header(tmp_path):
     """ctypes mirrors vs the C structs: same size and same offset for every field."""
-    from pedestrians_video_2_carla_amd._lib import AdamWDesc, CollateDesc, DecoderDesc, LstmDesc, MlpDesc, PoseHeadDesc
+    from pedestrians_video_2_carla_amd._lib import (AdamWDesc, CollateDesc, DecoderDesc, LstmDesc, MlpDesc, PoseHeadDesc,
+                                                    TrainStepDesc)
     for cname, ctype in (('p2c_pose_head_desc', PoseHeadDesc), ('p2c_mlp_desc', MlpDesc), ('p2c_adamw_desc', AdamWDesc),
-                         ('p2c_lstm_desc', LstmDesc), ('p2c_decoder_desc', DecoderDesc), ('p2c_collate_desc', CollateDesc)):
+                         ('p2c_lstm_desc', LstmDesc), ('p2c_decoder_desc', DecoderDesc), ('p2c_collate_desc', CollateDesc),
+                         ('p2c_train_step_desc', TrainStepDesc)):
         fields = [f[0] for f in ctype._fields_]
         src = tmp_path / f'{cname}.c'
         body = '\n'.join(f'  printf("{f} %zu\\n", offsetof({cname}, {f}));' for f in fields)

@@ -226,7 +226,7 @@ def test_layer_with_the_default_zero_state(T, B, I, H):
 
 
 def test_weight_gradients_added_straight_into_the_flat_buffer_equal_autograd_accumulation():
-    """Flat trainer (ops.GRAD_SINKS: K12 adds dW into the views of the flat gradient buffer, returns no gradient to autograd)
+    """Flat trainer (ops.grad_sinks: K12 adds dW into the views of the flat gradient buffer, returns no gradient to autograd)
     vs the same model with per-parameter gradients through autograd: every gradient of one Seq2SeqEmbeddings train step."""
     from pedestrians_video_2_carla_amd import ops
     from pedestrians_video_2_carla_amd.data.carla.carla_recorded_synthetic import SyntheticCarlaRecordedDataModule
@@ -239,18 +239,18 @@ def test_weight_gradients_added_straight_into_the_flat_buffer_equal_autograd_acc
     grads = {}
     for flat in (True, False):
         seed_everything(12)
-        ops.GRAD_SINKS = False
         dm = SyntheticCarlaRecordedDataModule(clip_length=16, batch_size=80)      # 1 280 rows: the K12 path (>= 1 024)
         model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d,
                                   p_dropout=0.0)
         flow = LitAutoencoderFlow(movements_model=model, loss_modes=['loc_2d'], transform='hips_neck_bbox')
         trainer = Trainer(device=d, use_graph=False, flatten=flat).setup(flow, dm)
-        assert ops.GRAD_SINKS == flat
+        assert trainer._grad_sinks == flat and not ops.GRAD_SINKS      # a per-trainer context, not a process global
         batch = dm.generate_batch(d)
         flow.train()
-        flow.on_train_batch_start(batch, 0)
-        flow.training_step(batch, 0)['loss'].backward()
+        with ops.grad_sinks(trainer._grad_sinks):                        # what Trainer._forward_backward opens
+            flow.on_train_batch_start(batch, 0)
+            flow.training_step(batch, 0)['loss'].backward()
         grads[flat] = {n: p.grad.detach().clone() for n, p in flow.named_parameters()}
-    ops.GRAD_SINKS = False
+    assert not ops.GRAD_SINKS
     for n in grads[True]:
         close(grads[True][n], grads[False][n], 'grad ' + n, rtol=2e-5)

@@ -1,0 +1,189 @@
+"""GPU: the two-launch train step (csrc/p2c_train.hip, ops.fused_train_step) through the flow and the trainer.
+
+Parity chain: oracle (fp64, CPU) <- separate kernels (tests/test_flow_gpu.py) <- fused step, the last link BITWISE at the
+metric's batch size (same arithmetic, same summation orders), and the fused step directly against the oracle on ragged
+shapes. Graph mode on NEW batches every step == eager (static batch staging)."""
+import copy
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import pose_head as O
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_flow_gpu import close, dev, make  # noqa: E402
+
+
+def _trainer(flow, dm, **kw):
+    from pedestrians_video_2_carla_amd.trainer import Trainer
+    return Trainer(device=dev(), **kw).setup(flow, dm)
+
+
+def _took_fused_path(flow):
+    return getattr(flow, '_pair_counts', None) is not None
+
+
+@pytest.mark.parametrize('otype', ['pose_changes', 'relative_rot'])
+def test_fused_step_is_bit_identical_to_the_separate_kernels(monkeypatch, otype):
+    """B = 256 (one sample tile per CU: the separate path runs its split weight gradient): losses, parameters and both Adam
+    moments after 5 steps are the same BITS with and without the fused step."""
+    results = {}
+    for fused in ('0', '1'):
+        monkeypatch.setenv('P2C_FUSED_TRAIN', fused)
+        flow, dm = make(B=256, otype=otype)
+        trainer = _trainer(flow, dm)
+        batch = dm.generate_batch(dev())
+        losses = [trainer.train_step(flow, batch, i).clone() for i in range(5)]
+        assert _took_fused_path(flow) == (fused == '1')
+        opt = trainer.optimizers[0]
+        st = opt.state[trainer.flat.flat_param]
+        results[fused] = (torch.stack(losses).cpu(), trainer.flat.flat_param.detach().cpu().clone(),
+                          st['exp_avg'].cpu().clone(), st['exp_avg_sq'].cpu().clone(), float(st['step']),
+                          flow.logged['train_loss/loc_2d'].cpu().clone(), flow.logged['train_loss/loc_3d'].cpu().clone())
+    a, b = results['0'], results['1']
+    assert torch.isfinite(a[0]).all() and a[4] == b[4] == 5.0
+    for i, what in enumerate(('losses', 'parameters', 'exp_avg', 'exp_avg_sq')):
+        assert torch.equal(a[i], b[i]), f'{what}: max |diff| {(a[i] - b[i]).abs().max().item():.3e}'
+    assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
+
+
+@pytest.mark.parametrize('B,T,missing,transform', [(5, 16, 0.1, 'hips_neck_bbox'), (33, 7, 0.2, 'hips_neck'),
+                                                   (64, 16, 0.0, 'bbox'), (1, 1, 0.0, 'none')])
+def test_fused_step_matches_cpu_pipeline(monkeypatch, B, T, missing, transform):
+    """loss + every parameter gradient of one fused train step == LinearAE on CPU (fp64) + oracle pose head; ragged batch,
+    clips shorter than the 16-sample tile, every built-in transform, missing joints."""
+    from pedestrians_video_2_carla_amd.data.base.base_transforms import BaseTransforms
+    monkeypatch.setenv('P2C_FUSED_UPDATE', '0')                  # keep the gradients: the optimizer is a separate launch
+    flow, dm = make(B=B, T=T, missing=missing, transform=BaseTransforms[transform])
+    cpu_model = copy.deepcopy(flow.movements_model).double()
+    trainer = _trainer(flow, dm)
+    trainer.optimizers[0].zero_grad_in_step = False
+    batch = dm.generate_batch(dev())
+    frames, targets, meta = batch
+    loss = trainer._forward_backward(flow, batch, 0)
+    torch.cuda.synchronize()
+    assert _took_fused_path(flow)
+    gt2d = targets['projection_2d_transformed' if transform != 'none' else 'projection_2d']
+    o = O.pose_head(cpu_model(frames.double().cpu()), 'pose_changes_6d', meta['skel_type'].cpu(), transform=transform,
+                    gt2d=gt2d.double().cpu(), gt3d=targets['absolute_pose_loc'].double().cpu())
+    o['loc_2d_3d'].backward()
+    close(loss, o['loc_2d_3d'], 'loss')
+    close(flow.logged['train_loss/loc_2d'], o['loc_2d'], 'loc_2d')
+    close(flow.logged['train_loss/loc_3d'], o['loc_3d'], 'loc_3d')
+    # fp32 tolerance rule of tests/test_pose_head_gpu.py: max(1e-4, 2 x the error the fp32 CPU pipeline itself makes)
+    cpu32 = copy.deepcopy(cpu_model).float()
+    o32 = O.pose_head(cpu32(frames.float().cpu()), 'pose_changes_6d', meta['skel_type'].cpu(), transform=transform,
+                      gt2d=gt2d.float().cpu(), gt3d=targets['absolute_pose_loc'].float().cpu())
+    o32['loc_2d_3d'].backward()
+    for (n, p), q, q32 in zip(flow.movements_model.named_parameters(), cpu_model.parameters(), cpu32.parameters()):
+        ref_err = (q32.grad.double() - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-30)
+        close(p.grad, q.grad, n, rtol=max(1e-4, 2 * ref_err))
+
+
+def test_fused_step_with_world_motion_and_body25_targets_matches_separate_kernels(monkeypatch):
+    """Non-identity trajectory (dloc / drot) and an eval slice: fused step vs the separate kernels (tolerance: the two paths
+    run different weight-gradient orders at this batch size)."""
+    from pedestrians_video_2_carla_amd.modules.trajectory.trajectory import TrajectoryModel
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import TrajectoryModelOutputType
+
+    class Drift(TrajectoryModel):
+        output_type = property(lambda self: TrajectoryModelOutputType.changes)
+
+        def configure_optimizers(self):
+            return {}
+
+        def forward(self, x, *a, **k):
+            B, T = x.shape[:2]
+            g = torch.Generator().manual_seed(3)
+            dloc = (torch.randn(B, T, 3, generator=g) * 0.01).to(x.device)
+            ang = (torch.randn(B, T, generator=g) * 0.02).to(x.device)
+            c, s = ang.cos(), ang.sin()
+            z, o = torch.zeros_like(c), torch.ones_like(c)
+            drot = torch.stack((c, -s, z, s, c, z, z, z, o), -1).view(B, T, 3, 3)
+            return dloc, drot
+
+    grads = {}
+    monkeypatch.setenv('P2C_FUSED_UPDATE', '0')
+    for fused in ('0', '1'):
+        monkeypatch.setenv('P2C_FUSED_TRAIN', fused)
+        flow, dm = make(B=24, missing=0.1)
+        flow.trajectory_model = Drift()
+        monkeypatch.setattr(type(flow.movements_model), 'eval_slice', property(lambda self: slice(2, 13)))
+        trainer = _trainer(flow, dm)
+        trainer.optimizers[0].zero_grad_in_step = False
+        batch = dm.generate_batch(dev())
+        loss = trainer._forward_backward(flow, batch, 0)
+        assert _took_fused_path(flow) == (fused == '1')
+        grads[fused] = (loss.clone(), trainer.flat.flat_grad.clone())
+    close(grads['1'][0], grads['0'][0], 'loss', rtol=1e-6)
+    close(grads['1'][1], grads['0'][1], 'flat gradient', rtol=2e-5)
+
+
+@pytest.mark.parametrize('fused', ['0', '1'])
+def test_graph_mode_trains_on_new_batches_like_eager(monkeypatch, fused):
+    """Trainer(use_graph=True) fed a DIFFERENT batch every step == eager on the same 20 batches (static batch staging);
+    a resident batch object is not re-staged."""
+    monkeypatch.setenv('P2C_FUSED_TRAIN', fused)
+    curves = {}
+    for graph in (False, True):
+        flow, dm = make(B=32, missing=0.1)
+        trainer = _trainer(flow, dm, use_graph=graph)
+        losses = []
+        for i, batch in enumerate(dm.train_batches(dev(), 20)):
+            batch[2].pop('skel_type')                                    # the loader's meta: lists of strings only
+            losses.append(trainer.train_step(flow, batch, i).clone())
+        curves[graph] = torch.stack(losses).cpu()
+        if graph:
+            staged = trainer._static_batch
+            before = staged[0].clone()
+            trainer.train_step(flow, batch, 20)                          # same object again: nothing copied
+            assert torch.equal(staged[0], before) and trainer._staged_src is batch
+    assert torch.isfinite(curves[True]).all()
+    assert len(set(curves[False].tolist())) > 15                          # the batches really differ
+    assert torch.equal(curves[True], curves[False]), (curves[True] - curves[False]).abs().max()
+
+
+def test_graph_mode_rejects_a_batch_of_another_structure():
+    flow, dm = make(B=8)
+    trainer = _trainer(flow, dm, use_graph=True)
+    trainer.train_step(flow, dm.generate_batch(dev()), 0)
+    other = dm.generate_batch(dev(), batch_size=4)
+    with pytest.raises(RuntimeError, match='fixed structure'):
+        trainer.train_step(flow, other, 1)
+
+
+def test_fused_step_errors_and_count_kernel():
+    from pedestrians_video_2_carla_amd import _lib, ops
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    gt2d = torch.randn(6, 9, 26, 2, generator=g)
+    gt2d[torch.rand(6, 9, 26, generator=g) < 0.3] = 0.0
+    spec = ops.PoseHeadSpec(kind='pose_changes_6d', eval_slice=(1, 8))
+    counts = ops.count_target_pairs(spec, gt2d.to(d)).cpu()
+    mask = (gt2d != 0).all(-1)
+    mask[..., 1] = True                                                    # hips are never masked (tensors.py:33-38)
+    assert torch.equal(counts, mask[:, 1:8].sum((1, 2)).float())
+    with pytest.raises(_lib.P2CError):                                     # outside the deferred context
+        ops.fused_train_step(torch.zeros(2, 16, 26, 2, device=d), [], [], spec, torch.zeros(2, dtype=torch.int32, device=d),
+                             torch.zeros(2, device=d))
+    assert not ops.train_step_supported([52, 26, 13, 6, 19, 39, 78], 16) and not ops.train_step_supported(ops.LINEAR_AE_6D_DIMS, 17)
+
+
+def test_optimizer_step_is_not_skipped_when_the_fused_backward_did_not_run():
+    """with the optimizer riding on the backward, a step whose module took another path (eval mode) must still be
+    applied -- by the stand-alone optimizer launch."""
+    flow, dm = make(B=16)
+    trainer = _trainer(flow, dm)
+    assert trainer._opt_in_backward
+    batch = dm.generate_batch(dev())
+    trainer.train_step(flow, batch, 0)
+    flow.movements_model.eval()                                            # LinearAE.fused_args: no fused optimizer in eval()
+    before = trainer.flat.flat_param.detach().clone()
+    trainer.train_step(flow, batch, 1)
+    torch.cuda.synchronize()
+    assert float(trainer.optimizers[0].state[trainer.flat.flat_param]['step']) == 2.0
+    assert not torch.equal(before, trainer.flat.flat_param.detach())
