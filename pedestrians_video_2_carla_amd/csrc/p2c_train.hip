@@ -41,6 +41,38 @@ namespace p2c_train {
 using namespace p2c_mlp;
 namespace ph = p2c;
 
+#ifdef P2C_TRAIN_TRACE   // developer build only (tools/traintrace.py): shader-clock stamps of one workgroup per kernel
+static __device__ unsigned long long g_ttrace[2][40];
+#ifndef P2C_TRAIN_TRACE_BLOCK
+#define P2C_TRAIN_TRACE_BLOCK 0
+#endif
+#define TT(k, i)                                                                         \
+  do {                                                                                   \
+    if (blockIdx.x == P2C_TRAIN_TRACE_BLOCK && threadIdx.x == 0) {                       \
+      g_ttrace[k][i] = __builtin_readcyclecounter();                                     \
+      if ((i) == 0 || (i) == 39) g_ttrace[k][(i) == 0 ? 38 : 37] = wall_clock64();      \
+    }                                                                                    \
+  } while (0)
+#ifndef P2C_TRAIN_TRACE_TILE
+#define P2C_TRAIN_TRACE_TILE 60
+#endif
+// second kernel: stamps stay in registers and are written out by the LAST ARRIVER of one tile (the long path)
+#define TB_DECL unsigned long long tb_[40] = {0}; unsigned long long tbw0_ = wall_clock64()
+#define TB(i) tb_[i] = __builtin_readcyclecounter()
+#define TB_DUMP(cond)                                                      \
+  do {                                                                     \
+    if ((cond) && threadIdx.x == 0) {                                      \
+      for (int i_ = 0; i_ < 40; ++i_) g_ttrace[1][i_] = tb_[i_];           \
+      g_ttrace[1][38] = tbw0_, g_ttrace[1][37] = wall_clock64();           \
+    }                                                                      \
+  } while (0)
+#else
+#define TT(k, i)
+#define TB_DECL
+#define TB(i)
+#define TB_DUMP(cond)
+#endif
+
 using S = LinearAE156;                       // 52 -> 26 -> 13 -> 6 -> 39 -> 78 -> 156 (linear_ae.py:25-40, 6-D output)
 constexpr int NLAY = S::NLAY;
 constexpr int T_MAX = TS;                    // one clip = one sample tile
@@ -110,6 +142,9 @@ struct ClipArgs {
   const float *w_image;    // packed weight image (p2c_mlp_pack layout), current
   const float *counts;     // (B) unmasked 2-D target pairs per clip
   float *factors;          // (B, F_ROWS, 16)
+  int32_t *counters;       // arrival tickets of the second launch: zeroed here
+  int32_t n_counters;
+  int32_t identity_maps;   // gmap2d[j] == gmap3d[j] == j for every joint (host-checked)
 };
 
 template <int KIND>
@@ -130,6 +165,7 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   float *plane0 = H + ACT_FLOATS, *plane1 = G + S::h_off(1) * TP;
   float *scratch = plane0 + PLANE;
   const int clip = blockIdx.x, T = d.T;
+  TT(0, 0);
 
   // ---- loads: x tile, first image rounds, then what the pose head will need (all in flight during the MLP forward) ----
   TileRegs xr;
@@ -137,47 +173,65 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   const int64_t row0 = (int64_t)clip * T;
   tile_issue(m.x, row0, row0 + T, S::dims(0), true, xr);
   stage_issue(m.w_image, total4, wr, 0, 0, issue_mark<S>(1));
-  int t;
-  const ph::LaneCtx PL = ph::make_lane_tp(d, t);
-  ph::V3 l = ph::v3(0.f, 0.f, 0.f);
-  ph::M3 Rref = ph::identity();
-  if (PL.j < ph::J) {
-    const int st = d.skel_type[clip];
-    const float *pl = d.ref_rel_loc + ((size_t)st * ph::J + PL.j) * 3;
-    l = ph::v3(pl[0], pl[1], pl[2]);
-    if (K::SCAN) {
-      const float *pr = d.ref_rel_rot + ((size_t)st * ph::J + PL.j) * 9;
-#pragma unroll
-      for (int i = 0; i < 9; ++i) Rref.m[i] = pr[i];
-    }
+  // lane context of the pose head (= p2c::make_lane_tp) -- with identity joint maps (CARLA targets for a CARLA model, the
+  // usual case) nothing in this prologue depends on a loaded value: every load below is issued back to back. (The general
+  // maps are kernel arguments indexed by lane, i.e. vector loads whose result the target addresses wait for.)
+  ph::LaneCtx PL;
+  PL.lane = threadIdx.x & 63, PL.j = PL.lane & 31, PL.base = PL.lane & 32, PL.clip = clip;
+  const int t = (int)(threadIdx.x >> 6) * 2 + (PL.lane >> 5);
+  PL.active = (PL.j < ph::J) && (t < T);
+  if (m.identity_maps) {
+    PL.anc0 = ph::c_parent[PL.j], PL.anc1 = ph::c_anc_r2[PL.j], PL.anc2 = ph::c_anc_r3[PL.j];
+    PL.interior = (ph::kInteriorMask >> PL.j) & 1u;
+    PL.sub_end = ph::c_subtree_end[PL.j];
+    PL.gm2 = PL.gm3 = (PL.j < ph::J) ? PL.j : -1;
+    PL.never_masked = (PL.j == d.hips_lane);
+    PL.has2 = PL.active && d.gt2d;
+    PL.has3 = PL.active && d.gt3d;
+  } else {
+    ph::fill_lane(PL, d);
   }
-  float g2[2] = {0.f, 0.f}, g3[3] = {0.f, 0.f, 0.f};
+  // Every lane loads UNCONDITIONALLY from a clamped (always valid) address and selects afterwards: a load inside a divergent
+  // branch makes the compiler wait for it (and for every older load) at the branch's end.
+  const int jc = PL.j < ph::J ? PL.j : 0, tc = t < T ? t : T - 1;
+  const int st = d.skel_type[clip];
+  float lraw[3], rraw[9];
   {
-    const size_t frame = (size_t)clip * T + t;
-    if (PL.has2) {
-      const float *p = d.gt2d + (frame * d.gt2d_joints + PL.gm2) * d.gt2d_channels;
-      g2[0] = p[0], g2[1] = p[1];
-    }
-    if (PL.has3) {
-      const float *p = d.gt3d + (frame * d.gt3d_joints + PL.gm3) * 3;
-      g3[0] = p[0], g3[1] = p[1], g3[2] = p[2];
-    }
+    const float *pl = d.ref_rel_loc + ((size_t)st * ph::J + jc) * 3;
+    lraw[0] = pl[0], lraw[1] = pl[1], lraw[2] = pl[2];
+    const float *pr = d.ref_rel_rot + ((size_t)st * ph::J + jc) * 9;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) rraw[i] = K::SCAN ? pr[i] : 0.f;
   }
-  float cnt = 0.f;                            // small integers held in floats: exact in any order
-  for (int i = threadIdx.x; i < d.B; i += blockDim.x) cnt += m.counts[i];
+  float g2raw[2], g3raw[3];
+  {
+    const size_t frame = (size_t)clip * T + tc;
+    const float *b2 = d.gt2d ? d.gt2d : d.ref_rel_loc, *b3 = d.gt3d ? d.gt3d : d.ref_rel_loc;   // any readable address
+    const float *p2 = b2 + (PL.has2 ? (frame * d.gt2d_joints + PL.gm2) * d.gt2d_channels : 0);
+    const float *p3 = b3 + (PL.has3 ? (frame * d.gt3d_joints + PL.gm3) * 3 : 0);
+    g2raw[0] = p2[0], g2raw[1] = p2[1];
+    g3raw[0] = p3[0], g3raw[1] = p3[1], g3raw[2] = p3[2];
+  }
+  // pair counts: issued now, consumed after the MLP forward (no add here: an add would wait for every load above)
+  const float c0raw = m.counts[(int)threadIdx.x < d.B ? threadIdx.x : 0];
+  const float c1raw = m.counts[(int)threadIdx.x + NTH < d.B ? threadIdx.x + NTH : 0];
+  if (clip == 0 && (int)threadIdx.x < m.n_counters) m.counters[threadIdx.x] = 0;   // arrival tickets of train_wgrad_kernel
   init_rows(H, S::h_off(0) + S::dims(0), S::h_off(0) + k_rows(S::dims(0)), S::h_off(0) + S::dims(0));
 
   // ---- LinearAE forward of the clip's frames (mlp_fwd_kernel's first-tile schedule); the last layer writes y^T to LDS ----
+  TT(0, 1);
   tile_commit(S::dims(0), true, xr, H + S::h_off(0) * TP);
   for_layers(sh, 0, nl, [&](int ll) {
     stage_commit(total4, wr, lds, 0, ll == 0 ? 0 : rounds_upto<S>(ll - 1), rounds_upto<S>(ll));
     lds_barrier();
+    TT(0, 2 + ll);
     stage_issue(m.w_image, total4, wr, 0, issue_mark<S>(ll + 1), issue_mark<S>(ll + 2));
     const bool last = (ll == nl - 1);
     layer_forward(L, lds + S::w_off(ll), S::ld(ll), S::dims(ll), S::dims(ll + 1), !last, H + S::h_off(ll) * TP,
                   last ? Y : H + S::h_off(ll + 1) * TP, nullptr, false, false);
   });
   lds_barrier();
+  TT(0, 8);
 
   // ---- pose head of frame t (this 32-lane group), forward + backward: pose_head_rot_bwd_tangent_tp<KIND, TRAIN> ----
   float y6[6] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f};              // identity rotation for idle lanes
@@ -186,7 +240,18 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
     for (int i = 0; i < 6; ++i) y6[i] = Y[(PL.j * 6 + i) * TP + t];
   }
   float coef2 = 0.f, coef3 = 0.f;
+  const ph::V3 l = (PL.j < ph::J) ? ph::v3(lraw[0], lraw[1], lraw[2]) : ph::v3(0.f, 0.f, 0.f);
+  ph::M3 Rref = ph::identity();
+  if (K::SCAN && PL.j < ph::J) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rref.m[i] = rraw[i];
+  }
+  const float g2[2] = {PL.has2 ? g2raw[0] : 0.f, PL.has2 ? g2raw[1] : 0.f};
+  const float g3[3] = {PL.has3 ? g3raw[0] : 0.f, PL.has3 ? g3raw[1] : 0.f, PL.has3 ? g3raw[2] : 0.f};
   {
+    const float c0 = (int)threadIdx.x < d.B ? c0raw : 0.f, c1 = (int)threadIdx.x + NTH < d.B ? c1raw : 0.f;
+    float cnt = c0 + c1;                      // small integers held in floats: exact in any order
+    for (int i = threadIdx.x + 2 * NTH; i < d.B; i += NTH) cnt += m.counts[i];
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
     if (L.lane == 0) scratch[L.wave] = cnt;
@@ -196,6 +261,7 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   ph::M3 R = c;
   if (K::SCAN) R = ph::mul(scan_time2(c, t, PL.j, T, plane0, plane1), Rref);     // (its barriers also publish scratch[])
   else lds_barrier();
+  TT(0, 9);
   {
     float n2 = 0.f;
     for (int w = 0; w < WAVES; ++w) n2 += scratch[w];
@@ -207,18 +273,13 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   const ph::World W = ph::world_at(d, PL, t);
   ph::HeadAcc acc{0.f, 0.f, 0.f};
   ph::V3 F = ph::frame_head<ph::MODE_TRAIN>(d, PL, t, x, W, acc, coef2, coef3, nullptr, nullptr, g2, g3);
-  {   // this clip's loss sums, waves added in frame order
+  TT(0, 10);
+  float *red = scratch + 16;
+  {   // this clip's loss sums: per wave now, added in frame order at the very end (the barriers below publish red[])
     const float s2 = ph::wave_sum(acc.sum2), c2 = ph::wave_sum(acc.cnt2), s3 = ph::wave_sum(acc.sum3);
-    float *red = scratch + 16;
     if (L.lane == 0) red[L.wave * 3 + 0] = s2, red[L.wave * 3 + 1] = c2, red[L.wave * 3 + 2] = s3;
-    lds_barrier();
-    if (threadIdx.x == 0) {
-      float a = 0.f, b = 0.f, cc = 0.f;
-      for (int w = 0; w < WAVES; ++w) a += red[w * 3], b += red[w * 3 + 1], cc += red[w * 3 + 2];
-      float *p = d.partials + (size_t)clip * 4;
-      p[0] = a, p[1] = b, p[2] = cc, p[3] = 0.f;
-    }
   }
+  TT(0, 11);
   ph::V3 FX = ph::cross(F, x);
   ph::V3 PF = ph::v3(ph::group_prefix(F.x), ph::group_prefix(F.y), ph::group_prefix(F.z));
   ph::V3 PX = ph::v3(ph::group_prefix(FX.x), ph::group_prefix(FX.y), ph::group_prefix(FX.z));
@@ -240,6 +301,7 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
     const ph::M3 Rprev = (t > 0) ? ph::mulTN(c, R) : Rref;
     g = ph::vmulT(Ssum, Rprev);
   }
+  TT(0, 12);
   if (PL.j < ph::J) {
     float gy6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};             // frames beyond T: no gradient
     if (PL.active) {
@@ -268,12 +330,15 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   }
 
   // ---- dgrad chain G_l = relu'(H_l) .* (W_l^T G_{l+1}), l = L-1 .. 1 ----
+  TT(0, 13);
   for_layers_down(sh, nl - 1, 1, [&](int ll) {
     lds_barrier();
+    TT(0, 14 + ll);
     layer_dgrad(L, lds + S::w_off(ll), S::ld(ll), S::dims(ll), S::dims(ll + 1), G + S::h_off(ll + 1) * TP, H + S::h_off(ll) * TP,
                 G + S::h_off(ll) * TP);
   });
   lds_barrier();
+  TT(0, 20);
 
   // ---- the clip's factors, as they sit in LDS (transposed, 16 samples = 64 B per row) ----
   f32x4 *fdst = reinterpret_cast<f32x4 *>(m.factors) + (size_t)clip * F_ROWS * 4;
@@ -285,19 +350,35 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   };
   for_layers(sh, 0, nl, [&](int ll) { put(H + S::h_off(ll) * TP, fdst + f_h_off(ll) * 4, S::dims(ll)); });
   for_layers(sh, 0, nl, [&](int ll) { put(G + S::h_off(ll + 1) * TP, fdst + f_g_off(ll + 1) * 4, S::dims(ll + 1)); });
+  if (threadIdx.x == 0) {
+    float a = 0.f, b = 0.f, cc = 0.f;
+    for (int w = 0; w < WAVES; ++w) a += red[w * 3], b += red[w * 3 + 1], cc += red[w * 3 + 2];
+    float *pp = d.partials + (size_t)clip * 4;
+    pp[0] = a, pp[1] = b, pp[2] = cc, pp[3] = 0.f;
+  }
+  TT(0, 39);
 }
 
 // ---- second launch: weight gradient over all clips + optimizer + loss reduction ------------------------------------------
-// Workgroup t < n_tiles_w owns dW tile t. The contraction order is the one of mlp_wgrad_kernel (K split in 8 slices q, eight
-// partial sums w per slice: pair (q, w) walks sample tiles q + 8 w, + 64, ...; the partials are added in w order, then the
-// slices in q order) so that the result is bit-identical to the split weight gradient of p2c_mlp.hip; the 64 pairs are dealt
-// to the 16 waves, 4 accumulators each. Workgroup n_tiles_w runs loss_finalize's reduction.
-constexpr int WG_WAVES = 16, KS = 8, KW = 8, PAIRS = KS * KW, PER_WAVE = PAIRS / WG_WAVES;
+// Split-K over ALL CUs with an in-launch combine. Workgroup (t, q) -- q = blockIdx % 8, consecutive workgroups land on
+// consecutive XCDs -- owns dW tile t and the clips st = q (mod 8): the ones train_clip_kernel's workgroups on the SAME XCD
+// wrote a moment ago (speed only: plain stores keep the lines in that XCD's L2). Wave w walks clips q + 8 w, + 64, ... with
+// one accumulator, the eight waves are added in w order through LDS (= mlp_wgrad_kernel). The slice's partial tile is
+// PUBLISHED with write-through (sc1) stores; the workgroup whose ticket on the tile's counter is the last one reads the
+// eight slices back with sc1 loads, adds them in q order (fixed: not arrival order -> bitwise reproducible and identical
+// to mlp_reduce_small_kernel), applies AdamW and refreshes the packed image. Nobody waits on anybody: no spin, no
+// residency assumption (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "Valid forms", row 1: sc1 stores
+// drained by the storing wave -> agent-scope atomic add by one lane -> the last adder loads sc1 after its add returned).
+// The counters are zeroed by train_clip_kernel (previous launch on the stream) and re-armed by the last arriver.
+// One extra workgroup runs loss_finalize's reduction.
+constexpr int WG_WAVES = 8, KS = 8;
 struct WgradArgs {
   const float *factors;
   int32_t n_stiles, n_tiles_w;
   float *gW[NLAY], *gb[NLAY];
   float *w_image;
+  float *slices;                // (KS, n_tiles_w, 64, 4) partial tiles
+  int32_t *counters;            // (n_tiles_w) arrival tickets, zero at launch
   const float *loss_partials;   // (B, 4) from train_clip_kernel
   float n3_elems;
   int32_t has2d, has3d;
@@ -305,7 +386,6 @@ struct WgradArgs {
 };
 
 __device__ __forceinline__ void finalize_losses(const WgradArgs &a, double (*sh)[256]) {   // = p2c::loss_finalize
-  if (threadIdx.x >= 256) return;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   for (int i = threadIdx.x; i < a.n_stiles; i += 256) {
     s0 += (double)a.loss_partials[i * 4 + 0];
@@ -313,17 +393,14 @@ __device__ __forceinline__ void finalize_losses(const WgradArgs &a, double (*sh)
     s2 += (double)a.loss_partials[i * 4 + 2];
   }
   sh[0][threadIdx.x] = s0, sh[1][threadIdx.x] = s1, sh[2][threadIdx.x] = s2;
-  // (only the first four waves take part: named barrier semantics are not needed, the other waves have returned)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
     if ((int)threadIdx.x < s) {
       sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
       sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
       sh[2][threadIdx.x] += sh[2][threadIdx.x + s];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __syncthreads();
   }
   if (threadIdx.x == 0) {
     const double q2 = sh[0][0], n2 = sh[1][0], q3 = sh[2][0];
@@ -337,22 +414,24 @@ __device__ __forceinline__ void finalize_losses(const WgradArgs &a, double (*sh)
 
 template <bool ADAM>
 __global__ __launch_bounds__(64 * WG_WAVES) void train_wgrad_kernel(const WgradArgs a, const p2c_adamw_desc o) {
-  extern __shared__ float lds[];
-  if ((int)blockIdx.x == a.n_tiles_w) {      // the loss reduction rides on this launch
-    if (threadIdx.x >= 256) return;          // (whole waves leave: the barriers below count the remaining four)
-    finalize_losses(a, reinterpret_cast<double(*)[256]>(lds));
+  __shared__ f32x4 red[WG_WAVES][64];
+  __shared__ p2c_optim::Coefs sc;
+  __shared__ int sc_ready;
+  if (threadIdx.x == 0) sc_ready = 0;        // (published by the barrier behind the contraction)
+  if ((int)blockIdx.x == a.n_tiles_w * KS) {   // the loss reduction rides on this launch (256 of the 512 threads)
+    __shared__ double fin[3][256];
+    if (threadIdx.x >= 256) return;            // whole waves leave: the barriers below count the remaining four
+    finalize_losses(a, fin);
     return;
   }
-  f32x4 *red = reinterpret_cast<f32x4 *>(lds);                 // [PAIRS][64]
-  f32x4 *qsum = red + PAIRS * 64;                              // [KS][64]
-  p2c_optim::Coefs *sc = reinterpret_cast<p2c_optim::Coefs *>(qsum + KS * 64);
+  TB_DECL;
+  TB(0);
   const int lane = threadIdx.x & 63, r = lane & 15, k = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int t = blockIdx.x;
-  constexpr int dims[NLAY + 1] = {S::dim_at(0), S::dim_at(1), S::dim_at(2), S::dim_at(3), S::dim_at(4), S::dim_at(5), S::dim_at(6)};
+  const int q = blockIdx.x % KS, t = blockIdx.x / KS;
   int32_t dd[NLAY + 1];
 #pragma unroll
-  for (int i = 0; i <= NLAY; ++i) dd[i] = dims[i];
+  for (int i = 0; i <= NLAY; ++i) dd[i] = S::dim_at(i);
   const TileRef tr = locate_tile(dd, t);
   const int n_in = dd[tr.l], n_out = dd[tr.l + 1];
   const int n = tr.ntile * 16 + r, mm = tr.mtile * 16 + r;
@@ -364,80 +443,110 @@ __global__ __launch_bounds__(64 * WG_WAVES) void train_wgrad_kernel(const WgradA
   const size_t f_tile = (size_t)F_ROWS * 16;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, ones = {1.f, 1.f, 1.f, 1.f};
   float step = 0.f;
-  if (ADAM) step = *o.step + 1.f;            // read before this workgroup draws its completion ticket
+  if (ADAM) step = *o.step + 1.f;            // read at kernel start: before any workgroup can publish the new count
 
-  f32x4 acc[PER_WAVE];
-  int st[PER_WAVE];
+  auto load_a = [&](int st) -> f32x4 {
+    return a_ok ? *reinterpret_cast<const f32x4 *>(a.factors + (size_t)st * f_tile + a_off) : zero;
+  };
+  auto load_b = [&](int st) -> f32x4 {
+    return b_one ? ones : (b_ok ? *reinterpret_cast<const f32x4 *>(a.factors + (size_t)st * f_tile + b_off) : zero);
+  };
+  f32x4 acc = zero;
+  constexpr int UNROLL = 4;
+  const int stride = KS * WG_WAVES;
+  int st = q + KS * wave;
+  for (; st + (UNROLL - 1) * stride < a.n_stiles; st += UNROLL * stride) {   // UNROLL clips in flight
+    f32x4 av[UNROLL], bv[UNROLL];
 #pragma unroll
-  for (int u = 0; u < PER_WAVE; ++u) {
-    const int p = wave + u * WG_WAVES, q = p / KW, w = p % KW;
-    acc[u] = zero;
-    st[u] = q + KS * w;
-  }
-  constexpr int STEP = KS * KW;              // 64 sample tiles between two visits of a pair
-  for (;;) {
-    bool any = false;
-    f32x4 av[PER_WAVE], bv[PER_WAVE];
+    for (int u = 0; u < UNROLL; ++u) av[u] = load_a(st + u * stride), bv[u] = load_b(st + u * stride);
 #pragma unroll
-    for (int u = 0; u < PER_WAVE; ++u) {
-      const bool live = st[u] < a.n_stiles;
-      any |= live;
-      const float *base = a.factors + (size_t)(live ? st[u] : 0) * f_tile;
-      av[u] = (live && a_ok) ? *reinterpret_cast<const f32x4 *>(base + a_off) : zero;
-      bv[u] = !live ? zero : (b_one ? ones : (b_ok ? *reinterpret_cast<const f32x4 *>(base + b_off) : zero));
-    }
-    if (!any) break;
+    for (int u = 0; u < UNROLL; ++u) {
 #pragma unroll
-    for (int u = 0; u < PER_WAVE; ++u) {
-      if (st[u] < a.n_stiles) {              // wave-uniform
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][i], acc[u], 0, 0, 0);
-      }
-      st[u] += STEP;
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][i], acc, 0, 0, 0);
     }
   }
-  if (ADAM && threadIdx.x == 64 * WG_WAVES - 1) *sc = p2c_optim::coefs(o, step);   // fp64 arithmetic of one thread
+  for (; st < a.n_stiles; st += stride) {
+    const f32x4 av = load_a(st), bv = load_b(st);
 #pragma unroll
-  for (int u = 0; u < PER_WAVE; ++u) red[(wave + u * WG_WAVES) * 64 + lane] = acc[u];
-  __syncthreads();
-  if (threadIdx.x < KS * 64) {               // slice q: its eight partials in w order
-    const int q = threadIdx.x >> 6;
-    f32x4 s = red[(q * KW) * 64 + lane];
-#pragma unroll
-    for (int w = 1; w < KW; ++w) s += red[(q * KW + w) * 64 + lane];
-    qsum[q * 64 + lane] = s;
+    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
   }
+  TB(1);
+  red[wave][lane] = acc;
   __syncthreads();
-  if (threadIdx.x < 64) {                    // the slices in q order, then the update (= mlp_reduce_small_kernel)
-    f32x4 s = qsum[lane];
+  if (wave == 1 && ADAM) {                   // the fp64 bias corrections of this step: off wave 0's critical path
+    if (lane == 0) {
+      sc = p2c_optim::coefs(o, step);
+      __hip_atomic_store(&sc_ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;
+  }
+  if (wave != 0) return;
+  f32x4 s = red[0][lane];
 #pragma unroll
-    for (int q = 1; q < KS; ++q) s += qsum[q * 64 + lane];
-    const int m = tr.mtile * 16 + (lane & 15);
-    p2c_optim::Coefs c;
-    if (ADAM) c = *sc;
+  for (int w = 1; w < WG_WAVES; ++w) s += red[w][lane];
+  // what only the tile's last arriver will need is requested now by every slice (a few KB of L2 hits each): the latency
+  // hides behind the publish / ticket round trips. Nobody else writes these words during this launch.
+  const int m = tr.mtile * 16 + (lane & 15);
+  float *gp[4];
+  float pv[4], mv[4], vv[4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
+  for (int rr = 0; rr < 4; ++rr) {
+    const int nn = tr.ntile * 16 + 4 * (lane >> 4) + rr;
+    gp[rr] = (nn < n_out && m <= n_in) ? ((m < n_in) ? a.gW[tr.l] + nn * n_in + m : a.gb[tr.l] + nn) : nullptr;
+    pv[rr] = mv[rr] = vv[rr] = 0.f;
+    if (ADAM && gp[rr]) {
+      const ptrdiff_t off = gp[rr] - o.grad;
+      pv[rr] = o.param[off], mv[rr] = o.exp_avg[off], vv[rr] = o.exp_avg_sq[off];
+    }
+  }
+  // ---- publish this slice's partial tile (16-byte write-through stores), draw the tile's ticket ----
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.slices, 0, KS * a.n_tiles_w * 1024, 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int my_off = (q * a.n_tiles_w + t) * 1024 + lane * 16;
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), rs, my_off, 0, 16);      // aux 16 = sc1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the storing wave drains before it signals
+  int ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(a.counters + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);                 // (the returned value is used: the add has completed)
+  TB(2);
+  if (ticket != KS - 1) return;
+  // ---- last arriver of tile t: every slice is published. Sum in q order, update (= mlp_reduce_small_kernel) ----
+  f32x4 v[KS];
+#pragma unroll
+  for (int qq = 0; qq < KS; ++qq)                                  // sc1 loads: past this CU's L1
+    v[qq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (qq * a.n_tiles_w + t) * 1024 + lane * 16, 0, 16));
+  s = v[0];
+#pragma unroll
+  for (int qq = 1; qq < KS; ++qq) s += v[qq];
+  TB(3);
+  p2c_optim::Coefs c;
+  if (ADAM) {                                // wave 1 of THIS workgroup wrote them long ago (it waits for nobody)
+    while (__hip_atomic_load(&sc_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+    c = sc;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    if (!gp[rr]) continue;
+    *gp[rr] = (ADAM && o.zero_grad) ? 0.f : s[rr];   // zero_grad: the optimizer leaves the gradient buffer zeroed
+    if (ADAM) {
+      const ptrdiff_t off = gp[rr] - o.grad;
+      if (o.adamw) p2c_optim::update<true>(c, pv[rr], s[rr], mv[rr], vv[rr]);
+      else p2c_optim::update<false>(c, pv[rr], s[rr], mv[rr], vv[rr]);
+      o.param[off] = pv[rr], o.exp_avg[off] = mv[rr], o.exp_avg_sq[off] = vv[rr];
       const int nn = tr.ntile * 16 + 4 * (lane >> 4) + rr;
-      if (!(nn < n_out && m <= n_in)) continue;
-      float *gp = (m < n_in) ? a.gW[tr.l] + nn * n_in + m : a.gb[tr.l] + nn;
-      *gp = (ADAM && o.zero_grad) ? 0.f : s[rr];   // zero_grad: the optimizer leaves the gradient buffer zeroed
-      if (ADAM) {
-        const ptrdiff_t off = gp - o.grad;
-        float pv = o.param[off], mv = o.exp_avg[off], vv = o.exp_avg_sq[off];
-        if (o.adamw) p2c_optim::update<true>(c, pv, s[rr], mv, vv);
-        else p2c_optim::update<false>(c, pv, s[rr], mv, vv);
-        o.param[off] = pv, o.exp_avg[off] = mv, o.exp_avg_sq[off] = vv;
-        if (a.w_image) a.w_image[image_w_off(tr.l) + nn * image_ld(tr.l) + m] = pv;    // bias sits in column n_in == m
-      }
+      if (a.w_image) a.w_image[image_w_off(tr.l) + nn * image_ld(tr.l) + m] = pv[rr];    // bias sits in column n_in == m
     }
   }
-  if (ADAM) {                                // the last dW-tile workgroup to finish publishes the new step count
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(o.ticket, 1) == a.n_tiles_w - 1) {
+  TB(4);
+  if (lane == 0) {
+    __hip_atomic_store(a.counters + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+    if (ADAM && atomicAdd(o.ticket, 1) == a.n_tiles_w - 1) {   // the last tile to finish publishes the new step count
       *o.step = step;
       *o.ticket = 0;
     }
   }
+  TB(39);
+  TB_DUMP(t == P2C_TRAIN_TRACE_TILE);
 }
 
 // per-clip count of the 2-D target pairs the loss will not mask (utils/tensors.py:29-40, loss/loc_2d.py:69-89): a property
@@ -470,6 +579,12 @@ static bool shape_is_linear_ae156(const p2c_mlp_desc &m) {
   return true;
 }
 
+#ifdef P2C_TRAIN_TRACE
+extern "C" P2C_API int p2c_debug_train_trace(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_train::g_ttrace), sizeof(unsigned long long) * 80);
+}
+#endif
+
 extern "C" int p2c_train_step_supported(const p2c_train_step_desc *d) {
   if (!d) return 0;
   const p2c_pose_head_desc &h = d->head;
@@ -479,9 +594,11 @@ extern "C" int p2c_train_step_supported(const p2c_train_step_desc *d) {
   return 1;
 }
 
+static constexpr int kTilesW = 79;    // 16x16 tiles of the augmented weight gradients of LinearAE156 (checked below)
+// workspace: [factors (B, F_ROWS, 16) | slices (KS, tiles, 256) | counters (tiles, padded to 128 ints)]
 extern "C" int64_t p2c_train_step_workspace_floats(const p2c_train_step_desc *d) {
   if (!p2c_train_step_supported(d)) return 0;
-  return (int64_t)d->head.B * F_ROWS * 16;
+  return (int64_t)d->head.B * F_ROWS * 16 + (int64_t)KS * kTilesW * 256 + 128;
 }
 
 extern "C" int p2c_count_target_pairs(const p2c_pose_head_desc *desc, float *counts, void *stream_) {
@@ -536,8 +653,6 @@ extern "C" int p2c_train_step(const p2c_train_step_desc *desc, const float *cons
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void *)train_clip_kernel<P2C_KIND_POSE_CHANGES_6D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)train_clip_kernel<P2C_KIND_RELATIVE_ROT_6D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)train_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)train_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
   if (!m.skip_pack) {
@@ -547,7 +662,14 @@ extern "C" int p2c_train_step(const p2c_train_step_desc *desc, const float *cons
   ph::GradLosses gl{{nullptr, nullptr, nullptr}};
   if (grad_losses_)
     for (int i = 0; i < 3; ++i) gl.p[i] = grad_losses_[i];
-  ClipArgs ca{m.x, m.w_image, desc->pair_counts, m.partials};
+  int tiles = 0;
+  for (int l = 0; l < NLAY; ++l) tiles += ((m.dims[l + 1] + 15) / 16) * ((m.dims[l] + 1 + 15) / 16);
+  if (tiles != kTilesW) return P2C_E_SHAPE;
+  float *slices = m.partials + (size_t)d.B * F_ROWS * 16;
+  int32_t *counters = reinterpret_cast<int32_t *>(slices + (size_t)KS * kTilesW * 256);
+  int identity = 1;
+  for (int j = 0; j < P2C_JOINTS; ++j) identity &= (d.gmap2d[j] == j) && (d.gmap3d[j] == j);
+  ClipArgs ca{m.x, m.w_image, desc->pair_counts, m.partials, counters, tiles, identity};
   const size_t lds_a = (size_t)LDS_FLOATS * sizeof(float);
   if (d.kind == P2C_KIND_POSE_CHANGES_6D)
     hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_POSE_CHANGES_6D>, dim3((unsigned)d.B), dim3(64 * WAVES), lds_a, stream, d, gl, ca);
@@ -557,21 +679,17 @@ extern "C" int p2c_train_step(const p2c_train_step_desc *desc, const float *cons
   if (e != hipSuccess) return (int)e;
 
   WgradArgs wa{};
-  wa.factors = m.partials, wa.n_stiles = d.B;
-  int tiles = 0;
-  for (int l = 0; l < NLAY; ++l) {
-    wa.gW[l] = m.gW[l], wa.gb[l] = m.gb[l];
-    tiles += ((m.dims[l + 1] + 15) / 16) * ((m.dims[l] + 1 + 15) / 16);
-  }
-  wa.n_tiles_w = tiles;
+  wa.factors = m.partials, wa.n_stiles = d.B, wa.n_tiles_w = tiles;
+  for (int l = 0; l < NLAY; ++l) wa.gW[l] = m.gW[l], wa.gb[l] = m.gb[l];
   wa.w_image = adam ? m.w_image : nullptr;
+  wa.slices = slices, wa.counters = counters;
   wa.loss_partials = d.partials;
   wa.n3_elems = (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
   wa.has2d = d.gt2d ? 1 : 0, wa.has3d = d.gt3d ? 1 : 0;
   wa.loss_sums = d.loss_sums, wa.losses = d.losses;
-  const size_t lds_b = (size_t)(PAIRS + KS) * 64 * sizeof(f32x4) + 256;
-  if (adam) hipLaunchKernelGGL(train_wgrad_kernel<true>, dim3((unsigned)tiles + 1), dim3(64 * WG_WAVES), lds_b, stream, wa, o);
-  else hipLaunchKernelGGL(train_wgrad_kernel<false>, dim3((unsigned)tiles + 1), dim3(64 * WG_WAVES), lds_b, stream, wa, o);
+  const dim3 grid_b((unsigned)(tiles * KS + 1));
+  if (adam) hipLaunchKernelGGL(train_wgrad_kernel<true>, grid_b, dim3(64 * WG_WAVES), 0, stream, wa, o);
+  else hipLaunchKernelGGL(train_wgrad_kernel<false>, grid_b, dim3(64 * WG_WAVES), 0, stream, wa, o);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
