@@ -5,21 +5,29 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = on_train_batch_start + training_step (LinearAE forward, HIP pose head forward) + backward (HIP pose head
-backward, LinearAE backward) + [one flat RCCL all-reduce of the gradients] + AdamW, on a synthetic CarlaRecorded-shaped
-batch that is resident in HBM before the timed region. Workload at N=1: BASELINE.json's metric configuration
-(B=256 clips per GPU, T=16, J=26, pose_changes output, loss loc_2d_3d); weak scaling: every rank gets its own B clips.
+A "step" = training_step (LinearAE forward, HIP pose head forward) + backward (HIP pose head backward, LinearAE backward)
++ [one flat RCCL all-reduce of the gradients] + AdamW, on a synthetic CarlaRecorded-shaped batch that is resident in HBM
+before the timed region (its per-batch constants -- skeleton-type index, target-pair counts: on_train_batch_start -- are
+derived when the batch is staged). Workload at N=1: BASELINE.json's metric configuration (B=256 clips per GPU, T=16, J=26,
+pose_changes output, loss loc_2d_3d); weak scaling: every rank gets its own B clips. On one GPU at this batch the step is
+two launches (csrc/p2c_train.hip).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
-  step_breakdown  device time of every launch group of the step at the benchmark batch (graph-timed, HIP events)
-  roofline     the launch group that takes the most time in the step: algorithmic bytes (pose head, vs 8 TB/s HBM) or
-               flops (fused MLP, vs the 157.3 TFLOP/s fp32 MFMA peak) per launch / measured duration; `other` = the rest
+  repeat_ms_per_step  p50 / min / max of five more timed blocks of K steps (one hiccup cannot move the headline unseen)
+  fresh_batch_ms_per_step  the same step fed a NEW batch object every iteration: staging copy + batch-start hook + replay
+  step_breakdown_us  device time of every launch of the step at the benchmark batch (graph-timed, HIP events)
+  roofline     the launch that takes the most time in the step: algorithmic flops (vs the 157.3 TFLOP/s fp32 MFMA peak) or
+               bytes (vs 8 TB/s HBM) per launch / measured duration, PMC traffic; `other` = the rest
   roofline_sweep  the pose-head kernels at B = 256, 1024, 8192, 65536 (the step at B=256 is latency-bound by construction)
-  cpu_baseline the op-for-op CPU port of the reference step (oracle/reference_port.py) timed on this host's cores.
+  extra_configs  BASELINE.json configs[1] (B = 1024) and configs[2] (autoencoder, Seq2SeqEmbeddings, B = 512) on this GPU
+  cpu_baseline the op-for-op CPU port of the reference step (oracle/reference_port.py) timed on this host's cores:
+               all cores, one thread, and under torch DDP / gloo with world_size 1, 2, 4, 8 (oracle/ddp_baseline.py).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -49,7 +57,9 @@ def parse():
     p.add_argument('--full-outputs', action='store_true', help='materialise the logging tensors in training_step')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-sweep', action='store_true')
-    p.add_argument('--cpu-seconds', type=float, default=15.0)
+    p.add_argument('--cpu-seconds', type=float, default=12.0)
+    p.add_argument('--no-extra-configs', action='store_true')
+    p.add_argument('--repeats', type=int, default=5)
     return p.parse_args()
 
 
@@ -205,6 +215,48 @@ def mlp_times(device, model, B, fused_update):
     return out, {'mlp_fwd': 2 * macs * N, bwd_name: 2 * macs_bwd * N}
 
 
+def fused_step_times(device, flow, trainer, batch):
+    """Device time of each launch of the two-launch train step (csrc/p2c_train.hip) on the bench's own flow, weights and
+    batch, through the C ABI's measurement hook p2c_train_step_launch: HIP graphs of 20 back-to-back launches on the launch
+    stream, bracketed by HIP events. Returns ({name: us}, {name: algorithmic flops per launch}) or None when the flow does
+    not take the fused step at this batch. (The optimizer really steps: call after the loss has been read.)"""
+    import ctypes
+    from pedestrians_video_2_carla_amd import _lib, ops
+    lib = _lib.lib()
+    frames, targets, _meta = trainer._static_batch if trainer._static_batch is not None else batch
+    flow.train()
+    plan = flow._fused_train_plan(frames, targets) if hasattr(flow, '_fused_train_plan') else None
+    counts = getattr(flow, '_pair_counts', None)
+    if plan is None or counts is None:
+        return None
+    spec, gt2d, gt3d = plan
+    fa = flow.movements_model.fused_args(device)
+    f32 = dict(dtype=torch.float32, device=device)
+    B, T = frames.shape[:2]
+    bufs = {'partials': torch.empty(B * 4, **f32), 'loss_sums': torch.empty(4, **f32), 'losses': torch.empty(3, **f32)}
+    sinks = fa['sinks']
+    if sinks is None:
+        return None
+    desc, keep = ops.train_step_desc(frames, spec, flow.projection._skel_type, None, None, gt2d, gt3d, counts, fa['weights'],
+                                     fa['biases'], sinks[0::2], sinks[1::2], bufs, fa['image'], fa['image_is_current'],
+                                     fa['fused_optimizer'])
+    gl = torch.tensor([0.0, 0.0, 1.0], **f32)
+    out = {}
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        s = stream.cuda_stream
+        glp = _lib.grad_loss_pointers(vector=gl.data_ptr())
+        for name, which in (('train_clip_kernel', 1), ('train_wgrad_kernel(+adamw+loss)', 2), ('train_step(2 launches)', 3)):
+            _lib.check(lib.p2c_train_step_launch(ctypes.byref(desc), glp, 3, s), 'train step')      # valid factors / counters
+            out[name] = _graph_us(lambda: _lib.check(lib.p2c_train_step_launch(ctypes.byref(desc), glp, which, s), name), stream)
+    shapes = [(l.weight.shape[0], l.weight.shape[1]) for l in flow.movements_model._linears()]
+    macs = sum(o * i for o, i in shapes)
+    macs_dgrad = sum(o * i for o, i in shapes[1:])
+    N = B * T
+    flops = {'train_clip_kernel': 2 * (macs + macs_dgrad) * N, 'train_wgrad_kernel(+adamw+loss)': 2 * macs * N}
+    return out, flops
+
+
 def mfma_entry(name, B, us, flops):
     achieved = flops / (us * 1e-6) / 1e12
     return {'kernel': name, 'B': B, 'us_per_launch': round(us, 2), 'bound': 'mfma', 'achieved': round(achieved, 3),
@@ -225,6 +277,56 @@ def load_traffic():
         with open(path) as f:
             return json.load(f)
     return {}
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_ddp_baseline(cores, seconds):
+    """The CPU port under torch DDP / gloo, world_size 1, 2, 4, 8, threads = cores / world_size."""
+    out = {}
+    script = os.path.join(ROOT, 'oracle', 'ddp_baseline.py')
+    # torch's autograd engine opens the GPU in every process that runs a backward (its device-thread set-up asks the HIP
+    # runtime for a device count), and a GPU box admits at most 6 processes on its card: with this process holding it too,
+    # world_size 8 cannot run there. P2C_CPU_DDP_MAX_WORLD=8 on a host without that guard.
+    max_world = int(os.environ.get('P2C_CPU_DDP_MAX_WORLD', '4'))
+    for world in (1, 2, 4, 8):
+        if world > cores:
+            break
+        if world > max_world:
+            out[str(world)] = {'skipped': f'at most {max_world} ranks beside the benchmark process on this box (process guard: 6 '
+                                          f'processes per GPU; every rank\'s autograd engine opens the device)'}
+            continue
+        threads = max(1, cores // world)
+        port = 29650 + world
+        procs = []
+        try:
+            for r in range(world):
+                env = dict(os.environ, OMP_NUM_THREADS=str(threads), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                           RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), HIP_VISIBLE_DEVICES='',
+                           CUDA_VISIBLE_DEVICES='')
+                procs.append(subprocess.Popen([sys.executable, script, '--seconds', str(seconds), '--threads', str(threads)],
+                                              env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                              stderr=subprocess.DEVNULL, text=True))
+            stdout, _ = procs[0].communicate(timeout=seconds * 6 + 120)
+            for pr in procs[1:]:
+                pr.wait(timeout=60)
+            line = [l for l in stdout.splitlines() if l.startswith('{')]
+            out[str(world)] = json.loads(line[-1]) if line else {'error': 'no result line'}
+        except Exception as e:                                      # noqa: BLE001 -- a baseline leg must not sink the bench
+            out[str(world)] = {'error': repr(e)[:200]}
+            for pr in procs:                                        # exactly the processes started here
+                if pr.poll() is None:
+                    pr.kill()
+    return out
 
 
 def cpu_baseline(batch_size, seconds):
@@ -258,10 +360,90 @@ def cpu_baseline(batch_size, seconds):
         dt = time.perf_counter() - t0
         if dt >= seconds or n >= 200:
             break
-    return {'value': round(batch_size * n / dt, 1), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'ms_per_step': round(dt / n * 1e3, 1),
-            'sample': f'{n} steps of B={batch_size},T={T_FRAMES} (op-for-op port of the reference step, eager PyTorch '
-                      f'CPU fp32, {torch.get_num_threads()} threads)'}
+    result = {'value': round(batch_size * n / dt, 1), 'unit': 'clips/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+              'ms_per_step': round(dt / n * 1e3, 1),
+              'sample': f'{n} steps of B={batch_size},T={T_FRAMES} (op-for-op port of the reference step, eager PyTorch '
+                        f'CPU fp32, {torch.get_num_threads()} threads)',
+              'cpu_model': _cpu_model(), 'host_cores': os.cpu_count(),
+              'note': 'optimistic by about 1.8x: the port builds a light per-clip object where the reference builds a '
+                      'ControlledPedestrian + P3dPose + 26 mock transforms per clip (BASELINE.md section 2: 447.6 ms for the '
+                      'real reference vs about 250 ms for this port on the same 8 vCPU)'}
+    # one thread
+    torch.set_num_threads(1)
+    n1, t0 = 0, time.perf_counter()
+    while True:
+        P.port_train_step(model, opt, b['frames'], targets, meta)
+        n1 += 1
+        d1 = time.perf_counter() - t0
+        if d1 >= seconds * 0.6 or n1 >= 50:
+            break
+    result['threads_1'] = {'value': round(batch_size * n1 / d1, 1), 'unit': 'clips/s', 'ms_per_step': round(d1 / n1 * 1e3, 1),
+                           'sample': f'{n1} steps, 1 thread'}
+    torch.set_num_threads(cores)
+    result['gloo_ddp'] = cpu_ddp_baseline(cores, max(4.0, seconds * 0.5))
+    return result
+
+
+def timed_steps(trainer, flow, batches, steps, barrier):
+    """EXACTLY `steps` train steps bracketed by barrier + synchronize; batches[i % len] is fed at step i."""
+    n = len(batches)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = trainer.train_step(flow, batches[i % n], i)
+    barrier()
+    return time.perf_counter() - t0, loss
+
+
+def extra_config(device, name, steps=100, warmup=10):
+    """One more BASELINE.json configuration on this GPU: ms/step and clips/s of its captured train step (resident batch)."""
+    from pedestrians_video_2_carla_amd.data.carla.carla_recorded_synthetic import SyntheticCarlaRecordedDataModule
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.trainer import Trainer, seed_everything
+    seed_everything(22742)
+    if name == 'cfg2':
+        from pedestrians_video_2_carla_amd.modules.flow.pose_lifting import LitPoseLiftingFlow
+        from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE
+        B = 1024
+        model = LinearAE(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON)
+        flow = LitPoseLiftingFlow(movements_model=model, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
+        workload = 'flow=pose_lifting LinearAE(pose_changes) loss=loc_2d_3d clip_length=16 batch_size=1024 (BASELINE.json configs[1])'
+    else:
+        from pedestrians_video_2_carla_amd.modules.flow.autoencoder import LitAutoencoderFlow
+        from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2SeqEmbeddings
+        B = 512
+        model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d)
+        flow = LitAutoencoderFlow(movements_model=model, loss_modes=['loc_2d'], transform='hips_neck_bbox')
+        workload = ('flow=autoencoder Seq2SeqEmbeddings movements_output_type=pose_2d clip_length=16 batch_size=512 '
+                    '(BASELINE.json configs[2])')
+    dm = SyntheticCarlaRecordedDataModule(clip_length=T_FRAMES, batch_size=B)
+    trainer = Trainer(device=device, use_graph=True).setup(flow, dm)
+    batch = dm.generate_batch(device)
+    for i in range(warmup):
+        trainer.train_step(flow, batch, i)
+    torch.cuda.synchronize(device)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for i in range(steps):
+            loss = trainer.train_step(flow, batch, i)
+        torch.cuda.synchronize(device)
+        times.append((time.perf_counter() - t0) / steps)
+    dt = statistics.median(times)
+    out = {'workload': workload, 'B': B, 'ms_per_step': round(dt * 1e3, 4), 'clips_per_s': round(B / dt, 1), 'dtype': 'f32',
+           'hip_graph': True, 'steps': steps, 'final_loss': float(loss)}
+    if name == 'cfg2':
+        out['note'] = ('configs[1] names bf16: the LinearAE runs exact fp32 MFMA (bit-for-bit an fmaf chain); no bf16 arm is '
+                       'built, so no reduced-precision number is claimed')
+        mt, flops = mlp_times(device, model, B, getattr(trainer, '_opt_in_backward', False))
+        out['roofline'] = [mfma_entry(k, B, mt[k], fl) for k, fl in flops.items()]
+    else:
+        # the recurrences (K7b encoder layers, K7c decoder loop) priced against the fp32 MFMA peak: 2*T*B*H*4H flop per
+        # LSTM layer and direction of the data flow (forward; the backward kernels do the same again with W^T)
+        H, T = 64, T_FRAMES
+        out['recurrence_flops_per_layer'] = 2 * T * B * H * 4 * H
+    return out
 
 
 def main():
@@ -284,17 +466,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = trainer.train_step(flow, batch, i)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, loss = timed_steps(trainer, flow, [batch], args.steps, barrier)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss)
+
+    # more timed blocks of the same K steps, and the same step on a NEW batch object every iteration (every rank runs them:
+    # with an exchange in the step the collectives must pair up)
+    repeats = [timed_steps(trainer, flow, [batch], args.steps, barrier)[0] / args.steps * 1e3 for _ in range(max(args.repeats, 0))]
+    fresh = [dm.generate_batch(device, seed_offset=rank + 1000 * (k + 1)) for k in range(8)]
+    timed_steps(trainer, flow, fresh, 16, barrier)
+    fresh_ms = timed_steps(trainer, flow, fresh, args.steps, barrier)[0] / args.steps * 1e3
+    allreduce_us = None
+    if world > 1:
+        # the collective alone, event-timed on the step's stream: what the step pays for the exchange on top of its kernels
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            trainer.exchange.all_reduce_gradients()
+        e0.record()
+        for _ in range(50):
+            trainer.exchange.all_reduce_gradients()
+        e1.record()
+        e1.synchronize()
+        allreduce_us = e0.elapsed_time(e1) * 1e3 / 50
+        trainer.flat.zero_grad()
 
     if rank != 0:
         if world > 1:
@@ -304,6 +501,8 @@ def main():
 
     global_batch = args.batch_size * world
     value = global_batch * args.steps / elapsed
+    cfg_name = {256: 'BASELINE.json metric config', 1024: 'BASELINE.json configs[1]' if world == 1 else
+                'BASELINE.json configs[3]: 8192 global over 8 GPUs' if world == 8 else 'BASELINE.json configs[1]/[3] per-GPU batch'}
     result = {
         'metric': 'clips/sec (B=256,T=16,J=26) pose_lifting train step',
         'value': round(value, 1), 'unit': 'clips/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -311,40 +510,76 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'flow=pose_lifting movements_model=LinearAE(pose_changes) loss=loc_2d_3d '
                                f'transform=hips_neck_bbox clip_length={T_FRAMES} J={JOINTS} batch_size='
-                               f'{args.batch_size}/GPU (BASELINE.json metric config; configs[1]/[3] = --batch-size 1024)',
+                               f'{args.batch_size}/GPU ({cfg_name.get(args.batch_size, "custom batch")}; configs[1]/[3] = '
+                               f'--batch-size 1024)',
                    'global_batch': global_batch, 'per_gpu_batch': args.batch_size, 'parallelism': f'dp{world}',
                    'hip_graph': not args.no_graph, 'lean_train_outputs': not args.full_outputs,
-                   'deferred_loss_finalize': os.environ.get('P2C_DEFER_FINALIZE', '1') != '0',
+                   'deferred_loss_finalize': os.environ.get('P2C_DEFER_FINALIZE', '2') != '0',
+                   'two_launch_step': getattr(flow, '_pair_counts', None) is not None,
                    'grad_allreduce_bytes': trainer.flat.nbytes(), 'final_loss': final_loss},
     }
+    if repeats:
+        result['repeat_ms_per_step'] = {'n': len(repeats), 'p50': round(statistics.median(repeats), 4),
+                                        'min': round(min(repeats), 4), 'max': round(max(repeats), 4)}
+    result['fresh_batch_ms_per_step'] = round(fresh_ms, 4)
+    if allreduce_us is not None:
+        result['allreduce_us'] = round(allreduce_us, 2)
+
     traffic = load_traffic()
-    kt = kernel_times(device, args.batch_size)
-    names = {'fwd': 'pose_head_rot_fwd<6D>(+loss_finalize)', 'bwd': 'pose_head_rot_bwd<6D>'}
-    per_clip = {'fwd': BYTES_FWD, 'bwd': BYTES_BWD}
-    entries = {names[w]: roofline_entry(names[w], args.batch_size, kt[w], per_clip[w],
-                                        (traffic.get(f'{names[w]}@B{args.batch_size}') or {}).get('bytes')) for w in ('fwd', 'bwd')}
-    if int(os.environ.get('P2C_DEFER_FINALIZE', '2')) == 2 and args.batch_size <= 2048:
-        breakdown = {'pose_head_train(count + fwd/bwd in one kernel + finalize)': round(kt['train'], 2)}
+    B = args.batch_size
+
+    def with_traffic(entry):
+        entry['traffic'] = (traffic.get(f'{entry["kernel"]}@B{B}') or {}).get('bytes')
+        return entry
+
+    entries, breakdown = {}, {}
+    fused = fused_step_times(device, flow, trainer, batch) if world == 1 else None
+    if fused is not None:
+        ft, fflops = fused
+        breakdown.update({k: round(v, 2) for k, v in ft.items()})
+        for k, fl in fflops.items():
+            entries[k] = with_traffic(mfma_entry(k, B, ft[k], fl))
+        # the same launch against the HBM roofline: compulsory traffic of the step at the plugin boundary = frames + both
+        # targets in (the model output and its gradient never exist in memory), nothing out but three scalars
+        step_bytes = 4 * T_FRAMES * JOINTS * (2 + 2 + 3) + 4
+        entries['train_clip_kernel']['hbm_view'] = roofline_entry('train_clip_kernel', B, ft['train_clip_kernel'], step_bytes)
     else:
-        breakdown = {names[w]: round(kt[w], 2) for w in ('fwd', 'bwd')}
-    if getattr(flow.movements_model, 'fused_mlp', False):
-        mt, flops = mlp_times(device, flow.movements_model, args.batch_size, getattr(trainer, '_opt_in_backward', False))
-        breakdown.update({k: round(v, 2) for k, v in mt.items()})
-        for k, fl in flops.items():
-            entries[k] = mfma_entry(k, args.batch_size, mt[k], fl)
-            entries[k]['traffic'] = (traffic.get(f'{k}@B{args.batch_size}') or {}).get('bytes')
+        kt = kernel_times(device, B)
+        names = {'fwd': 'pose_head_rot_fwd<6D>(+loss_finalize)', 'bwd': 'pose_head_rot_bwd<6D>'}
+        per_clip = {'fwd': BYTES_FWD, 'bwd': BYTES_BWD}
+        for w in ('fwd', 'bwd'):
+            entries[names[w]] = with_traffic(roofline_entry(names[w], B, kt[w], per_clip[w]))
+        if int(os.environ.get('P2C_DEFER_FINALIZE', '2')) == 2 and B <= 2048:
+            breakdown['pose_head_train(count + fwd/bwd in one kernel + finalize)'] = round(kt['train'], 2)
+        else:
+            breakdown.update({names[w]: round(kt[w], 2) for w in ('fwd', 'bwd')})
+        if getattr(flow.movements_model, 'fused_mlp', False):
+            mt, flops = mlp_times(device, flow.movements_model, B, getattr(trainer, '_opt_in_backward', False))
+            breakdown.update({k: round(v, 2) for k, v in mt.items()})
+            for k, fl in flops.items():
+                entries[k] = with_traffic(mfma_entry(k, B, mt[k], fl))
     result['step_breakdown_us'] = breakdown
     dominant = max(entries, key=lambda k: entries[k]['us_per_launch'])
     result['roofline'] = entries.pop(dominant)
     result['roofline']['other'] = list(entries.values())
     if not args.no_sweep and world == 1:
+        names = {'fwd': 'pose_head_rot_fwd<6D>(+loss_finalize)', 'bwd': 'pose_head_rot_bwd<6D>'}
+        per_clip = {'fwd': BYTES_FWD, 'bwd': BYTES_BWD}
         sweep = []
-        for B in (256, 1024, 8192, 65536):
-            k = kernel_times(device, B, reps=10 if B > 8192 else 20)
+        for Bs in (256, 1024, 8192, 65536):
+            k = kernel_times(device, Bs, reps=10 if Bs > 8192 else 20)
             for which in ('fwd', 'bwd'):
-                sweep.append(roofline_entry(names[which], B, k[which], per_clip[which],
-                                            (traffic.get(f'{names[which]}@B{B}') or {}).get('bytes')))
+                sweep.append(roofline_entry(names[which], Bs, k[which], per_clip[which],
+                                            (traffic.get(f'{names[which]}@B{Bs}') or {}).get('bytes')))
         result['roofline_sweep'] = sweep
+    if not args.no_extra_configs and world == 1:
+        extra = {}
+        for name in ('cfg2', 'cfg3'):
+            try:
+                extra[name] = extra_config(device, name)
+            except Exception as e:                                  # noqa: BLE001 -- an extra must not sink the headline
+                extra[name] = {'error': repr(e)[:300]}
+        result['extra_configs'] = extra
     if not args.no_cpu_baseline and world == 1:
         result['cpu_baseline'] = cpu_baseline(args.batch_size, args.cpu_seconds)
     print(json.dumps(result), flush=True)

@@ -236,6 +236,11 @@ typedef struct p2c_train_step_desc {
 P2C_API int p2c_train_step_supported(const p2c_train_step_desc *desc);          /* 1 = shapes / kind the kernels cover */
 P2C_API int64_t p2c_train_step_workspace_floats(const p2c_train_step_desc *desc);
 P2C_API int p2c_train_step(const p2c_train_step_desc *desc, const float *const grad_losses[3], void *stream);
+/* Measurement hook: the same call with only some of its launches -- which = 1: the per-clip kernel, 2: the weight-gradient /
+ * optimizer / loss kernel (on the factors a previous full call left in the workspace; each launch re-applies the optimizer
+ * step), 3: both (= p2c_train_step). bench.py times the launches one by one with it. */
+P2C_API int p2c_train_step_launch(const p2c_train_step_desc *desc, const float *const grad_losses[3], int32_t which,
+                                  void *stream);
 /* counts[b] = number of (frame, joint) pairs of clip b inside [t0, t1) whose 2-D target the loss does not mask
  * (utils/tensors.py:29-40 via loss/base_pose_loss.py:36-66): reads only the target-side fields of desc (gt2d, gmap2d,
  * hips_lane, mask_missing_joints, t0, t1); y / partials / losses may be NULL. One launch. */

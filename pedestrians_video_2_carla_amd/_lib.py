@@ -134,6 +134,7 @@ SYMBOLS = {
     'p2c_train_step_supported': (ctypes.c_int, [ctypes.POINTER(TrainStepDesc)]),
     'p2c_train_step_workspace_floats': (_i64, [ctypes.POINTER(TrainStepDesc)]),
     'p2c_train_step': (ctypes.c_int, [ctypes.POINTER(TrainStepDesc), ctypes.POINTER(_vp * 3), _vp]),
+    'p2c_train_step_launch': (ctypes.c_int, [ctypes.POINTER(TrainStepDesc), ctypes.POINTER(_vp * 3), _i32, _vp]),
     'p2c_count_target_pairs': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp, _vp]),
 }
 

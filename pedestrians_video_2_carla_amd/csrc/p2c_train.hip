@@ -617,7 +617,13 @@ extern "C" int p2c_count_target_pairs(const p2c_pose_head_desc *desc, float *cou
 }
 
 extern "C" int p2c_train_step(const p2c_train_step_desc *desc, const float *const grad_losses_[3], void *stream_) {
+  return p2c_train_step_launch(desc, grad_losses_, 3, stream_);
+}
+
+extern "C" int p2c_train_step_launch(const p2c_train_step_desc *desc, const float *const grad_losses_[3], int32_t which,
+                                     void *stream_) {
   if (!desc) return P2C_E_NULL;
+  if ((which & 3) == 0) return P2C_E_ENUM;
   if (!p2c_train_step_supported(desc)) return P2C_E_SHAPE;
   p2c_pose_head_desc d = desc->head;
   const p2c_mlp_desc &m = desc->mlp;
@@ -655,7 +661,7 @@ extern "C" int p2c_train_step(const p2c_train_step_desc *desc, const float *cons
     (void)hipFuncSetAttribute((const void *)train_clip_kernel<P2C_KIND_RELATIVE_ROT_6D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
-  if (!m.skip_pack) {
+  if (!m.skip_pack && (which & 1)) {
     rc = p2c_mlp_pack(&m, stream_);
     if (rc) return rc;
   }
@@ -671,12 +677,16 @@ extern "C" int p2c_train_step(const p2c_train_step_desc *desc, const float *cons
   for (int j = 0; j < P2C_JOINTS; ++j) identity &= (d.gmap2d[j] == j) && (d.gmap3d[j] == j);
   ClipArgs ca{m.x, m.w_image, desc->pair_counts, m.partials, counters, tiles, identity};
   const size_t lds_a = (size_t)LDS_FLOATS * sizeof(float);
-  if (d.kind == P2C_KIND_POSE_CHANGES_6D)
-    hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_POSE_CHANGES_6D>, dim3((unsigned)d.B), dim3(64 * WAVES), lds_a, stream, d, gl, ca);
-  else
-    hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_RELATIVE_ROT_6D>, dim3((unsigned)d.B), dim3(64 * WAVES), lds_a, stream, d, gl, ca);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return (int)e;
+  hipError_t e = hipSuccess;
+  if (which & 1) {
+    if (d.kind == P2C_KIND_POSE_CHANGES_6D)
+      hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_POSE_CHANGES_6D>, dim3((unsigned)d.B), dim3(64 * WAVES), lds_a, stream, d, gl, ca);
+    else
+      hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_RELATIVE_ROT_6D>, dim3((unsigned)d.B), dim3(64 * WAVES), lds_a, stream, d, gl, ca);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  if (!(which & 2)) return 0;
 
   WgradArgs wa{};
   wa.factors = m.partials, wa.n_stiles = d.B, wa.n_tiles_w = tiles;

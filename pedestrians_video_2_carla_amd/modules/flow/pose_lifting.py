@@ -94,11 +94,21 @@ class LitPoseLiftingFlow(LitBaseFlow):
         if plan is not None:
             from pedestrians_video_2_carla_amd import ops
             spec, gt2d, _gt3d = plan
-            # one persistent buffer: a captured step reads this address for every batch staged later
+            # one persistent buffer and one prebuilt launch descriptor: a captured step reads this address for every batch
+            # staged later, and staging a batch costs one ctypes call here
+            n, dev = len(batch[0]), batch[0].device
             buf = getattr(self, '_pair_counts_buf', None)
-            if buf is None or buf.shape[0] != len(batch[0]) or buf.device != batch[0].device:
-                buf = self._pair_counts_buf = torch.zeros(len(batch[0]), dtype=torch.float32, device=batch[0].device)
-            self._pair_counts = ops.count_target_pairs(spec, gt2d, out=buf) if gt2d is not None else buf.zero_()
+            if buf is None or buf.shape[0] != n or buf.device != dev:
+                buf = self._pair_counts_buf = torch.zeros(n, dtype=torch.float32, device=dev)
+                self._pair_counter = None
+            if gt2d is None:
+                self._pair_counts = buf.zero_()
+            else:
+                pc = getattr(self, '_pair_counter', None)
+                if pc is None or pc.spec is not spec or not pc.matches(gt2d.shape, gt2d.device):
+                    pc = self._pair_counter = ops.PairCounter(spec, gt2d, out=buf)
+                    pc.spec = spec
+                self._pair_counts = pc(gt2d if gt2d.is_contiguous() else gt2d.contiguous())
 
     # ---- fused-path configuration -----------------------------------------------------------------------------------
     def _fusable(self, transform_callable) -> bool:
@@ -143,7 +153,28 @@ class LitPoseLiftingFlow(LitBaseFlow):
         """(PoseHeadSpec, gt2d, gt3d) when this batch can take ``ops.fused_train_step`` -- LinearAE with the 6-D rotation
         output on CARLA nodes, built-in transform, fusable losses, lean outputs, one clip per 16-sample tile, a small
         batch (``P2C_FUSED_TRAIN_MAX_B``, default 512: beyond it the persistent kernels win) -- else None.
-        ``P2C_FUSED_TRAIN=0`` turns the path off."""
+        ``P2C_FUSED_TRAIN=0`` turns the path off. Everything but the two target tensors is a function of the configuration
+        and the batch shape: it is worked out once per (shape, configuration) and cached."""
+        import os
+        model = self.movements_model
+        if type(model) is not LinearAE or not frames.is_cuda or (self._datamodule is None and getattr(getattr(self, 'trainer', None), 'datamodule', None) is None):
+            return None
+        transform_callable = self.datamodule.transform_callable
+        key = (tuple(frames.shape), frames.device, frames.dtype, tuple(targets.keys()), os.environ.get('P2C_FUSED_TRAIN', '1'),
+               os.environ.get('P2C_FUSED_TRAIN_MAX_B', '512'), self.lean_train_outputs, type(model), model.eval_slice.start,
+               model.eval_slice.stop, getattr(model, 'rotation_output_format', None), id(transform_callable),
+               id(self.trajectory_model), bool(self.mask_missing_joints), model.fused_mlp, model.training,
+               tuple(targets[k].shape for k in ('projection_2d_transformed', 'projection_2d', 'absolute_pose_loc') if k in targets))
+        cached = getattr(self, '_fused_plan_cache', None)
+        if cached is None or cached[0] != key:
+            cached = self._fused_plan_cache = (key, self._fused_train_plan_uncached(frames, targets, transform_callable))
+        static = cached[1]
+        if static is None:
+            return None
+        spec, gt2d_key, want3d = static
+        return spec, (targets[gt2d_key] if gt2d_key else None), (targets.get('absolute_pose_loc') if want3d else None)
+
+    def _fused_train_plan_uncached(self, frames, targets, transform_callable):
         import os
         from pedestrians_video_2_carla_amd import ops
         model = self.movements_model
@@ -160,18 +191,15 @@ class LitPoseLiftingFlow(LitBaseFlow):
         fa = model.fused_args(frames.device)
         if fa is None or not ops.train_step_supported(fa['dims'], T):
             return None
-        transform_callable = self.datamodule.transform_callable
         if not self._fusable(transform_callable):
             return None
         names = {name for (name, *_r) in self._losses_to_calculate}
         gt2d_key = self._gt2d_key(targets) if 'loc_2d' in names else None
-        gt2d = targets[gt2d_key] if gt2d_key else None
-        gt3d = targets.get('absolute_pose_loc') if 'loc_3d' in names else None
         kind = 'pose_changes_6d' if model.output_type == MovementsModelOutputType.pose_changes else 'relative_rot_6d'
         absolute = (self.trajectory_model.output_type == TrajectoryModelOutputType.loc_rot
                     and not bool(getattr(self.trajectory_model, 'is_identity', False)))
         spec = ops.PoseHeadSpec(kind=kind, world_absolute=absolute, **self._spec_kwargs(transform_callable, targets))
-        return spec, gt2d, gt3d
+        return spec, gt2d_key, ('loc_3d' in names)
 
     def _fused_train_step(self, frames, targets, stage):
         """The whole train step as one autograd node, or None when the separate kernels have to run."""

@@ -651,38 +651,56 @@ LINEAR_AE_6D_DIMS = (52, 26, 13, 6, 39, 78, 156)
 FUSED_TRAIN_MAX_T = 16
 
 
+class PairCounter:
+    """``count_target_pairs`` for one (spec, target shape) with its launch descriptor built once: called for every staged
+    batch, so the per-call host work is one ctypes call."""
+
+    def __init__(self, spec: PoseHeadSpec, gt2d: Tensor, out: Optional[Tensor] = None):
+        gt2d = _require_device(gt2d, 'gt2d')
+        if gt2d.ndim != 4 or gt2d.shape[3] < 2:
+            raise RuntimeError(f'gt2d should have shape (B, T, joints, >= 2), got {tuple(gt2d.shape)}')
+        B, T = gt2d.shape[0], gt2d.shape[1]
+        if max(spec.gmap2d) >= gt2d.shape[2]:
+            raise RuntimeError(f'gt2d has {gt2d.shape[2]} joints but the joint map needs index {max(spec.gmap2d)}')
+        if out is not None and (tuple(out.shape) != (B,) or out.dtype != torch.float32 or out.device != gt2d.device
+                                or not out.is_contiguous()):
+            raise RuntimeError(f'out should be a contiguous float32 ({B},) tensor on {gt2d.device}')
+        d = PoseHeadDesc()
+        d.B, d.T = B, T
+        d.kind, d.transform = KIND[spec.kind], TRANSFORM[spec.transform]
+        d.t0, d.t1 = spec.frames(T)
+        d.mask_missing_joints, d.hips_lane = int(spec.mask_missing_joints), spec.hips_lane
+        d.n_hips = d.n_neck = 1
+        d.hips_idx[0], d.neck_idx[0] = spec.hips_idx[0], spec.neck_idx[0]
+        d.gmap2d[:] = spec.gmap2d
+        d.gmap3d[:] = spec.gmap3d
+        d.n_common2d = sum(1 for v in spec.gmap2d if v >= 0)
+        d.n_common3d = sum(1 for v in spec.gmap3d if v >= 0)
+        d.gt2d_joints, d.gt2d_channels = gt2d.shape[2], gt2d.shape[3]
+        self.counts = out if out is not None else torch.empty(B, dtype=torch.float32, device=gt2d.device)
+        d.skel_type = self.counts.data_ptr()                  # not read by the count kernel; validation wants non-NULL tables
+        d.ref_rel_loc = d.ref_rel_rot = d.ref_hn_shift = d.ref_hn_scale = self.counts.data_ptr()
+        self.desc, self.shape, self.device, self._lib = d, tuple(gt2d.shape), gt2d.device, _lib.lib()
+
+    def matches(self, spec_shape, device) -> bool:
+        return self.shape == tuple(spec_shape) and self.device == device
+
+    def __call__(self, gt2d: Tensor) -> Tensor:
+        if tuple(gt2d.shape) != self.shape or gt2d.device != self.device or gt2d.dtype != torch.float32 or not gt2d.is_contiguous():
+            raise RuntimeError(f'gt2d should be a contiguous float32 {self.shape} tensor on {self.device}')
+        self.desc.gt2d = gt2d.data_ptr()
+        _lib.check(self._lib.p2c_count_target_pairs(ctypes.byref(self.desc), self.counts.data_ptr(),
+                                                    torch.cuda.current_stream(self.device).cuda_stream), 'p2c_count_target_pairs')
+        return self.counts
+
+
 def count_target_pairs(spec: PoseHeadSpec, gt2d: Tensor, out: Optional[Tensor] = None) -> Tensor:
     """(B,) float: per clip, the (frame, joint) pairs inside the eval slice whose 2-D target the loss does not mask
     (utils/tensors.py:29-40). A property of the targets alone: computed once when a batch is staged. ``out``: write into
     this (B,) buffer (a captured train step keeps reading the SAME address for every later batch)."""
-    lib = _lib.lib()
     gt2d = _require_device(gt2d, 'gt2d')
-    if gt2d.ndim != 4 or gt2d.shape[3] < 2:
-        raise RuntimeError(f'gt2d should have shape (B, T, joints, >= 2), got {tuple(gt2d.shape)}')
-    B, T = gt2d.shape[0], gt2d.shape[1]
-    if max(spec.gmap2d) >= gt2d.shape[2]:
-        raise RuntimeError(f'gt2d has {gt2d.shape[2]} joints but the joint map needs index {max(spec.gmap2d)}')
-    d = PoseHeadDesc()
-    d.B, d.T = B, T
-    d.kind, d.transform = KIND[spec.kind], TRANSFORM[spec.transform]
-    d.t0, d.t1 = spec.frames(T)
-    d.mask_missing_joints, d.hips_lane = int(spec.mask_missing_joints), spec.hips_lane
-    d.n_hips = d.n_neck = 1
-    d.hips_idx[0], d.neck_idx[0] = spec.hips_idx[0], spec.neck_idx[0]
-    d.gmap2d[:] = spec.gmap2d
-    d.gmap3d[:] = spec.gmap3d
-    d.n_common2d = sum(1 for v in spec.gmap2d if v >= 0)
-    d.n_common3d = sum(1 for v in spec.gmap3d if v >= 0)
-    d.gt2d, d.gt2d_joints, d.gt2d_channels = gt2d.data_ptr(), gt2d.shape[2], gt2d.shape[3]
-    if out is not None and (tuple(out.shape) != (B,) or out.dtype != torch.float32 or out.device != gt2d.device
-                            or not out.is_contiguous()):
-        raise RuntimeError(f'out should be a contiguous float32 ({B},) tensor on {gt2d.device}')
-    counts = out if out is not None else torch.empty(B, dtype=torch.float32, device=gt2d.device)
-    d.skel_type = counts.data_ptr()                       # not read by the count kernel; validation wants non-NULL tables
-    d.ref_rel_loc = d.ref_rel_rot = d.ref_hn_shift = d.ref_hn_scale = counts.data_ptr()
     with torch.cuda.device(gt2d.device):
-        _lib.check(lib.p2c_count_target_pairs(ctypes.byref(d), counts.data_ptr(), _stream()), 'p2c_count_target_pairs')
-    return counts
+        return PairCounter(spec, gt2d, out)(gt2d)
 
 
 class FusedTrainStepFunction(torch.autograd.Function):
@@ -739,35 +757,13 @@ class FusedTrainStepFunction(torch.autograd.Function):
             gl = _lib.grad_loss_pointers(vector=g_losses.data_ptr())
         else:
             gl = _lib.grad_loss_pointers(*[_ptr(g) for g in scalars])
-        desc = _lib.TrainStepDesc()
-        head = _fill_desc(spec, _MetaPtr((B, T, J, 6), x.device), skel_type, dloc, drot, gt2d, gt3d, ctx.bufs, {})
-        head.y = None
-        desc.head = head
-        m = _mlp_desc(x.reshape(B * T, -1), weights, biases)
-        n_image = lib.p2c_mlp_image_floats(ctypes.byref(m))
-        image, skip_pack = ctx.image, ctx.skip_pack
-        if image is None:
-            image, skip_pack = torch.empty(n_image, dtype=torch.float32, device=x.device), False
-        elif image.numel() != n_image or image.device != x.device or image.dtype != torch.float32:
-            raise RuntimeError('packed weight image of the wrong size / device')
-        m.w_image, m.skip_pack = image.data_ptr(), int(skip_pack)
         if ctx.sinks is not None:
             gws, gbs = ctx.sinks[0::2], ctx.sinks[1::2]
         else:
             gws = [torch.empty_like(w) for w in weights]
             gbs = [torch.empty_like(b) for b in biases]
-        for l in range(n):
-            m.gW[l], m.gb[l] = gws[l].data_ptr(), gbs[l].data_ptr()
-        desc.mlp = m
-        desc.pair_counts = counts.data_ptr()
-        if not lib.p2c_train_step_supported(ctypes.byref(desc)):
-            raise _lib.P2CError('p2c_train_step does not cover this shape (LinearAE 52-26-13-6-39-78-156, T <= 16)')
-        ws = torch.empty(lib.p2c_train_step_workspace_floats(ctypes.byref(desc)), dtype=torch.float32, device=x.device)
-        desc.mlp.partials = ws.data_ptr()
-        opt_desc = None
-        if ctx.fused_opt is not None:
-            opt_desc = ctx.fused_opt.descriptor_for_fusion()
-            desc.mlp.fused_adamw = ctypes.addressof(opt_desc)
+        desc, keep = train_step_desc(x, spec, skel_type, dloc, drot, gt2d, gt3d, counts, weights, biases, gws, gbs, ctx.bufs,
+                                     ctx.image, ctx.skip_pack, ctx.fused_opt)
         with torch.cuda.device(x.device):
             _lib.check(lib.p2c_train_step(ctypes.byref(desc), gl, _stream()), 'p2c_train_step')
         if ctx.fused_opt is not None:
@@ -776,6 +772,38 @@ class FusedTrainStepFunction(torch.autograd.Function):
         if ctx.sinks is not None:
             return head_none + (None,) * (2 * n)
         return head_none + (*gws, *gbs)
+
+
+def train_step_desc(x, spec, skel_type, dloc, drot, gt2d, gt3d, counts, weights, biases, gws, gbs, bufs, image=None,
+                    skip_pack=False, fused_opt=None):
+    """(p2c_train_step_desc, objects to keep alive while it is used) for one fused train step on device tensors."""
+    lib = _lib.lib()
+    B, T = x.shape[0], x.shape[1]
+    desc = _lib.TrainStepDesc()
+    head = _fill_desc(spec, _MetaPtr((B, T, J, 6), x.device), skel_type, dloc, drot, gt2d, gt3d, bufs, {})
+    head.y = None
+    desc.head = head
+    xf = x.reshape(B * T, -1)
+    m = _mlp_desc(xf, weights, biases)
+    n_image = lib.p2c_mlp_image_floats(ctypes.byref(m))
+    if image is None:
+        image, skip_pack = torch.empty(n_image, dtype=torch.float32, device=x.device), False
+    elif image.numel() != n_image or image.device != x.device or image.dtype != torch.float32:
+        raise RuntimeError('packed weight image of the wrong size / device')
+    m.w_image, m.skip_pack = image.data_ptr(), int(bool(skip_pack))
+    for l in range(len(weights)):
+        m.gW[l], m.gb[l] = gws[l].data_ptr(), gbs[l].data_ptr()
+    desc.mlp = m
+    desc.pair_counts = counts.data_ptr()
+    if not lib.p2c_train_step_supported(ctypes.byref(desc)):
+        raise _lib.P2CError('p2c_train_step does not cover this shape (LinearAE 52-26-13-6-39-78-156, T <= 16)')
+    ws = torch.empty(lib.p2c_train_step_workspace_floats(ctypes.byref(desc)), dtype=torch.float32, device=x.device)
+    desc.mlp.partials = ws.data_ptr()
+    opt_desc = None
+    if fused_opt is not None:       # the optimizer step rides on the gradient reduction (see p2c_mlp_desc.fused_adamw)
+        opt_desc = fused_opt.descriptor_for_fusion()
+        desc.mlp.fused_adamw = ctypes.addressof(opt_desc)
+    return desc, (xf, image, ws, opt_desc, gws, gbs)
 
 
 class _MetaPtr:

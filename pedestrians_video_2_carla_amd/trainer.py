@@ -231,13 +231,21 @@ class Trainer:
             frames, targets, meta = batch
             clone = lambda d: {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}   # noqa: E731
             self._static_batch = (frames.clone(), clone(targets), clone(meta))
+            named = self._batch_tensors(self._static_batch)
+            self._static_names, self._static_dst = [k for k, _ in named], [v for _, v in named]
         else:
-            src, dst = self._batch_tensors(batch), self._batch_tensors(self._static_batch)
-            if [(k, v.shape, v.dtype) for k, v in src] != [(k, v.shape, v.dtype) for k, v in dst]:
-                raise RuntimeError('graph mode needs batches of one fixed structure: got keys/shapes '
-                                   f'{[(k, tuple(v.shape)) for k, v in src]} after {[(k, tuple(v.shape)) for k, v in dst]}')
-            torch._foreach_copy_([v for _, v in dst], [v for _, v in src])
-            for k, v in batch[2].items():                 # lists of strings etc. travel by reference
+            frames, targets, meta = batch
+            try:        # the same tensors, in the order of the static list (no sorting / renaming per batch)
+                src = [frames if k == 'frames' else (targets[k[8:]] if k[0] == 't' else meta[k[5:]]) for k in self._static_names]
+            except KeyError as e:
+                raise RuntimeError(f'graph mode needs batches of one fixed structure: {e.args[0]!r} is missing') from None
+            n_tensors = 1 + sum(isinstance(v, torch.Tensor) for v in targets.values()) + sum(isinstance(v, torch.Tensor) for v in meta.values())
+            if n_tensors != len(src) or any(s.shape != d.shape or s.dtype != d.dtype for s, d in zip(src, self._static_dst)):
+                raise RuntimeError('graph mode needs batches of one fixed structure: got '
+                                   f'{[(k, tuple(v.shape)) for k, v in self._batch_tensors(batch)]} after '
+                                   f'{[(k, tuple(v.shape)) for k, v in zip(self._static_names, self._static_dst)]}')
+            torch._foreach_copy_(self._static_dst, src)
+            for k, v in meta.items():                     # lists of strings etc. travel by reference
                 if not isinstance(v, torch.Tensor):
                     self._static_batch[2][k] = v
         self._staged_src = key

@@ -21,6 +21,8 @@ GROUPS = {
     'mlp_bwd(+reduce)': ('mlp_bwd_kernel', 'mlp_wgrad_kernel', 'mlp_reduce_kernel', 'mlp_reduce_small_kernel'),
     'mlp_bwd(+reduce+adamw)': ('mlp_bwd_kernel', 'mlp_wgrad_kernel', 'mlp_reduce_kernel', 'mlp_reduce_small_kernel'),
     'adamw': ('adamw_kernel',),
+    'train_clip_kernel': ('train_clip_kernel',),
+    'train_wgrad_kernel(+adamw+loss)': ('train_wgrad_kernel',),
 }
 
 
