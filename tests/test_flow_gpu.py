@@ -77,8 +77,16 @@ def test_training_step_matches_cpu_pipeline(otype):
     close(flow.logged['train_loss/loc_2d'], o['loc_2d'], 'loc_2d')
     close(flow.logged['train_loss/loc_3d'], o['loc_3d'], 'loc_3d')
     close(flow.logged['train_loss/primary'], o['loc_2d_3d'], 'primary')
-    for (n, p), q in zip(flow.movements_model.named_parameters(), cpu_model.parameters()):
-        close(p.grad, q.grad, n, rtol=2e-4)
+    # parameter gradients: 1e-4, or twice what the reference's own fp32 arithmetic (LinearAE fp32 on the CPU + fp32 oracle)
+    # loses against fp64 on this batch -- the rule of tests/test_pose_head_gpu.py
+    cpu32 = copy.deepcopy(cpu_model).float()
+    o32 = O.pose_head(cpu32(frames.float().cpu()), kind, meta['skel_type'].cpu(),
+                      gt2d=targets['projection_2d_transformed'].float().cpu(),
+                      gt3d=targets['absolute_pose_loc'].float().cpu())
+    o32['loc_2d_3d'].backward()
+    for (n, p), q, q32 in zip(flow.movements_model.named_parameters(), cpu_model.parameters(), cpu32.parameters()):
+        ref_err = (q32.grad.double() - q.grad).abs().max().item() / (q.grad.abs().max().item() + 1e-30)
+        close(p.grad, q.grad, n, rtol=max(1e-4, 2 * ref_err))
     assert out['preds']['absolute_pose_loc'] is None          # lean train outputs
 
 
