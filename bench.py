@@ -19,7 +19,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline     the launch that takes the most time in the step: algorithmic flops (vs the 157.3 TFLOP/s fp32 MFMA peak) or
                bytes (vs 8 TB/s HBM) per launch / measured duration, PMC traffic; `other` = the rest
   roofline_sweep  the pose-head kernels at B = 256, 1024, 8192, 65536 (the step at B=256 is latency-bound by construction)
-  extra_configs  BASELINE.json configs[1] (B = 1024) and configs[2] (autoencoder, Seq2SeqEmbeddings, B = 512) on this GPU
+  extra_configs  BASELINE.json configs[1] (B = 1024), configs[2] (autoencoder, Seq2SeqEmbeddings, B = 512) and one GPU's share
+                 of configs[4] (PoseFormer, clip_length 81, B = 32) on this GPU
   cpu_baseline the op-for-op CPU port of the reference step (oracle/reference_port.py) timed on this host's cores:
                all cores, one thread, and under torch DDP / gloo with world_size 1, 2, 4, 8 (oracle/ddp_baseline.py).
 """
@@ -409,6 +410,14 @@ def extra_config(device, name, steps=100, warmup=10):
         model = LinearAE(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON)
         flow = LitPoseLiftingFlow(movements_model=model, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
         workload = 'flow=pose_lifting LinearAE(pose_changes) loss=loc_2d_3d clip_length=16 batch_size=1024 (BASELINE.json configs[1])'
+    elif name == 'cfg5':
+        from pedestrians_video_2_carla_amd.modules.flow.pose_lifting import LitPoseLiftingFlow
+        from pedestrians_video_2_carla_amd.modules.movements.pose_former import PoseFormer
+        B, clip = 32, 81                      # configs[4]: 256 clips of 81 frames over 8 GPUs -> 32 per GPU
+        model = PoseFormer(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, clip_length=clip)
+        flow = LitPoseLiftingFlow(movements_model=model, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
+        workload = ('flow=pose_lifting PoseFormer(9 frames, 26 joints, E=32, depth 4, 8 heads; restated, library attention) '
+                    'clip_length=81 absolute_loc head batch_size=32 = one GPU\'s share of BASELINE.json configs[4] (256 over 8 GPUs)')
     else:
         from pedestrians_video_2_carla_amd.modules.flow.autoencoder import LitAutoencoderFlow
         from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2SeqEmbeddings
@@ -417,9 +426,11 @@ def extra_config(device, name, steps=100, warmup=10):
         flow = LitAutoencoderFlow(movements_model=model, loss_modes=['loc_2d'], transform='hips_neck_bbox')
         workload = ('flow=autoencoder Seq2SeqEmbeddings movements_output_type=pose_2d clip_length=16 batch_size=512 '
                     '(BASELINE.json configs[2])')
-    dm = SyntheticCarlaRecordedDataModule(clip_length=T_FRAMES, batch_size=B)
+    dm = SyntheticCarlaRecordedDataModule(clip_length=81 if name == 'cfg5' else T_FRAMES, batch_size=B)
     trainer = Trainer(device=device, use_graph=True).setup(flow, dm)
     batch = dm.generate_batch(device)
+    if name == 'cfg5':
+        steps, warmup = 20, 3
     for i in range(warmup):
         trainer.train_step(flow, batch, i)
     torch.cuda.synchronize(device)
@@ -438,6 +449,10 @@ def extra_config(device, name, steps=100, warmup=10):
                        'built, so no reduced-precision number is claimed')
         mt, flops = mlp_times(device, model, B, getattr(trainer, '_opt_in_backward', False))
         out['roofline'] = [mfma_entry(k, B, mt[k], fl) for k, fl in flops.items()]
+    elif name == 'cfg5':
+        out['note'] = ('transformer arithmetic parity-unpinned (third-party source absent); attention / GEMMs are library kernels, '
+                       'the pose head is the HIP absolute_loc kernel; stochastic depth (0.2) on')
+        out['windows_per_step'] = B * (81 - 9 + 1)
     else:
         # the recurrences (K7b encoder layers, K7c decoder loop) priced against the fp32 MFMA peak: 2*T*B*H*4H flop per
         # LSTM layer and direction of the data flow (forward; the backward kernels do the same again with W^T)
@@ -574,7 +589,7 @@ def main():
         result['roofline_sweep'] = sweep
     if not args.no_extra_configs and world == 1:
         extra = {}
-        for name in ('cfg2', 'cfg3'):
+        for name in ('cfg2', 'cfg3', 'cfg5'):
             try:
                 extra[name] = extra_config(device, name)
             except Exception as e:                                  # noqa: BLE001 -- an extra must not sink the headline

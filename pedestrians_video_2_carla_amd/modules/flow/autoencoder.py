@@ -24,13 +24,20 @@ class LitAutoencoderFlow(LitBaseFlow):
     def get_default_models(cls) -> Dict[str, torch.nn.Module]:
         return {'movements': Seq2SeqEmbeddings}
 
+    def get_initial_metrics(self):
+        """reference autoencoder.py:63-71: the share of missing joints in the input data (no masking: it measures it)."""
+        from pedestrians_video_2_carla_amd.metrics import MissingJointsRatio
+        return {'MJR': MissingJointsRatio(input_nodes=self.movements_model.input_nodes,
+                                          output_nodes=self.movements_model.output_nodes)}
+
     def get_metrics(self):
-        """reference autoencoder.py:73-102 (the two PCK variants; the MSE wrapper is the loss itself)."""
-        from pedestrians_video_2_carla_amd.metrics import PCK
+        """reference autoencoder.py:73-102: masked MSE through MultiinputWrapper and the two PCK variants."""
+        from pedestrians_video_2_carla_amd.metrics import PCK, MeanSquaredError, MultiinputWrapper
         kw = dict(input_nodes=self.movements_model.input_nodes, output_nodes=self.movements_model.output_nodes,
-                  mask_missing_joints=self.mask_missing_joints, key=self._outputs_key)
-        return {'PCKhn@01': PCK(threshold=0.1, get_normalization_tensor='hn', **kw),
-                'PCK@005': PCK(threshold=0.05, get_normalization_tensor='bbox', **kw)}
+                  mask_missing_joints=self.mask_missing_joints)
+        return {'MSE': MultiinputWrapper(MeanSquaredError(), self._outputs_key, self._outputs_key, **kw),
+                'PCKhn@01': PCK(threshold=0.1, get_normalization_tensor='hn', key=self._outputs_key, **kw),
+                'PCK@005': PCK(threshold=0.05, get_normalization_tensor='bbox', key=self._outputs_key, **kw)}
 
     def _inner_step(self, frames, targets, edge_index=None, batch_vector=None, stage='train'):
         model = self.movements_model

@@ -63,10 +63,16 @@ class LitPoseLiftingFlow(LitBaseFlow):
         return {'trajectory': ZeroTrajectory, 'movements': LinearAE}
 
     def get_metrics(self):
-        """reference pose_lifting.py:88-105 (MPJPE, MRPE; the FB_* wrappers need the absent third_party code)."""
-        from pedestrians_video_2_carla_amd.metrics import MPJPE, MRPE
+        """reference pose_lifting.py:88-105: MPJPE, MRPE (HIP reductions) and the five FB_* wrappers (tensor reductions on
+        the device; VideoPose3D definitions restated, parity-unpinned -- metrics/extra_metrics.py)."""
+        from pedestrians_video_2_carla_amd.metrics import (FB_MPJPE, FB_MPJVE, FB_N_MPJPE, FB_PA_MPJPE, FB_WeightedMPJPE, MPJPE,
+                                                         MRPE)
         nodes = dict(input_nodes=self.movements_model.input_nodes, output_nodes=self.movements_model.output_nodes)
-        return {'MPJPE': MPJPE(**nodes), 'MRPE': MRPE(**nodes)}
+        metrics = {'MPJPE': MPJPE(**nodes), 'MRPE': MRPE(**nodes)}
+        if self.movements_model.input_nodes is self.movements_model.output_nodes:     # the FB wrappers compare whole tensors
+            metrics.update({'FB_MPJPE': FB_MPJPE(), 'FB_WeightedMPJPE': FB_WeightedMPJPE(), 'FB_PA_MPJPE': FB_PA_MPJPE(),
+                            'FB_N_MPJPE': FB_N_MPJPE(), 'FB_MPJVE': FB_MPJVE()})
+        return metrics
 
     def _get_crucial_keys(self):
         return [self._outputs_key, *_PROJECTION_KEYS]

@@ -5,8 +5,9 @@ and un-pinned: parity of its arithmetic is UNPINNED). What the r
 here -- is the wrapper: a sliding window of ``receptive_frames`` over the clip, each window's (B,1,J,3) centre-frame
 prediction broadcast into frames [i+shift, i+shift+receptive) (later windows overwrite), ``eval_slice`` restricted to
 the frames that have a full receptive field, output type absolute_loc, AdamW(4e-4, wd 0.1) + ExponentialLR(0.99).
-``inner_model`` injects the transformer; without it (and without the third-party package) construction raises
-``NotAvailableException`` like the reference does for absent optional models.
+``inner_model`` injects a transformer; otherwise the third-party package is used when it is importable and, when it is not
+(the submodule is empty in the reference checkout), the build's own restatement of the published architecture,
+``pose_transformer.PoseTransformer`` (parity-unpinned).
 """
 import torch
 
@@ -18,8 +19,8 @@ from pedestrians_video_2_carla_amd.utils.exceptions import NotAvailableException
 def _third_party_model(**kw):
     try:
         from common.model_poseformer import PoseTransformer        # third_party/PoseFormer on sys.path
-    except ImportError as e:
-        raise NotAvailableException('PoseFormer', 'pose_lifting') from e
+    except ImportError:
+        from pedestrians_video_2_carla_amd.modules.movements.pose_former.pose_transformer import PoseTransformer
     return PoseTransformer(**kw)
 
 

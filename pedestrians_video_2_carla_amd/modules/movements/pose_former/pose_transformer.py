@@ -1,0 +1,108 @@
+"""``PoseTransformer``: the spatial-temporal transformer the reference's PoseFormer plugin wraps
+(modules/movements/pose_former/pose_former.py:6,62-76 binds ``third_party.pose_former.model_poseformer.PoseTransformer``).
+
+The third-party source is an EMPTY git submodule in the reference checkout (.gitmodules:5-8, no commit pinned), so this is
+the build's own module written from the published architecture (Zheng et al., "3D Human Pose Estimation with Spatial and
+Temporal Transformers", ICCV 2021, section 3 + the public repository's layer list) -- arithmetic parity with the third-party
+code is UNPINNED. Parameter names follow the published checkpoint layout so that a state_dict of the
+original loads: ``Spatial_patch_to_embedding``, ``Spatial_pos_embed``, ``Temporal_pos_embed``, ``Spatial_blocks.N.*``,
+``blocks.N.*`` (``norm1``, ``attn.qkv``, ``attn.proj``, ``norm2``, ``mlp.fc1``, ``mlp.fc2``), ``Spatial_norm``,
+``Temporal_norm``, ``weighted_mean``, ``head.0`` / ``head.1``.
+
+    x (B, F, J, C) 2-D keypoints of F = num_frame frames
+      per frame : joints are tokens -- Linear(C, E) + learned joint positions -> `depth` pre-norm transformer blocks (E wide)
+      per window: frames are tokens of width J*E + learned frame positions -> `depth` blocks -> LayerNorm
+      -> a learned weighted mean over the F frames (Conv1d(F, 1, 1)) -> LayerNorm + Linear(J*E, 3 J)
+    returns (B, 1, J, 3): the 3-D pose of the CENTRE frame.
+
+Attention runs through ``torch.nn.functional.scaled_dot_product_attention`` (library kernels): 26-token / 9-token sequences.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+class _DropPath(nn.Module):
+    """Stochastic depth: in training a sample's residual branch is dropped with probability p (survivors scaled by 1/(1-p))."""
+
+    def __init__(self, p: float = 0.0):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        if self.p == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.p
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias, qk_scale, attn_drop, proj_drop):
+        super().__init__()
+        self.num_heads, self.scale = num_heads, qk_scale if qk_scale is not None else (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = attn_drop
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        out = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop if self.training else 0.0, scale=self.scale)
+        return self.proj_drop(self.proj(out.transpose(1, 2).reshape(B, N, C)))
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden, drop):
+        super().__init__()
+        self.fc1, self.act, self.fc2, self.drop = nn.Linear(dim, hidden), nn.GELU(), nn.Linear(hidden, dim), nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop, attn_drop, drop_path, norm_layer):
+        super().__init__()
+        self.norm1, self.norm2 = norm_layer(dim), norm_layer(dim)
+        self.attn = _Attention(dim, num_heads, qkv_bias, qk_scale, attn_drop, drop)
+        self.drop_path = _DropPath(drop_path)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio), drop)
+
+    def forward(self, x):
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class PoseTransformer(nn.Module):
+    def __init__(self, num_frame=9, num_joints=17, in_chans=2, embed_dim_ratio=32, depth=4, num_heads=8, mlp_ratio=2.,
+                 qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or (lambda d: nn.LayerNorm(d, eps=1e-6))
+        embed_dim = embed_dim_ratio * num_joints
+        self.num_frame, self.num_joints = num_frame, num_joints
+        self.Spatial_patch_to_embedding = nn.Linear(in_chans, embed_dim_ratio)
+        self.Spatial_pos_embed = nn.Parameter(torch.zeros(1, num_joints, embed_dim_ratio))
+        self.Temporal_pos_embed = nn.Parameter(torch.zeros(1, num_frame, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [float(v) for v in torch.linspace(0, drop_path_rate, depth)]          # stochastic-depth decay rule
+        mk = lambda dim, i: _Block(dim, num_heads, mlp_ratio, qkv_bias, qk_scale, drop_rate, attn_drop_rate, dpr[i], norm_layer)  # noqa: E731
+        self.Spatial_blocks = nn.ModuleList([mk(embed_dim_ratio, i) for i in range(depth)])
+        self.blocks = nn.ModuleList([mk(embed_dim, i) for i in range(depth)])
+        self.Spatial_norm, self.Temporal_norm = norm_layer(embed_dim_ratio), norm_layer(embed_dim)
+        self.weighted_mean = nn.Conv1d(in_channels=num_frame, out_channels=1, kernel_size=1)
+        self.head = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, num_joints * 3))
+
+    def forward(self, x):
+        B, Fr, J, C = x.shape
+        t = self.Spatial_patch_to_embedding(x.reshape(B * Fr, J, C)) + self.Spatial_pos_embed
+        t = self.pos_drop(t)
+        for blk in self.Spatial_blocks:
+            t = blk(t)
+        t = self.Spatial_norm(t).reshape(B, Fr, -1) + self.Temporal_pos_embed
+        t = self.pos_drop(t)
+        for blk in self.blocks:
+            t = blk(t)
+        t = self.weighted_mean(self.Temporal_norm(t))                                # (B, 1, J*E): learned mean over the frames
+        return self.head(t).view(B, 1, J, 3)

@@ -577,8 +577,73 @@ def golden_models_extra():
         npz('model_' + name, frames=frames, n_params=sum(p.numel() for p in model.parameters()), **outs, **sd)
 
 
+def golden_metrics_extra():
+    """Section 9b (the rest): the reference's own MultiinputWrapper (metrics/multiinput_wrapper.py) around a
+    mean-squared-error base metric, and MissingJointsRatio (metrics/missing_joints_ratio.py), run on two batches each.
+    torchmetrics is absent: ``Metric`` gets the stand-in of section 9 and ``MeanSquaredError`` its public definition
+    (sum of squared errors / number of elements). The FB_* metrics wrap third_party/video_pose_3d (empty submodule): they
+    cannot be run here and stay parity-unpinned."""
+    class Metric(torch.nn.Module):
+        def __init__(self, dist_sync_on_step=False, **kwargs):
+            super().__init__()
+
+        def add_state(self, name, default, dist_reduce_fx=None):
+            setattr(self, name, default.clone())
+
+    class MeanSquaredError(Metric):
+        def __init__(self, **kwargs):
+            super().__init__(**kwargs)
+            self.add_state('sum_squared_error', torch.tensor(0.0))
+            self.add_state('total', torch.tensor(0))
+
+        def update(self, preds, target):
+            self.sum_squared_error += ((preds - target) ** 2).sum()
+            self.total += target.numel()
+
+        def compute(self):
+            return self.sum_squared_error / self.total
+
+    _module('torchmetrics', Metric=Metric, MeanSquaredError=MeanSquaredError)
+    from pedestrians_video_2_carla.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla.data.openpose.skeleton import BODY_25_SKELETON
+    from pedestrians_video_2_carla.metrics.missing_joints_ratio import MissingJointsRatio
+    from pedestrians_video_2_carla.metrics.multiinput_wrapper import MultiinputWrapper
+    g = torch.Generator().manual_seed(101)
+    out, batches = {}, []
+    for k in range(2):
+        B = 3 + k
+        b = dict(pred=torch.randn(B, 16, 26, 2, generator=g), gt=torch.randn(B, 16, 26, 2, generator=g),
+                 gt_b25=torch.randn(B, 16, 25, 2, generator=g))
+        b['gt'][torch.rand(B, 16, 26, generator=g) < 0.15] = 0           # missing ground-truth joints
+        b['gt_b25'][torch.rand(B, 16, 25, generator=g) < 0.15] = 0
+        b['pred_mj'] = b['pred'].clone()
+        b['pred_mj'][torch.rand(B, 16, 26, generator=g) < 0.2] = 0       # predicted "missing" joints for the ratio
+        batches.append(b)
+        for name, v in b.items():
+            out[f'b{k}_{name}'] = v
+    key = 'projection_2d_transformed'
+    mse = MultiinputWrapper(MeanSquaredError(), key, key, input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON)
+    mse_nomask = MultiinputWrapper(MeanSquaredError(), key, key, input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON,
+                                   mask_missing_joints=False)
+    mse_b25 = MultiinputWrapper(MeanSquaredError(), key, key, input_nodes=BODY_25_SKELETON, output_nodes=CARLA_SKELETON)
+    mjr = MissingJointsRatio(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON)
+    mjr_b25 = MissingJointsRatio(input_nodes=BODY_25_SKELETON, output_nodes=CARLA_SKELETON)
+    for b in batches:
+        mse.update({key: b['pred']}, {key: b['gt']})
+        mse_nomask.update({key: b['pred']}, {key: b['gt']})
+        mse_b25.update({key: b['pred']}, {key: b['gt_b25']})
+        mjr.update({'projection_2d': b['pred_mj']}, {})
+        mjr_b25.update({'projection_2d': b['pred_mj']}, {})
+    npz('metrics_extra', mse=mse.compute(), mse_nomask=mse_nomask.compute(), mse_b25=mse_b25.compute(), mjr=mjr.compute(),
+        mjr_b25=mjr_b25.compute(), mjr_present=mjr.present_joints, mjr_total=mjr.total, **out)
+
+
 if __name__ == '__main__':
-    if sys.argv[1:] == ['models_extra']:
+    if sys.argv[1:] == ['metrics_extra']:
+        install_standins()
+        sys.path.insert(0, REF_SRC)
+        golden_metrics_extra()
+    elif sys.argv[1:] == ['models_extra']:
         golden_models_extra()
     elif sys.argv[1:] == ['losses_extra']:
         golden_losses_extra()
@@ -591,3 +656,4 @@ if __name__ == '__main__':
     else:
         main()
         golden_metrics()
+        golden_metrics_extra()

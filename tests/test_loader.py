@@ -1,0 +1,106 @@
+"""Subset container, predict-mode writer (CPU) and the device loader feeding the train step (GPU).
+
+Reference: data/base/base_datamodule.py:334-359 (get_dataloader), :468-508 (_save_subset), :560-630 (save_predictions);
+data/base/base_dataset.py:206-234 (__getitem__)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _fake_subset(n=37, T=16, J=26, seed=0):
+    g = np.random.default_rng(seed)
+    projection_2d = (g.random((n, T, J, 2)) * 300 + 100).astype(np.float32)
+    targets = {'absolute_pose_loc': g.standard_normal((n, T, J, 3)).astype(np.float32),
+               'world_loc': np.zeros((n, T, 3), np.float32)}
+    ages, genders = ['adult', 'child'], ['female', 'male']
+    meta = {'age': [ages[i % 2] for i in range(n)], 'gender': [genders[(i // 2) % 2] for i in range(n)],
+            'video_id': [f'clip-{i:03d}' for i in range(n)], 'start_frame': np.arange(n, dtype=np.int64) * 16}
+    return projection_2d, targets, meta
+
+
+def test_subset_container_round_trip(tmp_path):
+    from pedestrians_video_2_carla_amd.data.base.subset_io import load_subset, save_subset
+    p2d, targets, meta = _fake_subset()
+    path = save_subset(str(tmp_path), 'train', p2d, targets, meta, prefer_hdf5=False)
+    assert path.endswith('train.npz')
+    with np.load(path) as d:                                   # the reference's key layout (base_datamodule.py:468-508)
+        assert {'projection_2d', 'targets/absolute_pose_loc', 'targets/world_loc', 'meta/age', 'meta/age__labels',
+                'meta/start_frame'} <= set(d.files)
+        assert d['meta/age'].dtype == np.uint16                # strings: uint16 codes + label table
+    q2d, qt, qm = load_subset(path)
+    assert np.array_equal(q2d, p2d) and all(np.array_equal(qt[k], targets[k]) for k in targets)
+    assert qm['age'] == meta['age'] and qm['video_id'] == meta['video_id'] and np.array_equal(qm['start_frame'], meta['start_frame'])
+
+
+def test_save_predictions_follows_the_reference(tmp_path):
+    from pedestrians_video_2_carla_amd.data.base.base_datamodule import BaseDataModule
+    from pedestrians_video_2_carla_amd.data.base.subset_io import load_subset
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    dm = BaseDataModule(data_nodes=CARLA_SKELETON, clip_length=4, batch_size=3)
+    g = torch.Generator().manual_seed(1)
+    outputs = []
+    for b in range(2):
+        B = 3 - b
+        sliced = {'projection_2d_transformed': torch.randn(B, 4, 26, 3, generator=g),
+                  'absolute_pose_loc': torch.randn(B, 4, 26, 3, generator=g), 'relative_pose_loc': None,
+                  'targets': {'absolute_pose_loc': torch.zeros(B, 4, 26, 3), 'relative_pose_loc': torch.ones(B, 4, 26, 3),
+                              'projection_2d_scale': torch.ones(B, 4), 'projection_2d_shift': torch.zeros(B, 4, 2),
+                              'world_loc': torch.zeros(B, 4, 3)}}
+        outputs.append((sliced, {'age': ['adult'] * B, 'gender': ['male'] * B, 'clip_id': torch.arange(B) + 10 * b}))
+    out_dir = dm.save_predictions('run7', outputs, ['projection_2d_transformed', 'absolute_pose_loc', 'relative_pose_loc'],
+                                  'projection_2d_transformed', str(tmp_path), predict_set_name='val', prefer_hdf5=False)
+    assert out_dir == os.path.join(str(tmp_path), 'Predictions', 'run7')
+    p2d, targets, meta = load_subset(os.path.join(out_dir, 'val.npz'))
+    assert p2d.shape == (5, 4, 26, 3)                          # the (normalised) predictions as they are: reference quirk
+    assert np.array_equal(p2d[:3], outputs[0][0]['projection_2d_transformed'].numpy())
+    assert set(targets) == {'absolute_pose_loc', 'relative_pose_loc', 'world_loc'}       # no projection_2d_* keys
+    assert np.array_equal(targets['absolute_pose_loc'][:3], outputs[0][0]['absolute_pose_loc'].numpy())   # prediction wins
+    assert (targets['relative_pose_loc'] == 1).all()           # no prediction (None): the target is kept
+    assert meta['age'] == ['adult'] * 5 and meta['clip_id'].tolist() == [0, 1, 2, 10, 11]
+
+
+@pytest.mark.gpu
+def test_device_loader_feeds_the_captured_train_step(tmp_path):
+    """Stored subset -> pinned staging -> H2D one batch ahead -> K11 -> Trainer: (i) a loader batch equals the input pipeline
+    run directly on the same rows; (ii) graph mode over the loader == eager over the loader, bit for bit, for 2 epochs."""
+    from pedestrians_video_2_carla_amd.data.base.subset_io import save_subset
+    from pedestrians_video_2_carla_amd.data.carla.carla_recorded_synthetic import SyntheticCarlaRecordedDataModule
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.pose_lifting import LitPoseLiftingFlow
+    from pedestrians_video_2_carla_amd.modules.movements.linear_ae import LinearAE
+    from pedestrians_video_2_carla_amd.trainer import Trainer, seed_everything
+    d = torch.device('cuda:0')
+    dm = SyntheticCarlaRecordedDataModule(clip_length=16, batch_size=32)
+    frames, targets, meta = dm.generate_batch(d, batch_size=150)     # the "dataset": raw projections + 3-D targets
+    path = save_subset(str(tmp_path), 'train', targets['projection_2d'].cpu().numpy(),
+                       {'absolute_pose_loc': targets['absolute_pose_loc'].cpu().numpy()},
+                       {'age': meta['age'], 'gender': meta['gender']}, prefer_hdf5=False)
+    loader = dm.get_dataloader(path, d, shuffle=True, missing_joint_probabilities=(0.1,), seed=5)
+    assert len(loader) == 4                                          # 150 // 32, ragged tail dropped
+    f0, t0, m0 = next(iter(loader))
+    assert f0.shape == (32, 16, 26, 2) and t0['projection_2d_transformed'].shape == (32, 16, 26, 2)
+    assert {'projection_2d', 'projection_2d_shift', 'projection_2d_scale', 'absolute_pose_loc'} <= set(t0)
+    assert len(m0['age']) == 32 and m0['skel_type'].dtype == torch.int32
+    # the rows really are the shuffled ones, and the targets are the (undeformed) normalisation of them
+    order = torch.randperm(150, generator=torch.Generator().manual_seed(5))[:32]
+    torch.testing.assert_close(t0['projection_2d'].cpu(), targets['projection_2d'].cpu()[order])
+    torch.testing.assert_close(t0['projection_2d_transformed'].cpu(), dm.transform_callable(targets['projection_2d'][order.to(d)]).cpu(),
+                               rtol=1e-5, atol=1e-6)
+    assert (f0 == 0).all(-1).float().mean() > 0.05                   # the deformation hit the model input
+
+    curves = {}
+    for graph in (False, True):
+        seed_everything(22742)
+        flow = LitPoseLiftingFlow(movements_model=LinearAE(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON),
+                                  loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
+        trainer = Trainer(device=d, use_graph=graph).setup(flow, dm)
+        ld = dm.get_dataloader(path, d, shuffle=True, missing_joint_probabilities=(0.1,), seed=5)
+        losses = []
+        for _epoch in range(2):
+            for i, batch in enumerate(ld):
+                losses.append(trainer.train_step(flow, batch, i).clone())
+        curves[graph] = torch.stack(losses).cpu()
+    assert len(curves[True]) == 8 and torch.isfinite(curves[True]).all()
+    assert torch.equal(curves[True], curves[False])

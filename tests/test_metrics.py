@@ -1,5 +1,7 @@
 """Validation metrics: oracle vs the reference's own MPJPE / MRPE / PCK classes (golden vectors, CPU), and the
 device metrics (HIP, through the C ABI) vs the oracle and the same golden vectors."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -92,3 +94,69 @@ def test_device_metrics_ragged_and_masked(B, T):
     assert abs(float(r.compute()) - 1000 * float(s) / n) <= 1e-5 * 1000 * float(s) / n
     c, tot = OM.pck_update(p2, g2)
     assert float(p._state[0]) == float(c) and float(p._state[2]) == float(tot)
+
+
+# ---- the rest of SURVEY 8f rank 1: MultiinputWrapper(MSE), MissingJointsRatio (pinned by the reference's own classes),
+# ---- FB_* (restated from the VideoPose3D definitions, parity-unpinned: checked against direct formulas) -------------------
+def _extra_batches(g):
+    return [{k[3:]: v for k, v in g.items() if k.startswith(f'b{i}_')} for i in range(2)]
+
+
+def test_multiinput_wrapper_and_missing_joints_ratio_match_the_reference(golden):
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.data.openpose.skeleton import BODY_25_SKELETON
+    from pedestrians_video_2_carla_amd.metrics import MeanSquaredError, MissingJointsRatio, MultiinputWrapper
+    g = golden('metrics_extra')
+    key = 'projection_2d_transformed'
+    mse = MultiinputWrapper(MeanSquaredError(), key, key, input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON)
+    mse_nomask = MultiinputWrapper(MeanSquaredError(), key, key, input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON,
+                                   mask_missing_joints=False)
+    mse_b25 = MultiinputWrapper(MeanSquaredError(), key, key, input_nodes=BODY_25_SKELETON, output_nodes=CARLA_SKELETON)
+    mjr = MissingJointsRatio(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON)
+    mjr_b25 = MissingJointsRatio(input_nodes=BODY_25_SKELETON, output_nodes=CARLA_SKELETON, report_per_joint=True)
+    for b in _extra_batches(g):
+        mse.update({key: b['pred']}, {key: b['gt']})
+        mse_nomask.update({key: b['pred']}, {key: b['gt']})
+        mse_b25.update({key: b['pred']}, {key: b['gt_b25']})
+        mjr.update({'projection_2d': b['pred_mj']}, {})
+        mjr_b25.update({'projection_2d': b['pred_mj']}, {})
+        mjr.update({}, {})                                  # no 'projection_2d': ignored, as in the reference
+    for got, want in ((mse.compute(), g['mse']), (mse_nomask.compute(), g['mse_nomask']), (mse_b25.compute(), g['mse_b25']),
+                      (mjr.compute(), g['mjr']), (mjr_b25.compute()['mean'], g['mjr_b25'])):
+        assert abs(float(got) - float(want)) <= 1e-6 * abs(float(want)), (float(got), float(want))
+    assert torch.equal(mjr._state[:-1].float(), g['mjr_present'].float()) and int(mjr._state[-1]) == int(g['mjr_total'])
+    assert len(mjr_b25.compute()['per_joint']) == 21
+    mse.reset()
+    assert float(mse.base_metric._state.abs().sum()) == 0
+
+
+def test_fb_metrics_follow_the_published_definitions():
+    from pedestrians_video_2_carla_amd.metrics import FB_MPJPE, FB_MPJVE, FB_N_MPJPE, FB_PA_MPJPE, FB_WeightedMPJPE
+    gen = torch.Generator().manual_seed(7)
+    tot = {k: 0.0 for k in ('mpjpe', 'n', 'v', 'pa')}
+    frames = 0
+    ms = {'mpjpe': FB_MPJPE(), 'w': FB_WeightedMPJPE(), 'n': FB_N_MPJPE(), 'v': FB_MPJVE(), 'pa': FB_PA_MPJPE()}
+    for B in (2, 3):
+        gt = torch.randn(B, 5, 26, 3, generator=gen, dtype=torch.float64)
+        # a similarity transform of the target + noise: Procrustes alignment must remove all but the noise
+        c, s = math.cos(0.7), math.sin(0.7)
+        R = torch.tensor([[c, -s, 0.], [s, c, 0.], [0., 0., 1.]], dtype=torch.float64)
+        noise = 0.01 * torch.randn(B, 5, 26, 3, generator=gen, dtype=torch.float64)
+        pred = 1.7 * (gt @ R) + torch.tensor([0.3, -0.2, 0.5], dtype=torch.float64) + noise
+        for m in ms.values():
+            m.update({'absolute_pose_loc': pred}, {'absolute_pose_loc': gt})
+            m.update({'absolute_pose_loc': pred[:, :2]}, {'absolute_pose_loc': gt})      # shape mismatch: ignored (AssertionError)
+        n = B * 5
+        frames += n
+        tot['mpjpe'] += n * float((pred - gt).norm(dim=-1).mean())
+        scale = (gt * pred).sum(-1, keepdim=True).mean(2, keepdim=True) / (pred ** 2).sum(-1, keepdim=True).mean(2, keepdim=True)
+        tot['n'] += n * float((scale * pred - gt).norm(dim=-1).mean())
+        fp, fg = pred.reshape(-1, 26, 3), gt.reshape(-1, 26, 3)
+        tot['v'] += n * float(((fp[1:] - fp[:-1]) - (fg[1:] - fg[:-1])).norm(dim=-1).mean())
+        tot['pa'] = max(tot['pa'], float(noise.norm(dim=-1).mean()))
+    assert abs(float(ms['mpjpe'].compute()) - 1000 * tot['mpjpe'] / frames) < 1e-3 * 1000 * tot['mpjpe'] / frames
+    assert abs(float(ms['w'].compute()) - float(ms['mpjpe'].compute())) < 1e-6 * float(ms['mpjpe'].compute())   # unit weights
+    assert abs(float(ms['n'].compute()) - 1000 * tot['n'] / frames) < 1e-6 * 1000 * tot['n'] / frames
+    assert abs(float(ms['v'].compute()) - 1000 * tot['v'] / frames) < 1e-6 * 1000 * tot['v'] / frames
+    pa = float(ms['pa'].compute())
+    assert 0 < pa <= 1000 * tot['pa'] * 1.05 and pa < 0.05 * float(ms['mpjpe'].compute())     # the similarity transform is gone

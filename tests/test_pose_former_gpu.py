@@ -1,0 +1,85 @@
+"""GPU: PoseFormer (BASELINE.json configs[4]) through the pose-lifting flow at clip_length 81.
+
+The transformer's arithmetic is parity-unpinned (third-party source absent from the reference checkout): what is checked is
+what the reference owns -- the window wrapper (pose_former.py:117-127), eval_slice (:114-115), the optimizer / scheduler
+(:129-138) -- plus properties of the build's restatement (shapes, centre-frame dependence, permutation of the batch) and
+one captured train step of cfg5's per-GPU share."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _model(T):
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.movements.pose_former import PoseFormer
+    torch.manual_seed(5)
+    return PoseFormer(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, clip_length=T)
+
+
+def test_batched_windows_equal_the_reference_loop_and_properties():
+    T = 30
+    m = _model(T).to(dev()).eval()
+    assert sum(p.numel() for p in m.parameters()) == 22298744      # 4 + 4 blocks at widths 32 / 832, 26 joints
+    x = torch.randn(3, T, 26, 2, device=dev())
+    with torch.no_grad():
+        y = m(x)
+        ref = torch.zeros(3, T, 26, 3, device=dev())
+        for i in range(T - 9 + 1):                                 # pose_former.py:121-125, written out
+            ref[:, i + 4:i + 9 + 4] = m.pose_former(x[:, i:i + 9])
+        assert torch.allclose(y, ref, rtol=1e-4, atol=1e-5), (y - ref).abs().max()
+        assert m.eval_slice == slice(4, 26) and (y[:, :4] == 0).all()
+        # a window's output depends on its nine frames only, and clips do not talk to each other
+        x2 = x.clone()
+        x2[:, 20:] += 1.0
+        y2 = m(x2)
+        assert torch.equal(y2[:, 4:15], y[:, 4:15]) and not torch.allclose(y2[:, 16:], y[:, 16:])
+        assert torch.allclose(m(x[[2, 0, 1]]), y[[2, 0, 1]], rtol=1e-4, atol=1e-5)
+    cfg = m.configure_optimizers()
+    assert cfg['optimizer'].defaults['lr'] == 4e-4 and cfg['optimizer'].defaults['weight_decay'] == 0.1
+    assert isinstance(cfg['lr_scheduler'], torch.optim.lr_scheduler.ExponentialLR) and cfg['lr_scheduler'].gamma == 0.99
+
+
+def test_cfg5_train_steps_through_the_flow_with_lr_schedule():
+    """clip_length 81, BODY_25 data mapped onto the CARLA input skeleton with zero fill, absolute_loc head (K1b), loss over
+    frames [4, 77), AdamW + ExponentialLR stepped at epoch ends; eager and captured steps agree."""
+    from pedestrians_video_2_carla_amd.data.base.skeleton import get_common_indices
+    from pedestrians_video_2_carla_amd.data.carla.carla_recorded_synthetic import SyntheticCarlaRecordedDataModule
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.data.openpose.skeleton import BODY_25_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.pose_lifting import LitPoseLiftingFlow
+    from pedestrians_video_2_carla_amd.trainer import Trainer
+    d, T, B = dev(), 81, 8
+    dm = SyntheticCarlaRecordedDataModule(clip_length=T, batch_size=B)
+    frames, targets, meta = dm.generate_batch(d)
+    carla_idx, _ = get_common_indices(input_nodes=BODY_25_SKELETON, output_nodes=CARLA_SKELETON)
+    missing = [j for j in range(26) if j not in carla_idx]         # CARLA joints OpenPose does not see: zero-filled
+    frames[:, :, missing] = 0
+    targets['projection_2d_transformed'][:, :, missing] = 0
+    batch = (frames, targets, meta)
+    curves = {}
+    for graph in (False, True):
+        flow = LitPoseLiftingFlow(movements_model=_model(T), loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
+        trainer = Trainer(device=d, use_graph=graph, steps_per_epoch=2).setup(flow, dm)
+        assert len(trainer.lr_schedulers) == 1 and trainer.lr_schedulers[0]['interval'] == 'epoch'
+        flow.movements_model.train()
+        for blk in list(flow.movements_model.pose_former.Spatial_blocks) + list(flow.movements_model.pose_former.blocks):
+            blk.drop_path.p = 0.0                                   # stochastic depth off: the two runs must agree
+        losses = trainer.fit_steps(flow, [batch] * 4) if hasattr(trainer, 'fit_steps') else None
+        if losses is None:
+            losses = []
+            for i in range(4):
+                losses.append(trainer.train_step(flow, batch, i).clone())
+                if (i + 1) % 2 == 0:
+                    trainer.current_epoch += 1
+                    trainer.step_lr_schedulers('epoch')
+        curves[graph] = torch.stack(losses).cpu()
+        lr = trainer.optimizers[0].param_groups[0]['lr']
+        assert abs(lr - 4e-4 * 0.99 ** 2) < 1e-12, lr               # two epoch ends
+    assert torch.isfinite(curves[False]).all() and curves[False][-1] < curves[False][0]
+    assert torch.allclose(curves[True], curves[False], rtol=2e-3), (curves[True], curves[False])
