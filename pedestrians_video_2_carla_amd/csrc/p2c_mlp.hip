@@ -868,7 +868,16 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   int blocks = n_blocks(a.N);
   p2c_optim::Coefs *coefs = nullptr;
   allow_big_lds();
-  if (d->fused_adamw && (!d->fused_adamw->step || !d->fused_adamw->hyper)) return P2C_E_NULL;
+  if (d->fused_adamw) {                                         // everything about the optimizer BEFORE the first launch
+    const p2c_adamw_desc &o = *d->fused_adamw;
+    if (!o.param || !o.grad || !o.exp_avg || !o.exp_avg_sq || !o.step || !o.ticket || !o.hyper) return P2C_E_NULL;
+    for (int l = 0; l < a.n_layers; ++l) {                      // every gradient tensor must be a view of the optimizer's grad
+      const float *lo = o.grad, *hi = o.grad + o.n;
+      if (a.gW[l] < lo || a.gW[l] + (size_t)a.dims[l + 1] * a.dims[l] > hi || a.gb[l] < lo || a.gb[l] + a.dims[l + 1] > hi)
+        return P2C_E_INDEX;
+    }
+    if ((int64_t)a.n_params != o.n) return P2C_E_SHAPE;         // the MLP must be ALL the optimizer optimises (step counter)
+  }
   if (split_wgrad(a.N)) {
     const int n_stiles = (int)((a.N + TS - 1) / TS);
     a.factors = a.partials + (size_t)WGRAD_KS * a.n_tiles_w * 256;      // [KS partial tiles | factors]
@@ -884,14 +893,7 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   }
   const dim3 rgrid(a.n_tiles_w * (64 / RL)), rblock(RL * RG), sgrid((a.n_tiles_w * 64 + 255) / 256);
   if (d->fused_adamw) {
-    const p2c_adamw_desc o = *d->fused_adamw;
-    if (!o.param || !o.grad || !o.exp_avg || !o.exp_avg_sq || !o.step || !o.ticket || !o.hyper) return P2C_E_NULL;
-    for (int l = 0; l < a.n_layers; ++l) {                    // every gradient tensor must be a view of the optimizer's grad
-      const float *lo = o.grad, *hi = o.grad + o.n;
-      if (a.gW[l] < lo || a.gW[l] + (size_t)a.dims[l + 1] * a.dims[l] > hi || a.gb[l] < lo || a.gb[l] + a.dims[l + 1] > hi)
-        return P2C_E_INDEX;
-    }
-    if ((int64_t)a.n_params != o.n) return P2C_E_SHAPE;       // the MLP must be ALL the optimizer optimises (step counter)
+    const p2c_adamw_desc o = *d->fused_adamw;                 // (validated above, before the first launch)
     if (coefs)
       hipLaunchKernelGGL((mlp_reduce_small_kernel<true, WGRAD_KS>), sgrid, dim3(256), 0, (hipStream_t)stream_, a, o, coefs);
     else

@@ -174,10 +174,12 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         NB: (hidden, cell) are the encoder's for every frame -- see module docstring. ``force_indices`` (B,) bool and
         ``target`` (B,O) replace the reference's boolean-mask writes by ``torch.where`` (no host sync)."""
         out, _, _ = self.decoder(step_in, hidden, cell)
-        step_in = out
         if needs_forcing:
-            step_in = torch.where(force_indices.unsqueeze(-1), target, out)
-        return step_in, out
+            # the reference writes the forced rows INTO the decoder output (``input = output; input[idx] = target``, one
+            # tensor under two names, seq2seq.py:283-288): the forced values are also what ``outputs[t]`` receives, so those
+            # rows carry zero loss and zero gradient. Same here: one tensor is both the next input and the frame's output.
+            out = torch.where(force_indices.unsqueeze(-1), target, out)
+        return out, out
 
     def _encode(self, x: Tensor) -> Tuple[Tensor, Tensor]:
         return self.encoder(self._format_input(x))

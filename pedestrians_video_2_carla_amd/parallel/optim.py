@@ -7,7 +7,9 @@ With every parameter a view of one flat buffer (parallel/flat.py) the step is a 
     an LR scheduler (``param_groups[0]['lr']`` is re-uploaded when it changes);
   * the 1/world_size gradient averaging of data-parallel training (``grad_scale``) and next step's ``zero_grad`` are
     folded into the same pass.
-``state_dict()`` has torch's layout (``step``, ``exp_avg``, ``exp_avg_sq``), so checkpoints are interchangeable.
+``state_dict()`` has torch's layout (``step``, ``exp_avg``, ``exp_avg_sq``) for ONE flat parameter: it is interchangeable with a
+torch.optim.AdamW built over the same flat tensor, NOT with the reference's per-parameter optimizer state (there the moments
+are one pair per module parameter; slicing the flat moments by ``FlatParameters.params`` offsets converts between the two).
 """
 import ctypes
 

@@ -89,3 +89,42 @@ def test_two_ranks_match_single_process_mean_of_losses(tmp_path):
             trainer._optimizer_step()
     assert torch.allclose(trainer.flat.flat_param, p0, rtol=1e-5, atol=1e-7)
     assert p0.numel() == 17530                 # LinearAE pose_changes: the 70 120-byte all-reduce payload
+
+
+# ---- the agreement protocol that guards the captured all-reduce (Trainer._capture_with_allreduce), two ranks, one failing ----
+def _agree_worker(rank, world, port, out_dir):
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pedestrians_video_2_carla_amd.trainer import init_distributed, ranks_agree
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    init_distributed('gloo')
+    cpu = torch.device('cpu')
+    same = torch.tensor(1234.5678, dtype=torch.float64)
+    res = {
+        'all_ok': ranks_agree(True, cpu),
+        'one_failed': ranks_agree(rank != 1, cpu),                       # rank 1's capture raised: NOBODY may replay
+        'same_checksum': ranks_agree(True, cpu, same),
+        'different_checksum': ranks_agree(True, cpu, same + (1e-9 if rank == 1 else 0.0)),   # parameters differ in the last bits
+        'one_failed_with_checksum': ranks_agree(rank != 0, cpu, same),   # the failing rank contributes no checksum
+        'nan_checksum': ranks_agree(True, cpu, torch.tensor(float('nan'), dtype=torch.float64)),
+        'after': ranks_agree(True, cpu, same),                           # the protocol leaves the group usable
+    }
+    with open(os.path.join(out_dir, f'agree{rank}.json'), 'w') as f:
+        json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_capture_agreement_protocol_with_a_failing_rank(tmp_path):
+    """Every rank reaches the same verdict, and a single failing rank (or diverging parameters) sends ALL ranks to the eager
+    collective: a healthy rank never replays a graph holding an all-reduce its peer is not going to enter."""
+    import json
+    world = 2
+    mp.spawn(_agree_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = (json.load(open(os.path.join(tmp_path, f'agree{r}.json'))) for r in range(world))
+    assert r0 == r1
+    assert r0 == {'all_ok': True, 'one_failed': False, 'same_checksum': True, 'different_checksum': False,
+                  'one_failed_with_checksum': False, 'nan_checksum': False, 'after': True}
