@@ -445,10 +445,43 @@ def extra_config(device, name, steps=100, warmup=10):
     out = {'workload': workload, 'B': B, 'ms_per_step': round(dt * 1e3, 4), 'clips_per_s': round(B / dt, 1), 'dtype': 'f32',
            'hip_graph': True, 'steps': steps, 'final_loss': float(loss)}
     if name == 'cfg2':
-        out['note'] = ('configs[1] names bf16: the LinearAE runs exact fp32 MFMA (bit-for-bit an fmaf chain); no bf16 arm is '
-                       'built, so no reduced-precision number is claimed')
         mt, flops = mlp_times(device, model, B, getattr(trainer, '_opt_in_backward', False))
         out['roofline'] = [mfma_entry(k, B, mt[k], fl) for k, fl in flops.items()]
+        # configs[1] names bf16: the opt-in operand-precision arms of the fused MLP (accumulation stays fp32), each with its step
+        # time and the deviation of one real training step (same init, same batch) from the exact-fp32 step: loss, and the
+        # flat parameter gradient relative to its largest entry. fp32 remains the default and the headline.
+        arms = {}
+        ref = None
+        for prec in ('fp32', 'bf16x3', 'bf16'):
+            seed_everything(22742)
+            m = LinearAE(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, mlp_precision=prec)
+            fl = LitPoseLiftingFlow(movements_model=m, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
+            os.environ['P2C_FUSED_UPDATE'] = '0'                 # keep the gradient of the probe step
+            tr = Trainer(device=device, use_graph=False).setup(fl, dm)
+            tr.optimizers[0].zero_grad_in_step = False
+            loss1 = float(tr._forward_backward(fl, batch, 0))
+            grad = tr.flat.flat_grad.detach().double().clone()
+            os.environ.pop('P2C_FUSED_UPDATE', None)
+            seed_everything(22742)
+            m2 = LinearAE(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, mlp_precision=prec)
+            fl2 = LitPoseLiftingFlow(movements_model=m2, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
+            tr2 = Trainer(device=device, use_graph=True).setup(fl2, dm)
+            for i in range(warmup):
+                tr2.train_step(fl2, batch, i)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                tr2.train_step(fl2, batch, i)
+            torch.cuda.synchronize(device)
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            if ref is None:
+                ref = (loss1, grad)
+            arms[prec] = {'ms_per_step': round(ms, 4), 'clips_per_s': round(B / ms * 1e3, 1),
+                          'loss_rel_dev_vs_fp32': abs(loss1 - ref[0]) / abs(ref[0]),
+                          'grad_rel_dev_vs_fp32': float((grad - ref[1]).abs().max() / ref[1].abs().max())}
+        out['precision_arms'] = arms
+        out['note'] = ('dtype f32 = the default, exact fp32 MFMA (bit-for-bit an fmaf chain). precision_arms: opt-in bf16 / split-bf16 '
+                       'operands (LinearAE(mlp_precision=...) or P2C_MLP_PRECISION), fp32 accumulate; the pose head stays fp32')
     elif name == 'cfg5':
         out['note'] = ('transformer arithmetic parity-unpinned (third-party source absent); attention / GEMMs are library kernels, '
                        'the pose head is the HIP absolute_loc kernel; stochastic depth (0.2) on')

@@ -174,6 +174,13 @@ P2C_API int p2c_remap_nodes(const float *src, float *dst, int64_t N, int32_t Jsr
  * partial gradient tiles + reduction, or -- around one 16-row tile per CU -- activation / gradient factors + a contraction
  * over all rows + reduction (environment P2C_MLP_WGRAD=fused|split overrides the choice); the workspace size covers both. */
 #define P2C_MLP_MAX_LAYERS 8
+/* operand precision of the MLP's matrix products (accumulation is always fp32):
+ *   F32    v_mfma_f32_16x16x4_f32, bit-for-bit an fmaf chain (default; what every parity claim is made with)
+ *   BF16   operands rounded to bf16, v_mfma_f32_16x16x16_bf16: 1/8 of the MFMA cycles, ~2^-9 relative error per product
+ *   BF16X3 split-bf16 (hi + lo, three MFMAs): ~fp32-grade products at 3/8 of the cycles
+ * The reduced-precision arms exist for the LinearAE shapes with compile-time geometry (BASELINE.json configs[1] names bf16);
+ * any other shape with precision != F32 returns P2C_E_ENUM. */
+enum { P2C_PREC_F32 = 0, P2C_PREC_BF16 = 1, P2C_PREC_BF16X3 = 2 };
 struct p2c_adamw_desc;
 typedef struct p2c_mlp_desc {
   int32_t n_layers;
@@ -199,6 +206,7 @@ typedef struct p2c_mlp_desc {
   float *saved;                         /* optional, p2c_mlp_saved_floats floats (0 = not worth it at this N: pass NULL): the
                                            forward leaves the hidden activations there and the backward of the SAME call pair
                                            loads them instead of recomputing (bit-identical results) */
+  int32_t precision;                    /* P2C_PREC_*: same value for the forward and the backward of a step */
 } p2c_mlp_desc;
 P2C_API int64_t p2c_mlp_image_floats(const p2c_mlp_desc *desc);
 /* writes the packed image from the current weights (what p2c_mlp_fwd does first unless skip_pack) */

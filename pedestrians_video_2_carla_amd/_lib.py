@@ -12,6 +12,7 @@ P2C_JOINTS = 26
 
 KIND = {'pose_changes_6d': 0, 'pose_changes': 1, 'relative_rot_6d': 2, 'relative_rot': 3, 'absolute_loc': 4}
 TRANSFORM = {'none': 0, 'hips_neck': 1, 'bbox': 2, 'hips_neck_bbox': 3}
+PRECISION = {'fp32': 0, 'bf16': 1, 'bf16x3': 2}
 
 _f32p = ctypes.c_void_p  # device pointers travel as plain addresses
 _i32 = ctypes.c_int32
@@ -47,7 +48,7 @@ class MlpDesc(ctypes.Structure):
         ('n_layers', _i32), ('dims', _i32 * (P2C_MLP_MAX_LAYERS + 1)), ('N', ctypes.c_int64), ('x', _f32p),
         ('W', _f32p * P2C_MLP_MAX_LAYERS), ('b', _f32p * P2C_MLP_MAX_LAYERS), ('y', _f32p), ('gy', _f32p),
         ('gW', _f32p * P2C_MLP_MAX_LAYERS), ('gb', _f32p * P2C_MLP_MAX_LAYERS), ('partials', _f32p), ('w_image', _f32p),
-        ('fused_adamw', _f32p), ('skip_pack', ctypes.c_int32), ('saved', _f32p),
+        ('fused_adamw', _f32p), ('skip_pack', ctypes.c_int32), ('saved', _f32p), ('precision', ctypes.c_int32),
     ]
 
 

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const MlpArgs a) {
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
 // LDS: [weight images | H_0 .. H_{L-1}]   (the input rows of layer l are H_l, its output H_{l+1})
-template <class S>
+template <class S, int P = P2C_PREC_F32>
 __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
   const S sh(a);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
       if constexpr (S::kStatic && first) stage_issue(a.w_image, total4, wr, 0, issue_mark<S>(l + 1), issue_mark<S>(l + 2));
       TR(0, 3 + l);
       const bool last = (l == nl - 1);
-      layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), !last, H + sh.h_off(l) * TP,
+      layer_forward<P>(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), !last, H + sh.h_off(l) * TP,
                     last ? nullptr : H + sh.h_off(l + 1) * TP, last ? a.y + row * sh.dims(l + 1) : nullptr, row_ok,
                     a.vec_y != 0);
     });
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_fwd_kernel(const MlpArgs a) {
 #endif
 constexpr int FW_WAVES = P2C_FW_WAVES;
 constexpr int FW_XU = (TS * (MAXW - 1) + 63) / 64;   // x-tile floats per lane (static shapes use dims(0) * 16 / 64 of them)
-template <class S>
+template <class S, int P = P2C_PREC_F32>
 __global__ __launch_bounds__(64 * FW_WAVES) void mlp_fwd_wave_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
   const S sh(a);
@@ -198,9 +198,9 @@ __global__ __launch_bounds__(64 * FW_WAVES) void mlp_fwd_wave_kernel(const MlpAr
       float *y_row = last ? a.y + row * n_out : nullptr;
       for (int nt = 0; nt < ntiles; nt += 2) {
         if (nt + 1 < ntiles)
-          layer_forward_nt<2, 1>(L, wl, sh.ld(l), ksteps, nt, n_out, !last, in, last ? nullptr : out, y_row, row_ok, a.vec_y != 0);
+          layer_forward_nt<2, 1, P>(L, wl, sh.ld(l), ksteps, nt, n_out, !last, in, last ? nullptr : out, y_row, row_ok, a.vec_y != 0);
         else
-          layer_forward_nt<1, 1>(L, wl, sh.ld(l), ksteps, nt, n_out, !last, in, last ? nullptr : out, y_row, row_ok, a.vec_y != 0);
+          layer_forward_nt<1, 1, P>(L, wl, sh.ld(l), ksteps, nt, n_out, !last, in, last ? nullptr : out, y_row, row_ok, a.vec_y != 0);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64 * FW_WAVES) void mlp_fwd_wave_kernel(const MlpAr
 
 // ---- backward --------------------------------------------------------------------------------------------------------
 // LDS: [weight images | H_0 .. H_{L-1} | G_1 .. G_L (G_L = gy tile)]
-template <class S, bool FACTORS = false, bool SAVED = false>
+template <class S, bool FACTORS = false, bool SAVED = false, int P = P2C_PREC_F32>
 __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
   extern __shared__ float lds[];
   const S sh(a);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
           if (static_layers<S>() >= 4 && l == 2) tile_issue(a.gy, row0, a.N, sh.dims(nl), a.vec_gy != 0, gr);   // behind the image
         }
         TR(1, 3 + l);
-        layer_forward(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), true, H + sh.h_off(l) * TP,
+        layer_forward<P>(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), true, H + sh.h_off(l) * TP,
                       H + sh.h_off(l + 1) * TP, nullptr, false, false);
       });
       // the last layer's image (first use: the head of the dgrad chain) and the gy tile arrive behind the recomputation
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
     for_layers_down(sh, nl - 1, 1, [&](int l) {
       lds_barrier();
       TR(1, 12 + l);
-      layer_dgrad(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), G + sh.h_off(l + 1) * TP, H + sh.h_off(l) * TP,
+      layer_dgrad<P>(L, lds + sh.w_off(l), sh.ld(l), sh.dims(l), sh.dims(l + 1), G + sh.h_off(l + 1) * TP, H + sh.h_off(l) * TP,
                   G + sh.h_off(l) * TP);
     });
     lds_barrier();
@@ -336,8 +336,8 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_bwd_kernel(const MlpArgs a) {
       float av[4], bv[4];
 #pragma unroll
       for (int s = 0; s < TS / 4; ++s) av[s] = gp[4 * s], bv[s] = hp[4 * s];
-#pragma unroll
-      for (int s = 0; s < TS / 4; ++s) acc[slot] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s], acc[slot], 0, 0, 0);
+      static_assert(TS == 16, "one group of four k-steps per sample tile");
+      acc[slot] = mfma_k16<P>(av, bv, acc[slot]);
       if (last_tile && t < a.n_tiles_w) __builtin_nontemporal_store(acc[slot], &part[t * 64 + L.lane]);   // read once, by another kernel
     }
     }
@@ -371,6 +371,7 @@ constexpr int WG_UNROLL = 4;
 constexpr int WGW = P2C_WGRAD_WAVES;   // waves per workgroup of the contraction
 // `o` / `coefs_out` (optimizer in backward): the double-precision bias corrections of this step are worked out here, by
 // one thread, while the contraction runs -- the reduction that follows only loads them.
+template <int P = P2C_PREC_F32>
 __global__ __launch_bounds__(64 * WGW) void mlp_wgrad_kernel(const MlpArgs a, int n_stiles, int ks, const p2c_adamw_desc o,
                                                                p2c_optim::Coefs *coefs_out) {
   __shared__ f32x4 red[WGW][64];
@@ -423,14 +424,14 @@ __global__ __launch_bounds__(64 * WGW) void mlp_wgrad_kernel(const MlpArgs a, in
     for (int u = 0; u < WG_UNROLL; ++u) av[u] = load_a(st + u * step), bv[u] = load_b(st + u * step);
 #pragma unroll
     for (int u = 0; u < WG_UNROLL; ++u) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][i], bv[u][i], acc, 0, 0, 0);
+      const float a4[4] = {av[u][0], av[u][1], av[u][2], av[u][3]}, b4[4] = {bv[u][0], bv[u][1], bv[u][2], bv[u][3]};
+      acc = mfma_k16<P>(a4, b4, acc);
     }
   }
   for (; st < n_stiles; st += step) {
     const f32x4 av = load_a(st), bv = load_b(st);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+    const float a4[4] = {av[0], av[1], av[2], av[3]}, b4[4] = {bv[0], bv[1], bv[2], bv[3]};
+    acc = mfma_k16<P>(a4, b4, acc);
   }
   // (after this wave's loads and MFMAs are in the pipes: the fp64 arithmetic of one thread hides behind them)
   if (coefs_out && blockIdx.x == 0 && threadIdx.x == 64 * WGW - 1) *coefs_out = p2c_optim::coefs(o, *o.step + 1.f);
@@ -694,16 +695,20 @@ static bool wave_forward(const MlpArgs &a) {
   if (mode == 1) return true;
   return (a.N + TS - 1) / TS >= (int64_t)FW_WAVES * max_blocks();
 }
-template <class S>
+template <class S, int P = P2C_PREC_F32>
 static mlp_kernel_t pick_wave_of() {
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void *)mlp_fwd_wave_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)mlp_fwd_wave_kernel<S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     done = true;
   }
-  return mlp_fwd_wave_kernel<S>;
+  return mlp_fwd_wave_kernel<S, P>;
 }
-static mlp_kernel_t pick_wave(const MlpArgs &a) {
+// reduced-precision arms: LinearAE with the 6-D rotation output only (BASELINE.json configs[1]); nullptr = not available
+static bool reduced_ok(const MlpArgs &a) { return !force_generic() && LinearAE156::matches(a); }
+static mlp_kernel_t pick_wave(const MlpArgs &a, int prec) {
+  if (prec == P2C_PREC_BF16) return reduced_ok(a) ? pick_wave_of<LinearAE156, P2C_PREC_BF16>() : nullptr;
+  if (prec == P2C_PREC_BF16X3) return reduced_ok(a) ? pick_wave_of<LinearAE156, P2C_PREC_BF16X3>() : nullptr;
   if (!force_generic()) {
     if (LinearAE156::matches(a)) return pick_wave_of<LinearAE156>();
     if (LinearAE78::matches(a)) return pick_wave_of<LinearAE78>();
@@ -711,13 +716,25 @@ static mlp_kernel_t pick_wave(const MlpArgs &a) {
   }
   return pick_wave_of<DynShape>();
 }
-template <class S>
+template <class S, int P = P2C_PREC_F32>
 static mlp_kernel_t pick_of(bool bwd, bool factors, bool saved) {
-  if (!bwd) return mlp_fwd_kernel<S>;
-  if (factors) return mlp_bwd_kernel<S, true>;
-  return saved ? mlp_bwd_kernel<S, false, true> : mlp_bwd_kernel<S, false>;
+  if constexpr (P != P2C_PREC_F32) {
+    static bool done = false;
+    if (!done) {
+      (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S, false, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S, true, false, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)mlp_bwd_kernel<S, false, true, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void *)mlp_fwd_kernel<S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      done = true;
+    }
+  }
+  if (!bwd) return mlp_fwd_kernel<S, P>;
+  if (factors) return mlp_bwd_kernel<S, true, false, P>;
+  return saved ? mlp_bwd_kernel<S, false, true, P> : mlp_bwd_kernel<S, false, false, P>;
 }
-static mlp_kernel_t pick(const MlpArgs &a, bool bwd, bool factors = false, bool saved = false) {
+static mlp_kernel_t pick(const MlpArgs &a, int prec, bool bwd, bool factors = false, bool saved = false) {
+  if (prec == P2C_PREC_BF16) return reduced_ok(a) ? pick_of<LinearAE156, P2C_PREC_BF16>(bwd, factors, saved) : nullptr;
+  if (prec == P2C_PREC_BF16X3) return reduced_ok(a) ? pick_of<LinearAE156, P2C_PREC_BF16X3>(bwd, factors, saved) : nullptr;
   if (!force_generic()) {
     if (LinearAE156::matches(a)) return pick_of<LinearAE156>(bwd, factors, saved);
     if (LinearAE78::matches(a)) return pick_of<LinearAE78>(bwd, factors, saved);
@@ -843,13 +860,15 @@ extern "C" int p2c_mlp_fwd(const p2c_mlp_desc *d, void *stream_) {
   allow_big_lds();
   if (!d->skip_pack)
     hipLaunchKernelGGL(mlp_pack_kernel, dim3((a.w_total + 255) / 256), dim3(256), 0, (hipStream_t)stream_, a);
+  const int prec = d->precision;
+  if (prec < P2C_PREC_F32 || prec > P2C_PREC_BF16X3 || (prec != P2C_PREC_F32 && !reduced_ok(a))) return P2C_E_ENUM;
   if (wave_forward(a)) {
     const int64_t groups = ((a.N + TS - 1) / TS + FW_WAVES - 1) / FW_WAVES;
     const int cap = max_blocks();
-    hipLaunchKernelGGL(pick_wave(a), dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * FW_WAVES), lds_fwd_wave(a),
+    hipLaunchKernelGGL(pick_wave(a, prec), dim3((unsigned)(groups < cap ? groups : cap)), dim3(64 * FW_WAVES), lds_fwd_wave(a),
                        (hipStream_t)stream_, a);
   } else {
-    hipLaunchKernelGGL(pick(a, false), dim3(n_blocks(a.N)), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+    hipLaunchKernelGGL(pick(a, prec, false), dim3(n_blocks(a.N)), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -863,6 +882,8 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   for (int l = 0; l < a.n_layers; ++l)
     if (!a.gW[l] || !a.gb[l]) return P2C_E_NULL;
   if (a.n_tiles_w > MAX_SLOTS * WAVES) return P2C_E_SHAPE;
+  const int prec = d->precision;
+  if (prec < P2C_PREC_F32 || prec > P2C_PREC_BF16X3 || (prec != P2C_PREC_F32 && !reduced_ok(a))) return P2C_E_ENUM;
   const size_t lds = lds_bwd(a);
   if (lds > 160 * 1024) return P2C_E_SHAPE;
   int blocks = n_blocks(a.N);
@@ -881,15 +902,17 @@ extern "C" int p2c_mlp_bwd(const p2c_mlp_desc *d, void *stream_) {
   if (split_wgrad(a.N)) {
     const int n_stiles = (int)((a.N + TS - 1) / TS);
     a.factors = a.partials + (size_t)WGRAD_KS * a.n_tiles_w * 256;      // [KS partial tiles | factors]
-    hipLaunchKernelGGL(pick(a, true, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+    hipLaunchKernelGGL(pick(a, prec, true, true), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
     coefs = reinterpret_cast<p2c_optim::Coefs *>(a.factors + (size_t)n_stiles * a.f_rows * 16);
-    hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(a.n_tiles_w * WGRAD_KS), dim3(64 * WGW), 0, (hipStream_t)stream_, a,
+    const auto wgrad = prec == P2C_PREC_BF16 ? mlp_wgrad_kernel<P2C_PREC_BF16>
+                       : (prec == P2C_PREC_BF16X3 ? mlp_wgrad_kernel<P2C_PREC_BF16X3> : mlp_wgrad_kernel<P2C_PREC_F32>);
+    hipLaunchKernelGGL(wgrad, dim3(a.n_tiles_w * WGRAD_KS), dim3(64 * WGW), 0, (hipStream_t)stream_, a,
                        n_stiles, WGRAD_KS, d->fused_adamw ? *d->fused_adamw : p2c_adamw_desc{},
                        d->fused_adamw ? coefs : nullptr);
     blocks = WGRAD_KS;                                                   // what the reduction adds up
   } else {
     const bool saved = a.saved && save_activations(a);
-    hipLaunchKernelGGL(pick(a, true, false, saved), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
+    hipLaunchKernelGGL(pick(a, prec, true, false, saved), dim3(blocks), dim3(64 * WAVES), lds, (hipStream_t)stream_, a);
   }
   const dim3 rgrid(a.n_tiles_w * (64 / RL)), rblock(RL * RG), sgrid((a.n_tiles_w * 64 + 255) / 256);
   if (d->fused_adamw) {

@@ -242,6 +242,51 @@ struct Lane {
   int lane, c, g, wave;   // c = lane & 15 (sample / column), g = lane >> 4
 };
 
+// ---- arithmetic of one group of FOUR k-steps (K = 16) of a 16x16 tile --------------------------------------------------------
+// P2C_PREC_F32 (default everywhere): four v_mfma_f32_16x16x4_f32 -- bit-for-bit an fmaf chain in k order.
+// P2C_PREC_BF16: the same 4 + 4 operand floats rounded to bf16 (RNE, v_cvt_pk_bf16_f32), ONE v_mfma_f32_16x16x16_bf16 (fp32
+//   accumulate). Lane (row/col c, group g) feeds k = 4 u + g as element u of its 4-vector on BOTH operands: the instruction sums
+//   over all 16 (group, element) pairs, so any pairing that is the same for A and B is a valid K order -- the operand loads of
+//   the fp32 loop are reused as they are.
+// P2C_PREC_BF16X3: split-bf16 -- x = hi + lo with hi = bf16(x), lo = bf16(x - hi); hi*hi + hi*lo + lo*hi (three MFMAs, the
+//   lo*lo term ~2^-18 relative is dropped): ~fp32-grade products at 3/8 of the fp32 MFMA cycles.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+struct Bf16Pair {
+  s16x4 hi, lo;
+};
+template <int P>
+__device__ __forceinline__ Bf16Pair to_bf16(const float (&v)[4]) {
+  Bf16Pair r;
+  bf16x4 hi;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) hi[i] = (__bf16)v[i];
+  r.hi = __builtin_bit_cast(s16x4, hi);
+  r.lo = r.hi;
+  if constexpr (P == P2C_PREC_BF16X3) {
+    bf16x4 lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lo[i] = (__bf16)(v[i] - (float)hi[i]);
+    r.lo = __builtin_bit_cast(s16x4, lo);
+  }
+  return r;
+}
+template <int P>
+__device__ __forceinline__ f32x4 mfma_k16(const float (&a)[4], const float (&b)[4], f32x4 c) {
+  if constexpr (P == P2C_PREC_F32) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], c, 0, 0, 0);
+    return c;
+  } else {
+    const Bf16Pair A = to_bf16<P>(a), B = to_bf16<P>(b);
+    if constexpr (P == P2C_PREC_BF16X3) {     // small terms first
+      c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A.lo, B.hi, c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A.hi, B.lo, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(A.hi, B.hi, c, 0, 0, 0);
+  }
+}
+
 // 16 consecutive rows of a row-major [N][n] HBM matrix (one contiguous span) -> LDS transposed dst[k * TP + sample];
 // rows beyond N read as zero. ISSUE puts every load of the thread in flight, COMMIT (later, after other work) stores to
 // LDS: the HBM latency of the next tile hides behind the current tile's phases.
@@ -306,7 +351,7 @@ __device__ __forceinline__ void init_rows(float *area, int row0, int row1, int o
 __device__ __forceinline__ int k_rows(int n_in) { return ((((n_in + 1 + 3) >> 2) + 3) & ~3) * 4; }   // rows the k loop reads
 
 // out^T[n][s] = act( sum_k Waug[n][k] in^T_aug[k][s] ) for NT output tiles of this wave (nt0, nt0 + WAVES)
-template <int NT, int STRIDE = WAVES>
+template <int NT, int STRIDE = WAVES, int P = P2C_PREC_F32>
 __device__ __forceinline__ void layer_forward_nt(const Lane &L, const float *wl, int ld, int ksteps, int nt0, int n_out,
                                                  bool relu, const float *in, float *out, float *y_row, bool row_ok,
                                                  bool vec_y) {
@@ -330,10 +375,15 @@ __device__ __forceinline__ void layer_forward_nt(const Lane &L, const float *wl,
     }
   };
   auto fma4 = [&](const float (&bv)[4], const float (&av)[NT][4]) {
+    if constexpr (P == P2C_PREC_F32) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 4; ++u) {
 #pragma unroll
-      for (int h = 0; h < NT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][u], bv[u], acc[h], 0, 0, 0);
+        for (int h = 0; h < NT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][u], bv[u], acc[h], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < NT; ++h) acc[h] = mfma_k16<P>(av[h], bv, acc[h]);
     }
   };
   load(b0, a0, 0);
@@ -375,17 +425,19 @@ __device__ __forceinline__ void layer_forward_nt(const Lane &L, const float *wl,
 
 // in: LDS rows [k][TP] incl. ones row; out: LDS rows and/or HBM rows y. The output tiles (rows 0..n_out, ones row
 // included) are dealt round-robin to the waves.
+template <int P = P2C_PREC_F32>
 __device__ __forceinline__ void layer_forward(const Lane &L, const float *wl, int ld, int n_in, int n_out, bool relu,
                                               const float *in, float *out, float *y_row, bool row_ok, bool vec_y) {
   const int ksteps = (((n_in + 1 + 3) >> 2) + 3) & ~3;   // multiple of 4: image and activations are zero beyond n_in
   const int ntiles = (n_out + 16) >> 4;
   for (int nt = L.wave; nt < ntiles; nt += 2 * WAVES) {
-    if (nt + WAVES < ntiles) layer_forward_nt<2>(L, wl, ld, ksteps, nt, n_out, relu, in, out, y_row, row_ok, vec_y);
-    else layer_forward_nt<1>(L, wl, ld, ksteps, nt, n_out, relu, in, out, y_row, row_ok, vec_y);
+    if (nt + WAVES < ntiles) layer_forward_nt<2, WAVES, P>(L, wl, ld, ksteps, nt, n_out, relu, in, out, y_row, row_ok, vec_y);
+    else layer_forward_nt<1, WAVES, P>(L, wl, ld, ksteps, nt, n_out, relu, in, out, y_row, row_ok, vec_y);
   }
 }
 
 // gout^T[m][s] = (H^T[m][s] > 0 && m < n_in) * sum_k W[k][m] gin^T[k][s]; the m-tiles are dealt to the waves
+template <int P = P2C_PREC_F32>
 __device__ __forceinline__ void layer_dgrad(const Lane &L, const float *wl, int ld, int n_in, int n_out, const float *gin,
                                             const float *Hprev, float *gout) {
   const int ksteps = (((n_out + 3) >> 2) + 3) & ~3;      // multiple of 4: image rows and G rows are zero beyond n_out
@@ -399,10 +451,7 @@ __device__ __forceinline__ void layer_dgrad(const Lane &L, const float *wl, int 
 #pragma unroll
       for (int u = 0; u < 4; ++u) bv[u] = bp[(s + u) * 4 * TP], av[u] = a0p[(s + u) * 4 * ld];
     };
-    auto fma4 = [&](const float (&bv)[4], const float (&av)[4]) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], c0, 0, 0, 0);
-    };
+    auto fma4 = [&](const float (&bv)[4], const float (&av)[4]) { c0 = mfma_k16<P>(av, bv, c0); };
     load(b0, a0, 0);
     for (int s = 4;; s += 8) {   // same ping-pong pipeline as layer_forward_nt
       if (s < ksteps) load(b1, a1, s);

@@ -169,7 +169,7 @@ class LitPoseLiftingFlow(LitBaseFlow):
         key = (tuple(frames.shape), frames.device, frames.dtype, tuple(targets.keys()), os.environ.get('P2C_FUSED_TRAIN', '1'),
                os.environ.get('P2C_FUSED_TRAIN_MAX_B', '512'), self.lean_train_outputs, type(model), model.eval_slice.start,
                model.eval_slice.stop, getattr(model, 'rotation_output_format', None), id(transform_callable),
-               id(self.trajectory_model), bool(self.mask_missing_joints), model.fused_mlp, model.training,
+               id(self.trajectory_model), bool(self.mask_missing_joints), model.fused_mlp, model.training, model.mlp_precision,
                tuple(targets[k].shape for k in ('projection_2d_transformed', 'projection_2d', 'absolute_pose_loc') if k in targets))
         cached = getattr(self, '_fused_plan_cache', None)
         if cached is None or cached[0] != key:
@@ -185,6 +185,8 @@ class LitPoseLiftingFlow(LitBaseFlow):
         from pedestrians_video_2_carla_amd import ops
         model = self.movements_model
         if os.environ.get('P2C_FUSED_TRAIN', '1') == '0' or type(model) is not LinearAE or not self.lean_train_outputs:
+            return None
+        if getattr(model, 'mlp_precision', 'fp32') != 'fp32':        # the two-launch step is exact fp32 only
             return None
         if not (frames.is_cuda and frames.dtype == torch.float32 and frames.ndim == 4):
             return None

@@ -24,9 +24,13 @@ def _mlp(sizes, last_activation):
 
 
 class LinearAE(MovementsModelOutputTypeMixin, MovementsModel):
-    def __init__(self, fused_mlp: bool = True, **kwargs):
+    def __init__(self, fused_mlp: bool = True, mlp_precision: str = None, **kwargs):
         super().__init__(**kwargs)
         self.fused_mlp = fused_mlp
+        # operand precision of the fused MLP's matrix products: 'fp32' (exact, default), 'bf16', 'bf16x3' (ops.fused_mlp);
+        # P2C_MLP_PRECISION sets the default. The reduced arms are opt-in: every parity claim is made with fp32.
+        import os
+        self.mlp_precision = mlp_precision or os.environ.get('P2C_MLP_PRECISION', 'fp32')
         self.grad_sink = False          # set by the trainer: write parameter gradients straight into .grad
         self._image = None              # persistent packed-weight image of the fused MLP (device buffer, not a parameter)
         self._image_managed = False     # True: an optimizer keeps the image current -> no pack launch in forward()
@@ -114,7 +118,8 @@ class LinearAE(MovementsModelOutputTypeMixin, MovementsModel):
             fa = self.fused_args(flat.device)
             if fa is not None:
                 h = ops.fused_mlp(flat, fa['weights'], fa['biases'], fa['sinks'], image=fa['image'],
-                                  image_is_current=fa['image_is_current'], fused_optimizer=fa['fused_optimizer'])
+                                  image_is_current=fa['image_is_current'], fused_optimizer=fa['fused_optimizer'],
+                                  precision=self.mlp_precision)
                 return self._format_output(h.view(*lead, self.__n_out, self.output_features))
         h = self.__decoder(self.__encoder(flat))
         return self._format_output(h.view(*lead, self.__n_out, self.output_features))

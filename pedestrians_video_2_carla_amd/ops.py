@@ -538,7 +538,7 @@ class FusedMLPFunction(torch.autograd.Function):
     step (true for the flows here; do not combine with gradient accumulation)."""
 
     @staticmethod
-    def forward(ctx, x, n_layers, sinks, image, skip_pack, fused_opt, *params):
+    def forward(ctx, x, n_layers, sinks, image, skip_pack, fused_opt, precision, *params):
         lib = _lib.lib()
         x = _require_device(x, 'x')
         weights = [_require_device(p, 'weight') for p in params[:n_layers]]
@@ -551,6 +551,7 @@ class FusedMLPFunction(torch.autograd.Function):
         elif image.numel() != n_image or image.device != x.device or image.dtype != torch.float32:
             raise RuntimeError('packed weight image of the wrong size / device')
         desc.y, desc.w_image, desc.skip_pack = y.data_ptr(), image.data_ptr(), int(bool(skip_pack))
+        desc.precision = ctx.precision = int(precision)
         # many sample tiles per workgroup: the forward leaves its hidden activations for the backward (0 = recompute)
         saved = None
         if any(ctx.needs_input_grad):           # (grad mode is off inside Function.forward: ask the autograd context)
@@ -575,6 +576,7 @@ class FusedMLPFunction(torch.autograd.Function):
         gy = _require_device(gy, 'grad')
         desc = _mlp_desc(x, weights, biases)
         desc.gy, desc.w_image = gy.data_ptr(), image.data_ptr()
+        desc.precision = ctx.precision
         if ctx.saved_acts is not None:
             desc.saved = ctx.saved_acts.data_ptr()
         if ctx.sinks is not None:
@@ -595,20 +597,21 @@ class FusedMLPFunction(torch.autograd.Function):
         if ctx.fused_opt is not None:
             ctx.fused_opt.fused_steps_applied += 1       # the trainer checks that its deferred step really happened
         if ctx.sinks is not None:
-            return (None, None, None, None, None, None) + (None,) * (2 * n)
-        return (None, None, None, None, None, None, *gws, *gbs)
+            return (None,) * 7 + (None,) * (2 * n)
+        return (None,) * 7 + (*gws, *gbs)
 
 
 def fused_mlp(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tensor],
               sinks: Optional[Sequence[Tensor]] = None, image: Optional[Tensor] = None,
-              image_is_current: bool = False, fused_optimizer=None) -> Tensor:
+              image_is_current: bool = False, fused_optimizer=None, precision: str = 'fp32') -> Tensor:
     """``image``: optional persistent buffer (``mlp_image_floats`` floats) for the packed weights; with
     ``image_is_current`` the forward trusts it (kept current by ``mlp_pack`` + the optimizer's scatter) and launches no
     pack kernel. ``fused_optimizer`` (a FlatAdamW over exactly these parameters, with ``sinks`` = views of its gradient
     buffer): the backward applies the optimizer step inside its gradient reduction -- the caller must then NOT call
-    ``optimizer.step()`` for this backward."""
+    ``optimizer.step()`` for this backward. ``precision``: 'fp32' (exact fp32 MFMA, default), 'bf16' (operands rounded to bf16)
+    or 'bf16x3' (split-bf16, three MFMAs) -- the reduced arms exist for the 52-26-13-6-39-78-156 LinearAE only."""
     return FusedMLPFunction.apply(x, len(weights), None if sinks is None else list(sinks), image, image_is_current,
-                                  fused_optimizer, *weights, *biases)
+                                  fused_optimizer, _lib.PRECISION[precision], *weights, *biases)
 
 
 def mlp_image_layout(dims: Sequence[int]) -> Tuple[int, Tensor]:

@@ -41,7 +41,7 @@ for N in [int(a) for a in sys.argv[1:]] or [16, 256, 4096, 16384, 131072]:
             ops.fused_mlp(x, Ws, bs)
 
     def fb():
-        yy = ops.FusedMLPFunction.apply(x, len(Ws), sinks, None, False, None, *Ws, *bs)
+        yy = ops.FusedMLPFunction.apply(x, len(Ws), sinks, None, False, None, 0, *Ws, *bs)
         yy.backward(gy)
 
     tf = timeit(fwd)

@@ -15,7 +15,7 @@ for N in [int(a) for a in sys.argv[1:]] or [16, 4096]:
     gy = torch.randn(N, dims[-1], device=d)
     sinks = [torch.zeros_like(t) for pair in zip(Ws, bs) for t in pair]
     for _ in range(5):
-        ops.FusedMLPFunction.apply(x, len(Ws), sinks, None, False, None, *Ws, *bs).backward(gy)
+        ops.FusedMLPFunction.apply(x, len(Ws), sinks, None, False, None, 0, *Ws, *bs).backward(gy)
     torch.cuda.synchronize()
     buf = (ctypes.c_ulonglong * 80)()
     assert lib.p2c_debug_mlp_trace(buf) == 0
