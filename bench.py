@@ -483,6 +483,22 @@ def extra_config(device, name, steps=100, warmup=10):
         out['note'] = ('dtype f32 = the default, exact fp32 MFMA (bit-for-bit an fmaf chain). precision_arms: opt-in bf16 / split-bf16 '
                        'operands (LinearAE(mlp_precision=...) or P2C_MLP_PRECISION), fp32 accumulate; the pose head stays fp32')
     elif name == 'cfg5':
+        try:                                  # the same step with the transformer's GEMMs / attention under bf16 autocast
+            seed_everything(22742)
+            m16 = PoseFormer(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, clip_length=81, compute_dtype=torch.bfloat16)
+            f16 = LitPoseLiftingFlow(movements_model=m16, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
+            t16 = Trainer(device=device, use_graph=True).setup(f16, dm)
+            for i in range(3):
+                t16.train_step(f16, batch, i)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(steps):
+                l16 = t16.train_step(f16, batch, i)
+            torch.cuda.synchronize(device)
+            ms16 = (time.perf_counter() - t0) / steps * 1e3
+            out['bf16_autocast'] = {'ms_per_step': round(ms16, 3), 'clips_per_s': round(B / ms16 * 1e3, 1), 'final_loss': float(l16)}
+        except Exception as e:                                      # noqa: BLE001
+            out['bf16_autocast'] = {'error': repr(e)[:200]}
         out['note'] = ('transformer arithmetic parity-unpinned (third-party source absent); attention / GEMMs are library kernels, '
                        'the pose head is the HIP absolute_loc kernel; stochastic depth (0.2) on')
         out['windows_per_step'] = B * (81 - 9 + 1)

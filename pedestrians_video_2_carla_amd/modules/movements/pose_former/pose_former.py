@@ -28,7 +28,7 @@ class PoseFormer(MovementsModel):
     def __init__(self, clip_length: int = 30, receptive_frames: int = 9, single_joint_embeddings_size=32, depth=4,
                  num_heads=8, mlp_ratio=2, qkv_bias=True, qk_scale=None, drop_rate=0, attn_drop_rate=0,
                  drop_path_rate=0.2, input_features=2, output_features=3, inner_model: torch.nn.Module = None,
-                 **kwargs):
+                 compute_dtype: torch.dtype = torch.float32, **kwargs):
         super().__init__(**kwargs)
         self.__n_out = len(self.output_nodes)
         self.__out_features = output_features
@@ -40,7 +40,7 @@ class PoseFormer(MovementsModel):
             num_frame=receptive_frames, num_joints=len(self.input_nodes), in_chans=input_features,
             embed_dim_ratio=single_joint_embeddings_size, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio,
             qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate,
-            drop_path_rate=drop_path_rate, norm_layer=None)
+            drop_path_rate=drop_path_rate, norm_layer=None, **({'compute_dtype': compute_dtype} if compute_dtype != torch.float32 else {}))
         self._hparams.update({
             'receptive_frames': receptive_frames, 'single_joint_embeddings_size': single_joint_embeddings_size,
             'depth': depth, 'num_heads': num_heads, 'mlp_ratio': mlp_ratio, 'qkv_bias': qkv_bias, 'qk_scale': qk_scale,

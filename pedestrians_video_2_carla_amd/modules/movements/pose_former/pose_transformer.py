@@ -77,8 +77,13 @@ class _Block(nn.Module):
 
 class PoseTransformer(nn.Module):
     def __init__(self, num_frame=9, num_joints=17, in_chans=2, embed_dim_ratio=32, depth=4, num_heads=8, mlp_ratio=2.,
-                 qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=None):
+                 qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.2, norm_layer=None,
+                 compute_dtype: torch.dtype = torch.float32):
         super().__init__()
+        # fp32 by default (parameters, GEMMs, softmax). torch.bfloat16: the blocks run under autocast -- bf16 MFMA GEMMs and
+        # attention with fp32 accumulation, fp32 parameters and LayerNorm statistics (opt-in: the arithmetic is parity-unpinned
+        # either way, but every number quoted for the head behind it is an fp32 number)
+        self.compute_dtype = compute_dtype
         norm_layer = norm_layer or (lambda d: nn.LayerNorm(d, eps=1e-6))
         embed_dim = embed_dim_ratio * num_joints
         self.num_frame, self.num_joints = num_frame, num_joints
@@ -95,6 +100,12 @@ class PoseTransformer(nn.Module):
         self.head = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, num_joints * 3))
 
     def forward(self, x):
+        if self.compute_dtype != torch.float32 and x.is_cuda:
+            with torch.autocast('cuda', dtype=self.compute_dtype):
+                return self._forward(x).float()
+        return self._forward(x)
+
+    def _forward(self, x):
         B, Fr, J, C = x.shape
         t = self.Spatial_patch_to_embedding(x.reshape(B * Fr, J, C)) + self.Spatial_pos_embed
         t = self.pos_drop(t)
