@@ -445,8 +445,14 @@ def extra_config(device, name, steps=100, warmup=10):
     out = {'workload': workload, 'B': B, 'ms_per_step': round(dt * 1e3, 4), 'clips_per_s': round(B / dt, 1), 'dtype': 'f32',
            'hip_graph': True, 'steps': steps, 'final_loss': float(loss)}
     if name == 'cfg2':
-        mt, flops = mlp_times(device, model, B, getattr(trainer, '_opt_in_backward', False))
-        out['roofline'] = [mfma_entry(k, B, mt[k], fl) for k, fl in flops.items()]
+        fused = fused_step_times(device, flow, trainer, batch)
+        if fused is not None:                 # B = 1024 takes the two-launch step too (persistent over 4 clips per CU)
+            ft, fflops = fused
+            out['step_breakdown_us'] = {k: round(v, 2) for k, v in ft.items()}
+            out['roofline'] = [mfma_entry(k, B, ft[k], fl) for k, fl in fflops.items()]
+        else:
+            mt, flops = mlp_times(device, model, B, getattr(trainer, '_opt_in_backward', False))
+            out['roofline'] = [mfma_entry(k, B, mt[k], fl) for k, fl in flops.items()]
         # configs[1] names bf16: the opt-in operand-precision arms of the fused MLP (accumulation stays fp32), each with its step
         # time and the deviation of one real training step (same init, same batch) from the exact-fp32 step: loss, and the
         # flat parameter gradient relative to its largest entry. fp32 remains the default and the headline.

@@ -164,20 +164,21 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   float *Y = G + S::h_off(nl) * TP;                        // y^T, later grad_y^T (= G_L)
   float *plane0 = H + ACT_FLOATS, *plane1 = G + S::h_off(1) * TP;
   float *scratch = plane0 + PLANE;
-  const int clip = blockIdx.x, T = d.T;
+  const int T = d.T;
   TT(0, 0);
 
-  // ---- loads: x tile, first image rounds, then what the pose head will need (all in flight during the MLP forward) ----
+  // ---- clip-independent set-up --------------------------------------------------------------------------------------------------
+  // Persistent over clips: workgroup b walks clips b, b + gridDim.x, ... (grid = min(B, CUs)); the 84 KB weight image is staged
+  // ONCE, during the first clip's forward. The first clip's x tile is requested first, then the image rounds.
   TileRegs xr;
   ImageRegs wr;
-  const int64_t row0 = (int64_t)clip * T;
-  tile_issue(m.x, row0, row0 + T, S::dims(0), true, xr);
+  tile_issue(m.x, (int64_t)blockIdx.x * T, (int64_t)blockIdx.x * T + T, S::dims(0), true, xr);
   stage_issue(m.w_image, total4, wr, 0, 0, issue_mark<S>(1));
   // lane context of the pose head (= p2c::make_lane_tp) -- with identity joint maps (CARLA targets for a CARLA model, the
-  // usual case) nothing in this prologue depends on a loaded value: every load below is issued back to back. (The general
-  // maps are kernel arguments indexed by lane, i.e. vector loads whose result the target addresses wait for.)
+  // usual case) nothing in the prologue depends on a loaded value: every load is issued back to back. (The general maps
+  // are kernel arguments indexed by lane, i.e. vector loads whose result the target addresses wait for.)
   ph::LaneCtx PL;
-  PL.lane = threadIdx.x & 63, PL.j = PL.lane & 31, PL.base = PL.lane & 32, PL.clip = clip;
+  PL.lane = threadIdx.x & 63, PL.j = PL.lane & 31, PL.base = PL.lane & 32, PL.clip = blockIdx.x;
   const int t = (int)(threadIdx.x >> 6) * 2 + (PL.lane >> 5);
   PL.active = (PL.j < ph::J) && (t < T);
   if (m.identity_maps) {
@@ -191,9 +192,21 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   } else {
     ph::fill_lane(PL, d);
   }
+  const int jc = PL.j < ph::J ? PL.j : 0, tc = t < T ? t : T - 1;
+  // pair counts: issued now, consumed after the first clip's MLP forward (no add here: an add would wait for every load above)
+  const float c0raw = m.counts[(int)threadIdx.x < d.B ? threadIdx.x : 0];
+  const float c1raw = m.counts[(int)threadIdx.x + NTH < d.B ? threadIdx.x + NTH : 0];
+  if (blockIdx.x == 0 && (int)threadIdx.x < m.n_counters) m.counters[threadIdx.x] = 0;   // arrival tickets of train_wgrad_kernel
+  init_rows(H, S::h_off(0) + S::dims(0), S::h_off(0) + k_rows(S::dims(0)), S::h_off(0) + S::dims(0));
+  float coef2 = 0.f, coef3 = 0.f;             // loss coefficients: the same for every clip, worked out in the first one
+  float *red = scratch + 16;
+
+  auto one_clip = [&](const int clip, auto first_c) {
+  constexpr bool first = decltype(first_c)::value;
+  PL.clip = clip;
+  if constexpr (!first) lds_barrier();        // the previous clip's factor store / loss sums have consumed H, G and scratch
   // Every lane loads UNCONDITIONALLY from a clamped (always valid) address and selects afterwards: a load inside a divergent
   // branch makes the compiler wait for it (and for every older load) at the branch's end.
-  const int jc = PL.j < ph::J ? PL.j : 0, tc = t < T ? t : T - 1;
   const int st = d.skel_type[clip];
   float lraw[3], rraw[9];
   {
@@ -212,20 +225,18 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
     g2raw[0] = p2[0], g2raw[1] = p2[1];
     g3raw[0] = p3[0], g3raw[1] = p3[1], g3raw[2] = p3[2];
   }
-  // pair counts: issued now, consumed after the MLP forward (no add here: an add would wait for every load above)
-  const float c0raw = m.counts[(int)threadIdx.x < d.B ? threadIdx.x : 0];
-  const float c1raw = m.counts[(int)threadIdx.x + NTH < d.B ? threadIdx.x + NTH : 0];
-  if (clip == 0 && (int)threadIdx.x < m.n_counters) m.counters[threadIdx.x] = 0;   // arrival tickets of train_wgrad_kernel
-  init_rows(H, S::h_off(0) + S::dims(0), S::h_off(0) + k_rows(S::dims(0)), S::h_off(0) + S::dims(0));
-
   // ---- LinearAE forward of the clip's frames (mlp_fwd_kernel's first-tile schedule); the last layer writes y^T to LDS ----
   TT(0, 1);
   tile_commit(S::dims(0), true, xr, H + S::h_off(0) * TP);
+  {   // the next clip of this workgroup: its x tile waits in registers (rows beyond the batch read as zero, nothing is loaded)
+    const int64_t nxt = (int64_t)clip + gridDim.x;
+    tile_issue(m.x, nxt * T, nxt < d.B ? nxt * T + T : 0, S::dims(0), true, xr);
+  }
   for_layers(sh, 0, nl, [&](int ll) {
-    stage_commit(total4, wr, lds, 0, ll == 0 ? 0 : rounds_upto<S>(ll - 1), rounds_upto<S>(ll));
+    if constexpr (first) stage_commit(total4, wr, lds, 0, ll == 0 ? 0 : rounds_upto<S>(ll - 1), rounds_upto<S>(ll));
     lds_barrier();
     TT(0, 2 + ll);
-    stage_issue(m.w_image, total4, wr, 0, issue_mark<S>(ll + 1), issue_mark<S>(ll + 2));
+    if constexpr (first) stage_issue(m.w_image, total4, wr, 0, issue_mark<S>(ll + 1), issue_mark<S>(ll + 2));
     const bool last = (ll == nl - 1);
     layer_forward(L, lds + S::w_off(ll), S::ld(ll), S::dims(ll), S::dims(ll + 1), !last, H + S::h_off(ll) * TP,
                   last ? Y : H + S::h_off(ll + 1) * TP, nullptr, false, false);
@@ -239,7 +250,6 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
 #pragma unroll
     for (int i = 0; i < 6; ++i) y6[i] = Y[(PL.j * 6 + i) * TP + t];
   }
-  float coef2 = 0.f, coef3 = 0.f;
   const ph::V3 l = (PL.j < ph::J) ? ph::v3(lraw[0], lraw[1], lraw[2]) : ph::v3(0.f, 0.f, 0.f);
   ph::M3 Rref = ph::identity();
   if (K::SCAN && PL.j < ph::J) {
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   }
   const float g2[2] = {PL.has2 ? g2raw[0] : 0.f, PL.has2 ? g2raw[1] : 0.f};
   const float g3[3] = {PL.has3 ? g3raw[0] : 0.f, PL.has3 ? g3raw[1] : 0.f, PL.has3 ? g3raw[2] : 0.f};
-  {
+  if constexpr (first) {
     const float c0 = (int)threadIdx.x < d.B ? c0raw : 0.f, c1 = (int)threadIdx.x + NTH < d.B ? c1raw : 0.f;
     float cnt = c0 + c1;                      // small integers held in floats: exact in any order
     for (int i = threadIdx.x + 2 * NTH; i < d.B; i += NTH) cnt += m.counts[i];
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   if (K::SCAN) R = ph::mul(scan_time2(c, t, PL.j, T, plane0, plane1), Rref);     // (its barriers also publish scratch[])
   else lds_barrier();
   TT(0, 9);
-  {
+  if constexpr (first) {
     float n2 = 0.f;
     for (int w = 0; w < WAVES; ++w) n2 += scratch[w];
     ph::loss_coefs_n(d, gl, n2, ph::n3_elems(d), coef2, coef3);
@@ -274,7 +284,6 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   ph::HeadAcc acc{0.f, 0.f, 0.f};
   ph::V3 F = ph::frame_head<ph::MODE_TRAIN>(d, PL, t, x, W, acc, coef2, coef3, nullptr, nullptr, g2, g3);
   TT(0, 10);
-  float *red = scratch + 16;
   {   // this clip's loss sums: per wave now, added in frame order at the very end (the barriers below publish red[])
     const float s2 = ph::wave_sum(acc.sum2), c2 = ph::wave_sum(acc.cnt2), s3 = ph::wave_sum(acc.sum3);
     if (L.lane == 0) red[L.wave * 3 + 0] = s2, red[L.wave * 3 + 1] = c2, red[L.wave * 3 + 2] = s3;
@@ -357,6 +366,10 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
     pp[0] = a, pp[1] = b, pp[2] = cc, pp[3] = 0.f;
   }
   TT(0, 39);
+  };   // one_clip
+
+  if ((int)blockIdx.x < d.B) one_clip((int)blockIdx.x, std::true_type{});
+  for (int clip = (int)blockIdx.x + (int)gridDim.x; clip < d.B; clip += (int)gridDim.x) one_clip(clip, std::false_type{});
 }
 
 // ---- second launch: weight gradient over all clips + optimizer + loss reduction ------------------------------------------
@@ -594,6 +607,7 @@ extern "C" int p2c_train_step_supported(const p2c_train_step_desc *d) {
   return 1;
 }
 
+static constexpr int kClipBlocks = 256;   // CUs of an MI355X: one 156 KB-LDS workgroup each
 static constexpr int kTilesW = 79;    // 16x16 tiles of the augmented weight gradients of LinearAE156 (checked below)
 // workspace: [factors (B, F_ROWS, 16) | slices (KS, tiles, 256) | counters (tiles, padded to 128 ints)]
 extern "C" int64_t p2c_train_step_workspace_floats(const p2c_train_step_desc *d) {
@@ -678,11 +692,12 @@ extern "C" int p2c_train_step_launch(const p2c_train_step_desc *desc, const floa
   ClipArgs ca{m.x, m.w_image, desc->pair_counts, m.partials, counters, tiles, identity};
   const size_t lds_a = (size_t)LDS_FLOATS * sizeof(float);
   hipError_t e = hipSuccess;
+  const dim3 grid_a((unsigned)(d.B < kClipBlocks ? d.B : kClipBlocks));   // persistent: one workgroup per CU walks its clips
   if (which & 1) {
     if (d.kind == P2C_KIND_POSE_CHANGES_6D)
-      hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_POSE_CHANGES_6D>, dim3((unsigned)d.B), dim3(64 * WAVES), lds_a, stream, d, gl, ca);
+      hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_POSE_CHANGES_6D>, grid_a, dim3(64 * WAVES), lds_a, stream, d, gl, ca);
     else
-      hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_RELATIVE_ROT_6D>, dim3((unsigned)d.B), dim3(64 * WAVES), lds_a, stream, d, gl, ca);
+      hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_RELATIVE_ROT_6D>, grid_a, dim3(64 * WAVES), lds_a, stream, d, gl, ca);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }

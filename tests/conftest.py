@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # The oracle side of the GPU tests runs on the host: a GPU box shows all its 256 cores but gives a one-GPU job a share of
+    # 16; ATen's default of one intra-op thread per visible core makes ~10 KB tensor ops crawl there (bench.py: 131 s per step
+    # with 256 threads against 0.45 s with 8).
+    import torch
+    torch.set_num_threads(min(os.cpu_count() or 1, 8))
 
 
 @pytest.fixture(scope='session')

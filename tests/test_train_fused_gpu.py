@@ -52,10 +52,12 @@ def test_fused_step_is_bit_identical_to_the_separate_kernels(monkeypatch, otype)
 
 
 @pytest.mark.parametrize('B,T,missing,transform', [(5, 16, 0.1, 'hips_neck_bbox'), (33, 7, 0.2, 'hips_neck'),
-                                                   (64, 16, 0.0, 'bbox'), (1, 1, 0.0, 'none')])
+                                                   (64, 16, 0.0, 'bbox'), (1, 1, 0.0, 'none'),
+                                                   (300, 16, 0.1, 'hips_neck_bbox'), (777, 5, 0.1, 'hips_neck')])
 def test_fused_step_matches_cpu_pipeline(monkeypatch, B, T, missing, transform):
     """loss + every parameter gradient of one fused train step == LinearAE on CPU (fp64) + oracle pose head; ragged batch,
-    clips shorter than the 16-sample tile, every built-in transform, missing joints."""
+    clips shorter than the 16-sample tile, every built-in transform, missing joints; B > 256: the per-clip kernel is
+    persistent (a workgroup walks 2 - 4 clips, weight image staged once)."""
     from pedestrians_video_2_carla_amd.data.base.base_transforms import BaseTransforms
     monkeypatch.setenv('P2C_FUSED_UPDATE', '0')                  # keep the gradients: the optimizer is a separate launch
     flow, dm = make(B=B, T=T, missing=missing, transform=BaseTransforms[transform])
