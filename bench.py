@@ -258,6 +258,48 @@ def fused_step_times(device, flow, trainer, batch):
     return out, flops
 
 
+def recurrence_times(device, B, T=T_FRAMES, H=64, O=52):
+    """Device time of the Seq2SeqEmbeddings recurrences at cfg3's shapes through the C ABI (graph-timed): one LSTM layer's time
+    loop forward / backward (K7b) and the T-step decoder loop forward / backward (K7c), each with its algorithmic flops
+    (the h W_hh^T products of the cells; K7c adds its input projections and fc_out)."""
+    import ctypes
+    from pedestrians_video_2_carla_amd import _lib
+    lib = _lib.lib()
+    f32 = dict(dtype=torch.float32, device=device)
+    g = torch.Generator(device=device).manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, generator=g, **f32) * 0.2       # noqa: E731
+    keep = []
+    d = _lib.LstmDesc()
+    d.T, d.B, d.H = T, B, H
+    ten = {k: rnd(*s) for k, s in dict(gx=(T, B, 4 * H), w_hh=(4 * H, H), out=(T, B, H), hT=(B, H), cT=(B, H), acts=(T, B, 4 * H),
+                                       cs=(T, B, H), g_out=(T, B, H), g_gx=(T, B, 4 * H)).items()}
+    for k, v in ten.items():
+        setattr(d, k, v.data_ptr())
+    keep.append(ten)
+    dd = _lib.DecoderDesc()
+    dd.T, dd.B, dd.H, dd.O = T, B, H, O
+    ten2 = {k: rnd(*s) for k, s in dict(k0=(B, 4 * H), c0=(B, H), k1=(B, 4 * H), c1=(B, H), w_ih0=(4 * H, O), w_ih1=(4 * H, H),
+                                        w_fc=(O, H), b_fc=(O,), out=(T, B, O), acts0=(T, B, 4 * H), acts1=(T, B, 4 * H),
+                                        h0d=(T, B, H), h1=(T, B, H), g_out=(T, B, O), g_gates0=(T, B, 4 * H),
+                                        g_gates1=(T, B, 4 * H), g_outtot=(T, B, O), g_c0=(B, H), g_c1=(B, H)).items()}
+    for k, v in ten2.items():
+        setattr(dd, k, v.data_ptr())
+    keep.append(ten2)
+    out = {}
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        s = stream.cuda_stream
+        out['lstm_rec_fwd (K7b, one layer)'] = _graph_us(lambda: _lib.check(lib.p2c_lstm_rec_fwd(ctypes.byref(d), s), 'rec fwd'), stream)
+        out['lstm_rec_bwd (K7b, one layer)'] = _graph_us(lambda: _lib.check(lib.p2c_lstm_rec_bwd(ctypes.byref(d), s), 'rec bwd'), stream)
+        out['decoder_loop_fwd (K7c)'] = _graph_us(lambda: _lib.check(lib.p2c_decoder_fwd(ctypes.byref(dd), s), 'dec fwd'), stream)
+        out['decoder_loop_bwd (K7c)'] = _graph_us(lambda: _lib.check(lib.p2c_decoder_bwd(ctypes.byref(dd), s), 'dec bwd'), stream)
+    rec = 2 * T * B * H * 4 * H                                        # h_{t-1} W_hh^T for all t
+    dec = 2 * T * B * (O * 4 * H + H * 4 * H + H * O)                  # W_ih0 x_t, W_ih1 h0_t, fc_out h1_t
+    flops = {'lstm_rec_fwd (K7b, one layer)': rec, 'lstm_rec_bwd (K7b, one layer)': rec,
+             'decoder_loop_fwd (K7c)': dec, 'decoder_loop_bwd (K7c)': dec}
+    return out, flops
+
+
 def mfma_entry(name, B, us, flops):
     achieved = flops / (us * 1e-6) / 1e12
     return {'kernel': name, 'B': B, 'us_per_launch': round(us, 2), 'bound': 'mfma', 'achieved': round(achieved, 3),
@@ -511,8 +553,10 @@ def extra_config(device, name, steps=100, warmup=10):
     else:
         # the recurrences (K7b encoder layers, K7c decoder loop) priced against the fp32 MFMA peak: 2*T*B*H*4H flop per
         # LSTM layer and direction of the data flow (forward; the backward kernels do the same again with W^T)
-        H, T = 64, T_FRAMES
-        out['recurrence_flops_per_layer'] = 2 * T * B * H * 4 * H
+        rt, rflops = recurrence_times(device, B)
+        out['roofline'] = [mfma_entry(k, B, rt[k], fl) for k, fl in rflops.items()]
+        out['note'] = ('the four recurrence launches are latency chains (one workgroup barrier per time step, 16 sequences per '
+                       'workgroup = 32 workgroups on 256 CUs): their MFMA fraction says so; the rest of the step is glue launches')
     return out
 
 
@@ -526,6 +570,10 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the HIP hot path has no CPU fallback')
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
+    # host side: a GPU box shows every core of the machine but gives a one-GPU job a share of 16. ATen's default of one intra-op
+    # thread per visible core leaves hundreds of OpenMP workers spinning after each small CPU op (the synthetic batches are drawn
+    # with a host generator) and can starve the launching thread of a host-bound loop (seen: fresh-batch step 0.07 -> 0.43 ms)
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16) // max(world, 1)))
 
     flow, dm, trainer, batch = build_step(device, args.batch_size, not args.no_graph, not args.full_outputs)
     for i in range(max(args.warmup, 1)):
