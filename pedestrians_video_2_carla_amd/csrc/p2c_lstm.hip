@@ -18,10 +18,11 @@
 #include <stdint.h>
 
 #include "../../include/p2c.h"
+#include "p2c_rec_dev.h"
 
 namespace p2c_lstm {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace p2c_rec;
 constexpr int TS = 16;    // sequences per workgroup
 constexpr int TP = 17;    // LDS pitch of a transposed row [unit][sequence]
 
@@ -39,10 +40,6 @@ struct Args {
   float *g_h0, *g_c0;   // (B, H) or NULL         }
   int32_t T, B, H;
 };
-
-// v_exp_f32 + v_rcp_f32 (1 ulp each): the IEEE division sequence would triple the cost of the cell update
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 
 __device__ __forceinline__ f32x4 load4(const float *p, bool ok) {
   return ok ? *reinterpret_cast<const f32x4 *>(p) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -75,6 +72,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
   const bool ok = b < a.B;
   const int u0 = w * 16 + 4 * g;                  // first of this lane's four hidden units
   const int B = a.B, T = a.T;
+  const int off4 = (b * 4 * H + u0) * 4, off1 = (b * H + u0) * 4;   // byte offsets inside one step's rows
 
   stage_w<H>(a.w_hh, dyn_lds);
   float frag[4][KS];                              // A fragments: gate q, rows 16w + (lane & 15), k = 4 ks + g
@@ -89,49 +87,63 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
 #pragma unroll
     for (int r = 0; r < 4; ++r) hbuf[0][(u0 + r) * TP + c] = h[r];
   }
+  f32x4 nxt[4];
+  {
+    const __amdgpu_buffer_rsrc_t rg = step_rows(a.gx, 0, B, 4 * H);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = bload4(rg, off4 + q * H * 4);
+  }
   __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) pin(nxt[q]);        // resident on entry: the loop header then carries no pending loads
   int cur = 0;
   f32x4 hlast = {0.f, 0.f, 0.f, 0.f};
-  f32x4 nxt[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) nxt[q] = load4(a.gx + ((size_t)0 * B + b) * 4 * H + q * H + u0, ok);
   for (int t = 0; t < T; ++t) {
     f32x4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = nxt[q];
-    if (t + 1 < T) {                              // the next step's input projection is in flight during this step
+    {   // the next step's input projection is in flight during this step (the last step re-reads its own rows: no branch)
+      const __amdgpu_buffer_rsrc_t rg = step_rows(a.gx, (t + 1 < T) ? t + 1 : t, B, 4 * H);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) nxt[q] = load4(a.gx + ((size_t)(t + 1) * B + b) * 4 * H + q * H + u0, ok);
+      for (int q = 0; q < 4; ++q) nxt[q] = bload4(rg, off4 + q * H * 4);
     }
     const float *hb = hbuf[cur] + g * TP + c;
+    float bv[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) bv[ks] = hb[ks * 4 * TP];
+    // gates i and g first: their activations run on the VALU while the matrix pipe works through f and o
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const float bv = hb[ks * 4 * TP];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[q][ks], bv, acc[q], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[0][ks], bv[ks], acc[0], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[2][ks], bv[ks], acc[2], 0, 0, 0);
     }
-    f32x4 ai, af, ag, ao, h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[1][ks], bv[ks], acc[1], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[3][ks], bv[ks], acc[3], 0, 0, 0);
+    }
+    f32x4 ai, af, ag, ao, h, ig;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ai[r] = sigmoidf_(acc[0][r]), ag[r] = tanhf_(acc[2][r]), ig[r] = ai[r] * ag[r];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      ai[r] = sigmoidf_(acc[0][r]), af[r] = sigmoidf_(acc[1][r]), ag[r] = tanhf_(acc[2][r]), ao[r] = sigmoidf_(acc[3][r]);
-      cst[r] = af[r] * cst[r] + ai[r] * ag[r];
+      af[r] = sigmoidf_(acc[1][r]), ao[r] = sigmoidf_(acc[3][r]);
+      cst[r] = af[r] * cst[r] + ig[r];
       h[r] = ao[r] * tanhf_(cst[r]);
     }
     hlast = h;
-    if (ok) {
-      const size_t row = (size_t)t * B + b;
-      if (a.acts) {
-        float *p = a.acts + row * 4 * H + u0;
-        *reinterpret_cast<f32x4 *>(p) = ai, *reinterpret_cast<f32x4 *>(p + H) = af;
-        *reinterpret_cast<f32x4 *>(p + 2 * H) = ag, *reinterpret_cast<f32x4 *>(p + 3 * H) = ao;
-      }
-      if (a.cs) *reinterpret_cast<f32x4 *>(a.cs + row * H + u0) = cst;
-      *reinterpret_cast<f32x4 *>(a.out + row * H + u0) = h;
-    }
     float *hn = hbuf[cur ^ 1];
 #pragma unroll
     for (int r = 0; r < 4; ++r) hn[(u0 + r) * TP + c] = h[r];
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pin(nxt[q]);
+    {
+      const __amdgpu_buffer_rsrc_t ra = step_rows(a.acts, t, B, 4 * H), rc = step_rows(a.cs, t, B, H), ro = step_rows(a.out, t, B, H);
+      bstore4(ra, off4, ai), bstore4(ra, off4 + H * 4, af), bstore4(ra, off4 + 2 * H * 4, ag), bstore4(ra, off4 + 3 * H * 4, ao);
+      bstore4(rc, off1, cst);
+      bstore4(ro, off1, h);
+    }
+    lds_barrier();
     cur ^= 1;
   }
   if (ok) {
@@ -152,6 +164,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
   const bool ok = b < a.B;
   const int u0 = w * 16 + 4 * g;
   const int B = a.B, T = a.T;
+  const int off4 = (b * 4 * H + u0) * 4, off1 = (b * H + u0) * 4;
 
   stage_w<H>(a.w_hh, dyn_lds);
   float frag[KS];                                 // A fragments of W_hh^T: rows = units 16w + (lane & 15), k = gate row 4 ks + g
@@ -161,15 +174,27 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
 
   f32x4 dh = a.g_hT ? load4(a.g_hT + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 dc = a.g_cT ? load4(a.g_cT + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  // The saved rows of step t - 1 are requested at the top of step t and pinned at its end: their latency hides behind the
+  // whole step (cell math + 64 MFMAs).
+  struct Saved { f32x4 ai, af, ag, ao, cp, go; };
+  auto fetch = [&](int t, Saved &s) {             // t >= 0
+    const __amdgpu_buffer_rsrc_t ra = step_rows(a.acts, t, B, 4 * H), rg = step_rows(a.g_out, t, B, H);
+    const __amdgpu_buffer_rsrc_t rc = (t > 0) ? step_rows(a.cs, t - 1, B, H) : step_rows(a.c0, 0, B, H);
+    s.ai = bload4(ra, off4), s.af = bload4(ra, off4 + H * 4), s.ag = bload4(ra, off4 + 2 * H * 4), s.ao = bload4(ra, off4 + 3 * H * 4);
+    s.cp = bload4(rc, off1);
+    s.go = bload4(rg, off1);
+  };
+  Saved nx = {};
+  f32x4 ct = {0.f, 0.f, 0.f, 0.f};
+  if (T > 0) {
+    fetch(T - 1, nx);
+    ct = bload4(step_rows(a.cs, T - 1, B, H), off1);
+  }
+  pin(nx.ai), pin(nx.af), pin(nx.ag), pin(nx.ao), pin(nx.cp), pin(nx.go), pin(ct);
   int cur = 0;
   for (int t = T - 1; t >= 0; --t) {
-    const size_t row = (size_t)t * B + b;
-    const float *pa = a.acts + row * 4 * H + u0;
-    const f32x4 ai = load4(pa, ok), af = load4(pa + H, ok), ag = load4(pa + 2 * H, ok), ao = load4(pa + 3 * H, ok);
-    const f32x4 ct = load4(a.cs + row * H + u0, ok);
-    const f32x4 cp = (t > 0) ? load4(a.cs + (row - B) * H + u0, ok)
-                             : (a.c0 ? load4(a.c0 + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f});
-    const f32x4 go = a.g_out ? load4(a.g_out + row * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 ai = nx.ai, af = nx.af, ag = nx.ag, ao = nx.ao, cp = nx.cp, go = nx.go;
+    fetch(t > 0 ? t - 1 : 0, nx);                  // (the last step re-reads its own rows: no branch in the body)
     f32x4 pi, pf, pg, po;                          // gradients of the pre-activation gates
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -182,18 +207,18 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
       pg[r] = dct * ai[r] * (1.f - ag[r] * ag[r]);
       dc[r] = dct * af[r];
     }
-    if (ok) {
-      float *p = a.g_gx + row * 4 * H + u0;
-      *reinterpret_cast<f32x4 *>(p) = pi, *reinterpret_cast<f32x4 *>(p + H) = pf;
-      *reinterpret_cast<f32x4 *>(p + 2 * H) = pg, *reinterpret_cast<f32x4 *>(p + 3 * H) = po;
-    }
+    ct = cp;                                       // c[t-1] is the next step's cell state
     float *d = cur ? dg1 : dg0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       d[(u0 + r) * TP + c] = pi[r], d[(H + u0 + r) * TP + c] = pf[r];
       d[(2 * H + u0 + r) * TP + c] = pg[r], d[(3 * H + u0 + r) * TP + c] = po[r];
     }
-    __syncthreads();
+    {
+      const __amdgpu_buffer_rsrc_t rx = step_rows(a.g_gx, t, B, 4 * H);
+      bstore4(rx, off4, pi), bstore4(rx, off4 + H * 4, pf), bstore4(rx, off4 + 2 * H * 4, pg), bstore4(rx, off4 + 3 * H * 4, po);
+    }
+    lds_barrier();
     // dh[t-1] = W_hh^T d gates: two accumulators (even / odd k-steps) halve the dependent MFMA chain
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
     const float *db = d + g * TP + c;
@@ -203,11 +228,181 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
       e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(frag[ks + 1], db[(ks + 1) * 4 * TP], e1, 0, 0, 0);
     }
     dh = e0 + e1;
+    pin(nx.ai), pin(nx.af), pin(nx.ag), pin(nx.ao), pin(nx.cp), pin(nx.go);
     cur ^= 1;                                      // the other buffer was last read two steps ago: one barrier per step
   }
   if (ok) {
     if (a.g_h0) *reinterpret_cast<f32x4 *>(a.g_h0 + (size_t)b * H + u0) = dh;
     if (a.g_c0) *reinterpret_cast<f32x4 *>(a.g_c0 + (size_t)b * H + u0) = dc;
+  }
+}
+
+// ---- narrow variants: 4 sequences per workgroup ------------------------------------------------------------------------
+// At the batch sizes the flows train with (B = 512: 32 workgroups of 16 sequences) the 16 x 16 tile leaves 7/8 of the CUs
+// idle while each busy SIMD queues 64 MFMAs of 32 cycles per time step. v_mfma_f32_4x4x1_16B_f32 runs 16 independent
+// 4 x 4 x 1 outer products per instruction at the same FLOP rate (8 cycles): with the 16 blocks = 16 hidden units, the
+// 4 rows of a block = the unit's four gates and the 4 columns = 4 SEQUENCES (the B operand, shared by all blocks), a
+// workgroup needs only 4 sequences -- 4x the workgroups, a quarter of the MFMA cycles and of the cell math per step each.
+// Lane (block k, column s) receives the four gate pre-activations of (unit 16w + k, sequence s): the cell update is one
+// element per lane, again without any exchange. Used for B <= 4096 (above that the wide kernels fill the chip and stage
+// W_hh four times less often).
+constexpr int NS = 4;
+
+__device__ __forceinline__ f32x4 mfma4(float a_, float b_, f32x4 c_) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a_, b_, c_, 0, 0, 0); }
+
+template <int H>
+__global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_narrow_kernel(const Args a) {
+  constexpr int HP = H + 4;                       // LDS pitch of one sequence's h row (16-byte aligned)
+  extern __shared__ float dyn_lds[];              // [4H][H+1] staging image of W_hh, then unused
+  __shared__ __attribute__((aligned(16))) float hs[2][NS][HP];   // h[t-1], double buffered
+  const int lane = threadIdx.x & 63, s = lane & 3;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = w * 16 + (lane >> 2);             // this lane's hidden unit (its MFMA block)
+  const int b = blockIdx.x * NS + s;              // this lane's sequence (its MFMA column)
+  const bool ok = b < a.B;
+  const int B = a.B, T = a.T;
+  const int offg = (b * 4 * H + u) * 4, offh = (b * H + u) * 4;   // byte offsets inside one step's rows
+
+  stage_w<H>(a.w_hh, dyn_lds);
+  float frag[H];                                  // A operand: row (lane & 3) = gate, of this lane's block = unit; k = 0..H-1
+#pragma unroll
+  for (int k = 0; k < H; ++k) frag[k] = dyn_lds[(s * H + u) * (H + 1) + k];
+
+  float cst = (a.c0 && ok) ? a.c0[(size_t)b * H + u] : 0.f;
+  hs[0][s][u] = (a.h0 && ok) ? a.h0[(size_t)b * H + u] : 0.f;
+  f32x4 nxt;
+  {
+    const __amdgpu_buffer_rsrc_t rg = step_rows(a.gx, 0, B, 4 * H);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = bload1(rg, offg + q * H * 4);
+  }
+  __syncthreads();
+  pin(nxt);
+  int cur = 0;
+  float hlast = 0.f;
+  for (int t = 0; t < T; ++t) {
+    f32x4 acc0 = nxt, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1, acc3 = acc1;
+    {
+      const __amdgpu_buffer_rsrc_t rg = step_rows(a.gx, (t + 1 < T) ? t + 1 : t, B, 4 * H);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nxt[q] = bload1(rg, offg + q * H * 4);
+    }
+    const f32x4 *hp = reinterpret_cast<const f32x4 *>(hs[cur][s]);
+#pragma unroll
+    for (int k4 = 0; k4 < H / 4; ++k4) {
+      const f32x4 hv = hp[k4];
+      acc0 = mfma4(frag[4 * k4], hv[0], acc0), acc1 = mfma4(frag[4 * k4 + 1], hv[1], acc1);
+      acc2 = mfma4(frag[4 * k4 + 2], hv[2], acc2), acc3 = mfma4(frag[4 * k4 + 3], hv[3], acc3);
+    }
+    const f32x4 acc = (acc0 + acc1) + (acc2 + acc3);
+    const float ai = sigmoidf_(acc[0]), af = sigmoidf_(acc[1]), ag = tanhf_(acc[2]), ao = sigmoidf_(acc[3]);
+    cst = af * cst + ai * ag;
+    const float h = ao * tanhf_(cst);
+    hlast = h;
+    hs[cur ^ 1][s][u] = h;
+    pin(nxt);
+    {
+      const __amdgpu_buffer_rsrc_t ra = step_rows(a.acts, t, B, 4 * H), rc = step_rows(a.cs, t, B, H), ro = step_rows(a.out, t, B, H);
+      bstore1(ra, offg, ai), bstore1(ra, offg + H * 4, af), bstore1(ra, offg + 2 * H * 4, ag), bstore1(ra, offg + 3 * H * 4, ao);
+      bstore1(rc, offh, cst);
+      bstore1(ro, offh, h);
+    }
+    lds_barrier();
+    cur ^= 1;
+  }
+  if (ok) {
+    if (a.hT) a.hT[(size_t)b * H + u] = (T > 0) ? hlast : (a.h0 ? a.h0[(size_t)b * H + u] : 0.f);
+    if (a.cT) a.cT[(size_t)b * H + u] = cst;
+  }
+}
+
+// Backward, narrow: dh[t-1] = W_hh^T d gates has the hidden units as output rows and the 4H gate rows as K. A wave owns
+// units [16w, 16w+16) as 4 groups of 4; its 16 MFMA blocks are (unit group ug) x (K quarter q = gate q's H rows): H
+// instructions per step, then the four quarters are summed across lanes (two row-rotate DPP adds). For the cell math lane
+// (ug, q, s) takes the element (unit 16w + 4ug + q, sequence s), i.e. register q of the reduced tile.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(float, r);
+}
+
+template <int H>
+__global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(const Args a) {
+  constexpr int GP = 4 * H + 4;                   // LDS pitch of one sequence's d-gates row
+  extern __shared__ float dyn_lds[];              // [4H][H+1] staging image of W_hh
+  __shared__ __attribute__((aligned(16))) float dgs[2][NS][GP];
+  const int lane = threadIdx.x & 63, s = lane & 3, blk = lane >> 2, ug = blk >> 2, q = blk & 3;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = w * 16 + 4 * ug + q;              // this lane's element for the cell math
+  const int b = blockIdx.x * NS + s;
+  const bool ok = b < a.B;
+  const int B = a.B, T = a.T;
+  const int offg = (b * 4 * H + u) * 4, offh = (b * H + u) * 4;
+
+  stage_w<H>(a.w_hh, dyn_lds);
+  float frag[H];                                  // A operand: row (lane & 3) -> unit 16w + 4ug + (lane & 3); k -> gate row q H + k
+#pragma unroll
+  for (int k = 0; k < H; ++k) frag[k] = dyn_lds[(q * H + k) * (H + 1) + w * 16 + 4 * ug + s];
+
+  float dh = (a.g_hT && ok) ? a.g_hT[(size_t)b * H + u] : 0.f;
+  float dc = (a.g_cT && ok) ? a.g_cT[(size_t)b * H + u] : 0.f;
+  struct Saved { f32x4 act; float cp, go; };
+  auto fetch = [&](int t, Saved &sv) {
+    const __amdgpu_buffer_rsrc_t ra = step_rows(a.acts, t, B, 4 * H), rg = step_rows(a.g_out, t, B, H);
+    const __amdgpu_buffer_rsrc_t rc = (t > 0) ? step_rows(a.cs, t - 1, B, H) : step_rows(a.c0, 0, B, H);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sv.act[j] = bload1(ra, offg + j * H * 4);
+    sv.cp = bload1(rc, offh);
+    sv.go = bload1(rg, offh);
+  };
+  Saved nx = {};
+  float ct = 0.f;
+  if (T > 0) {
+    fetch(T - 1, nx);
+    ct = bload1(step_rows(a.cs, T - 1, B, H), offh);
+  }
+  __syncthreads();
+  pin(nx.act);
+  asm volatile("" : "+v"(nx.cp), "+v"(nx.go), "+v"(ct));
+  int cur = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    const float ai = nx.act[0], af = nx.act[1], ag = nx.act[2], ao = nx.act[3], cp = nx.cp, go = nx.go;
+    fetch(t > 0 ? t - 1 : 0, nx);
+    const float dht = go + dh;
+    const float tc = tanhf_(ct);
+    const float dct = dc + dht * ao * (1.f - tc * tc);
+    const float po = dht * tc * ao * (1.f - ao);
+    const float pi = dct * ag * ai * (1.f - ai);
+    const float pf = dct * cp * af * (1.f - af);
+    const float pg = dct * ai * (1.f - ag * ag);
+    dc = dct * af;
+    ct = cp;
+    float *d = dgs[cur][s];
+    d[u] = pi, d[H + u] = pf, d[2 * H + u] = pg, d[3 * H + u] = po;
+    {
+      const __amdgpu_buffer_rsrc_t rx = step_rows(a.g_gx, t, B, 4 * H);
+      bstore1(rx, offg, pi), bstore1(rx, offg + H * 4, pf), bstore1(rx, offg + 2 * H * 4, pg), bstore1(rx, offg + 3 * H * 4, po);
+    }
+    lds_barrier();
+    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0, e3 = e0;
+    const f32x4 *dp = reinterpret_cast<const f32x4 *>(d + q * H);
+#pragma unroll
+    for (int k4 = 0; k4 < H / 4; ++k4) {
+      const f32x4 dv = dp[k4];
+      e0 = mfma4(frag[4 * k4], dv[0], e0), e1 = mfma4(frag[4 * k4 + 1], dv[1], e1);
+      e2 = mfma4(frag[4 * k4 + 2], dv[2], e2), e3 = mfma4(frag[4 * k4 + 3], dv[3], e3);
+    }
+    f32x4 e = (e0 + e1) + (e2 + e3);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = dpp_add<0x128>(dpp_add<0x124>(e[i]));   // + row_ror:4, then + row_ror:8: all four quarters
+    dh = (q == 0) ? e[0] : (q == 1) ? e[1] : (q == 2) ? e[2] : e[3];
+    pin(nx.act);
+    asm volatile("" : "+v"(nx.cp), "+v"(nx.go));
+    cur ^= 1;                                      // the other buffer was last read two steps ago: one barrier per step
+  }
+  if (ok) {
+    if (a.g_h0) a.g_h0[(size_t)b * H + u] = dh;
+    if (a.g_c0) a.g_c0[(size_t)b * H + u] = dc;
   }
 }
 
@@ -217,7 +412,7 @@ using namespace p2c_lstm;
 
 static int check(const p2c_lstm_desc *d, Args &a) {
   if (!d || !d->w_hh) return P2C_E_NULL;
-  if (d->T < 0 || d->B < 0) return P2C_E_SHAPE;
+  if (d->T < 0 || d->B < 0 || d->B > (1 << 20)) return P2C_E_SHAPE;   // buffer offsets: (B + 16) * 4H * 4 bytes < 2^31
   if (d->H != 16 && d->H != 32 && d->H != 48 && d->H != 64) return P2C_E_SHAPE;
   a = Args{};
   a.gx = d->gx, a.h0 = d->h0, a.c0 = d->c0, a.w_hh = d->w_hh, a.out = d->out, a.hT = d->hT, a.cT = d->cT;
@@ -236,6 +431,8 @@ static void allow_lds() {
   if (done) return;
   (void)hipFuncSetAttribute((const void *)lstm_rec_fwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   (void)hipFuncSetAttribute((const void *)lstm_rec_bwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)lstm_rec_fwd_narrow_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)lstm_rec_bwd_narrow_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   done = true;
 }
 #define P2C_LSTM_DISPATCH(KERNEL, BWD)                                                                                     \
@@ -246,14 +443,29 @@ static void allow_lds() {
     default: allow_lds<64>(); hipLaunchKernelGGL(KERNEL<64>, grid, dim3(256), lds_bytes(64, BWD), (hipStream_t)stream, a);         \
   }
 
+// 4 sequences per workgroup up to B = 4096, 16 above; P2C_REC_TILE=wide|narrow forces one (tests run both)
+#include <stdlib.h>
+#include <string.h>
+static bool use_narrow(int B) {
+  const char *e = getenv("P2C_REC_TILE");
+  if (e && !strcmp(e, "wide")) return false;
+  if (e && !strcmp(e, "narrow")) return true;
+  return B <= 4096;
+}
+
 extern "C" int p2c_lstm_rec_fwd(const p2c_lstm_desc *d, void *stream) {
   Args a;
   int rc = check(d, a);
   if (rc) return rc;
   if (!a.gx || !a.out) return P2C_E_NULL;
   if (a.B == 0) return 0;
-  const dim3 grid((unsigned)((a.B + TS - 1) / TS));
-  P2C_LSTM_DISPATCH(lstm_rec_fwd_kernel, false)
+  if (use_narrow(a.B)) {
+    const dim3 grid((unsigned)((a.B + NS - 1) / NS));
+    P2C_LSTM_DISPATCH(lstm_rec_fwd_narrow_kernel, false)
+  } else {
+    const dim3 grid((unsigned)((a.B + TS - 1) / TS));
+    P2C_LSTM_DISPATCH(lstm_rec_fwd_kernel, false)
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -264,8 +476,13 @@ extern "C" int p2c_lstm_rec_bwd(const p2c_lstm_desc *d, void *stream) {
   if (rc) return rc;
   if (!a.acts || !a.cs || !a.g_gx) return P2C_E_NULL;
   if (a.B == 0) return 0;
-  const dim3 grid((unsigned)((a.B + TS - 1) / TS));
-  P2C_LSTM_DISPATCH(lstm_rec_bwd_kernel, true)
+  if (use_narrow(a.B)) {
+    const dim3 grid((unsigned)((a.B + NS - 1) / NS));
+    P2C_LSTM_DISPATCH(lstm_rec_bwd_narrow_kernel, false)
+  } else {
+    const dim3 grid((unsigned)((a.B + TS - 1) / TS));
+    P2C_LSTM_DISPATCH(lstm_rec_bwd_kernel, true)
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

@@ -1,0 +1,56 @@
+// p2c_rec_dev.h -- device helpers shared by the time-loop kernels (K7b p2c_lstm.hip, K7c p2c_s2s.hip).
+//
+// A recurrence step is ~1.3 us of MFMA + transcendental work; one exposed memory round trip per step doubles it. Two rules
+// keep the loop body free of them:
+//  (1) the waves exchange data through LDS only, so the barrier fences the LOCAL address space (lds_barrier) --
+//      __syncthreads() on gfx9 carries s_waitcnt vmcnt(0), i.e. it waits for the write acknowledgement of the step's own
+//      saved-row stores;
+//  (2) global rows go through BUFFER instructions with hardware range checking instead of `if (ok)` branches: lanes of
+//      sequences beyond B address past num_records (loads return 0, stores are dropped), a NULL tensor becomes a
+//      zero-record descriptor. The body is then straight-line code and the compiler's waitcnt pass can count
+//      (vmcnt(N) for "the loads issued before the last N stores") instead of falling back to vmcnt(0) at every join.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace p2c_rec {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// One time step's rows of a (T, B, row_floats) tensor as a raw buffer: base + t * B * row_floats, B * row_floats * 4 bytes
+// of records (0 for a NULL tensor). Lane offsets are b * row_bytes + column bytes: b >= B is out of range by construction.
+// The host bounds B so that every offset a lane can form stays below 2^31.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t step_rows(const float *base, int t, int B, int row_floats) {
+  const uintptr_t p = reinterpret_cast<uintptr_t>(base) + (size_t)t * B * row_floats * 4;   // (NULL: no records, never used)
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p), 0, base ? B * row_floats * 4 : 0, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void bstore4(__amdgpu_buffer_rsrc_t r, int byte_off, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
+}
+__device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, int byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), r, byte_off, 0, 0);
+}
+constexpr int OOB = 0x7fffff00;          // a byte offset no descriptor of these kernels reaches (host: records < 2^30)
+
+// Values loaded one step ahead are pinned (made resident) BEFORE the step's stores are issued: the wait the compiler
+// inserts for them then covers the loads only -- placed after the stores, vmcnt would also count the stores' round trip.
+__device__ __forceinline__ void pin(f32x4 &v) { asm volatile("" : "+v"(v)); }
+
+// v_exp_f32 + v_rcp_f32 (1 ulp each): the IEEE division sequence would triple the cost of the cell update
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
+
+}  // namespace p2c_rec

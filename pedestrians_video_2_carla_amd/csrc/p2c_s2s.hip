@@ -20,10 +20,11 @@
 #include <stdint.h>
 
 #include "../../include/p2c.h"
+#include "p2c_rec_dev.h"
 
 namespace p2c_s2s {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace p2c_rec;
 constexpr int TS = 16, TP = 17, H = 64, G4 = 4 * H, OMAX = 64;
 
 struct Args {
@@ -39,9 +40,6 @@ struct Args {
   int32_t T, B, O;
 };
 
-// v_exp_f32 + v_rcp_f32 (1 ulp each): the IEEE division sequence would triple the cost of the cell update
-__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 2.f * __builtin_amdgcn_rcpf(1.f + __expf(-2.f * x)) - 1.f; }
 __device__ __forceinline__ f32x4 load4(const float *p, bool ok) {
   return ok ? *reinterpret_cast<const f32x4 *>(p) : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
@@ -90,14 +88,15 @@ __device__ __forceinline__ void cell_bwd(const f32x4 &dh, const f32x4 &ai, const
     dc_acc[r] += dct * af[r];
   }
 }
-__device__ __forceinline__ void store_gates(float *base, size_t row, int u0, const f32x4 &a, const f32x4 &b, const f32x4 &c,
+__device__ __forceinline__ void store_gates(__amdgpu_buffer_rsrc_t rs, int off4, const f32x4 &a, const f32x4 &b, const f32x4 &c,
                                             const f32x4 &d) {
-  float *p = base + row * G4 + u0;
-  *reinterpret_cast<f32x4 *>(p) = a, *reinterpret_cast<f32x4 *>(p + H) = b;
-  *reinterpret_cast<f32x4 *>(p + 2 * H) = c, *reinterpret_cast<f32x4 *>(p + 3 * H) = d;
+  bstore4(rs, off4, a), bstore4(rs, off4 + H * 4, b), bstore4(rs, off4 + 2 * H * 4, c), bstore4(rs, off4 + 3 * H * 4, d);
 }
 
 // ---- forward -----------------------------------------------------------------------------------------------------------
+// KS0 = k-steps of the layer-0 product = ceil(O / 4) rounded to the instantiated values (13: pose_2d's 52 features; 16):
+// a compile-time bound keeps the k-loop free of the uniform guards that cut the MFMA stream into 4-instruction blocks.
+template <int KS0>
 __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
   extern __shared__ float img[];                    // staging image of one weight matrix at a time
   __shared__ float xT[OMAX * TP], h0T[H * TP], h1T[H * TP];
@@ -106,14 +105,15 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
   const int b = blockIdx.x * TS + c;
   const bool ok = b < a.B;
   const int u0 = w * 16 + 4 * g;
-  const int O = a.O, O4 = (O + 3) >> 2, B = a.B, T = a.T;
+  const int O = a.O, B = a.B, T = a.T;
+  const int off4 = (b * G4 + u0) * 4, off1 = (b * H + u0) * 4;
 
-  float fa0[4][OMAX / 4], fa1[4][H / 4], ffc[H / 4];
+  float fa0[4][KS0], fa1[4][H / 4], ffc[H / 4];
   stage(a.w_ih0, G4, O, img);
 #pragma unroll
   for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int ks = 0; ks < OMAX / 4; ++ks) {
+    for (int ks = 0; ks < KS0; ++ks) {
       const int k = 4 * ks + g;
       fa0[q][ks] = (k < O) ? img[(q * H + w * 16 + c) * (O + 1) + k] : 0.f;
     }
@@ -134,40 +134,42 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
   }
   const f32x4 c0r = load4(a.c0 + (size_t)b * H + u0, ok), c1r = load4(a.c1 + (size_t)b * H + u0, ok);
   f32x4 bfc;
+  int offo[4];                                       // byte offsets of this lane's four output features (OOB beyond O)
 #pragma unroll
-  for (int r = 0; r < 4; ++r) bfc[r] = (u0 + r < O) ? a.b_fc[u0 + r] : 0.f;
+  for (int r = 0; r < 4; ++r) {
+    bfc[r] = (u0 + r < O) ? a.b_fc[u0 + r] : 0.f;
+    offo[r] = (u0 + r < O) ? (b * O + u0 + r) * 4 : OOB;
+  }
   {   // x_0 (rows >= O stay zero: they only ever meet zero weight fragments)
 #pragma unroll
     for (int r = 0; r < 4; ++r) xT[(u0 + r) * TP + c] = (a.x0 && ok && u0 + r < O) ? a.x0[(size_t)b * O + u0 + r] : 0.f;
   }
+  f32x4 mask = bload4(step_rows(a.drop, 0, B, H), off1);
   __syncthreads();
+  pin(mask);
+  const bool has_drop = a.drop != nullptr;
 
   for (int t = 0; t < T; ++t) {
-    const size_t row = (size_t)t * B + b;
     f32x4 acc[4], ai, af, ag, ao, h;
+    const f32x4 m = mask;                            // this step's dropout mask was requested one step ahead
+    mask = bload4(step_rows(a.drop, (t + 1 < T) ? t + 1 : t, B, H), off1);
     // ---- layer 0
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = k0r[q];
 #pragma unroll
-    for (int ks = 0; ks < OMAX / 4; ++ks) {          // unrolled with a uniform guard: the fragments must stay in registers
-      if (ks < O4) {
-        const float bv = xT[(4 * ks + g) * TP + c];
+    for (int ks = 0; ks < KS0; ++ks) {
+      const float bv = xT[(4 * ks + g) * TP + c];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[q][ks], bv, acc[q], 0, 0, 0);
-      }
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[q][ks], bv, acc[q], 0, 0, 0);
     }
     cell_fwd(acc, c0r, ai, af, ag, ao, h);
-    if (a.drop) {
-      const f32x4 m = load4(a.drop + row * H + u0, ok);
-      h *= m;
-    }
-    if (ok) {
-      store_gates(a.acts0, row, u0, ai, af, ag, ao);
-      *reinterpret_cast<f32x4 *>(a.h0d + row * H + u0) = h;
-    }
+    if (has_drop) h *= m;
 #pragma unroll
     for (int r = 0; r < 4; ++r) h0T[(u0 + r) * TP + c] = h[r];
-    __syncthreads();
+    pin(mask);                                       // before the stores: the wait covers the one load only
+    store_gates(step_rows(a.acts0, t, B, G4), off4, ai, af, ag, ao);
+    bstore4(step_rows(a.h0d, t, B, H), off1, h);
+    lds_barrier();
     // ---- layer 1
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = k1r[q];
@@ -178,28 +180,31 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
       for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[q][ks], bv, acc[q], 0, 0, 0);
     }
     cell_fwd(acc, c1r, ai, af, ag, ao, h);
-    if (ok) {
-      store_gates(a.acts1, row, u0, ai, af, ag, ao);
-      *reinterpret_cast<f32x4 *>(a.h1 + row * H + u0) = h;
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) h1T[(u0 + r) * TP + c] = h[r];
-    __syncthreads();
-    // ---- fc: this wave's 16 output features
-    f32x4 o = bfc;
+    store_gates(step_rows(a.acts1, t, B, G4), off4, ai, af, ag, ao);
+    bstore4(step_rows(a.h1, t, B, H), off1, h);
+    lds_barrier();
+    // ---- fc: this wave's 16 output features (two accumulators halve the dependent chain)
+    f32x4 o = bfc, o2 = zero4();
 #pragma unroll
-    for (int ks = 0; ks < H / 4; ++ks)
+    for (int ks = 0; ks < H / 4; ks += 2) {
       o = __builtin_amdgcn_mfma_f32_16x16x4f32(ffc[ks], h1T[(4 * ks + g) * TP + c], o, 0, 0, 0);
+      o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ffc[ks + 1], h1T[(4 * ks + 4 + g) * TP + c], o2, 0, 0, 0);
+    }
+    o += o2;
+    const __amdgpu_buffer_rsrc_t ro = step_rows(a.out, t, B, O);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (ok && u0 + r < O) a.out[row * O + u0 + r] = o[r];
       xT[(u0 + r) * TP + c] = o[r];                // next step's input (features >= O are exactly zero)
+      bstore1(ro, offo[r], o[r]);
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------------
+template <int KS0>
 __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
   extern __shared__ float img[];
   __shared__ float doT[OMAX * TP], dg1T[G4 * TP], dg0T[G4 * TP];
@@ -208,13 +213,14 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
   const int b = blockIdx.x * TS + c;
   const bool ok = b < a.B;
   const int u0 = w * 16 + 4 * g;
-  const int O = a.O, O4 = (O + 3) >> 2, B = a.B, T = a.T;
+  const int O = a.O, B = a.B, T = a.T;
+  const int off4 = (b * G4 + u0) * 4, off1 = (b * H + u0) * 4;
 
   // transposed fragments: rows = this wave's 16 hidden units (or output features), k = the contracted index
-  float ffcT[OMAX / 4], f1T[G4 / 4], f0T[G4 / 4];
+  float ffcT[KS0], f1T[G4 / 4], f0T[G4 / 4];
   stage(a.w_fc, O, H, img);                          // dh1 = W_fc^T dout:  A[unit][k = o] = W_fc[o][unit]
 #pragma unroll
-  for (int ks = 0; ks < OMAX / 4; ++ks) {
+  for (int ks = 0; ks < KS0; ++ks) {
     const int k = 4 * ks + g;
     ffcT[ks] = (k < O) ? img[k * (H + 1) + w * 16 + c] : 0.f;
   }
@@ -227,37 +233,57 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
 
   const f32x4 c0r = load4(a.c0 + (size_t)b * H + u0, ok), c1r = load4(a.c1 + (size_t)b * H + u0, ok);
   f32x4 dc0 = zero4(), dc1 = zero4(), dx = zero4();
+  int offo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) offo[r] = (u0 + r < O) ? (b * O + u0 + r) * 4 : OOB;
+  const bool has_drop = a.drop != nullptr;
+
+  // The rows a step reads (loss gradient, saved gates of both layers, dropout mask) are requested at the top of the previous
+  // step and pinned at its end (a round trip to rows of a fresh 8 MB tensor measured longer than one 64-MFMA chain):
+  // requested at their use, each of the three groups would put that round trip on the critical path of the step.
+  struct Saved { f32x4 go, a1[4], a0[4], m; };
+  auto fetch = [&](int t, Saved &s) {
+    const __amdgpu_buffer_rsrc_t rg = step_rows(a.g_out, t, B, O), r1 = step_rows(a.acts1, t, B, G4), r0 = step_rows(a.acts0, t, B, G4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s.go[r] = bload1(rg, offo[r]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s.a1[q] = bload4(r1, off4 + q * H * 4), s.a0[q] = bload4(r0, off4 + q * H * 4);
+    s.m = bload4(step_rows(a.drop, t, B, H), off1);
+  };
+  auto pin_all = [&](Saved &s) {
+    pin(s.go), pin(s.m);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pin(s.a1[q]), pin(s.a0[q]);
+  };
+  Saved nx = {};
+  if (T > 0) fetch(T - 1, nx);
+  pin_all(nx);
 
   for (int t = T - 1; t >= 0; --t) {
-    const size_t row = (size_t)t * B + b;
+    const Saved sv = nx;
+    fetch(t > 0 ? t - 1 : 0, nx);                    // (the last step re-reads its own rows: no branch in the body)
     // ---- d out_t (loss + the next step's input gradient), this wave's 16 output features
-    f32x4 dout = dx;
+    f32x4 dout = dx + sv.go;                         // (features >= O: zero fragments gave dx = 0, the OOB load gave 0)
+    const __amdgpu_buffer_rsrc_t rt = step_rows(a.g_outtot, t, B, O);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if (ok && u0 + r < O) dout[r] += a.g_out[row * O + u0 + r];
-      else dout[r] = 0.f;
-      if (ok && u0 + r < O) a.g_outtot[row * O + u0 + r] = dout[r];
       doT[(u0 + r) * TP + c] = dout[r];
+      bstore1(rt, offo[r], dout[r]);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- fc backward: dh1 for this wave's 16 hidden units
     f32x4 dh = zero4();
 #pragma unroll
-    for (int ks = 0; ks < OMAX / 4; ++ks)
-      if (ks < O4) dh = __builtin_amdgcn_mfma_f32_16x16x4f32(ffcT[ks], doT[(4 * ks + g) * TP + c], dh, 0, 0, 0);
+    for (int ks = 0; ks < KS0; ++ks) dh = __builtin_amdgcn_mfma_f32_16x16x4f32(ffcT[ks], doT[(4 * ks + g) * TP + c], dh, 0, 0, 0);
     f32x4 pi, pf, pg, po;
-    {
-      const float *pa = a.acts1 + row * G4 + u0;
-      const f32x4 ai = load4(pa, ok), af = load4(pa + H, ok), ag = load4(pa + 2 * H, ok), ao = load4(pa + 3 * H, ok);
-      cell_bwd(dh, ai, af, ag, ao, c1r, pi, pf, pg, po, dc1);
-    }
-    if (ok) store_gates(a.g_gates1, row, u0, pi, pf, pg, po);
+    cell_bwd(dh, sv.a1[0], sv.a1[1], sv.a1[2], sv.a1[3], c1r, pi, pf, pg, po, dc1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       dg1T[(u0 + r) * TP + c] = pi[r], dg1T[(H + u0 + r) * TP + c] = pf[r];
       dg1T[(2 * H + u0 + r) * TP + c] = pg[r], dg1T[(3 * H + u0 + r) * TP + c] = po[r];
     }
-    __syncthreads();
+    store_gates(step_rows(a.g_gates1, t, B, G4), off4, pi, pf, pg, po);
+    lds_barrier();
     // ---- layer-1 input gradient: dh0 (two accumulators halve the dependent chain)
     f32x4 e0 = zero4(), e1 = zero4();
 #pragma unroll
@@ -266,19 +292,15 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
       e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1T[ks + 1], dg1T[(4 * ks + 4 + g) * TP + c], e1, 0, 0, 0);
     }
     dh = e0 + e1;
-    if (a.drop) dh *= load4(a.drop + row * H + u0, ok);
-    {
-      const float *pa = a.acts0 + row * G4 + u0;
-      const f32x4 ai = load4(pa, ok), af = load4(pa + H, ok), ag = load4(pa + 2 * H, ok), ao = load4(pa + 3 * H, ok);
-      cell_bwd(dh, ai, af, ag, ao, c0r, pi, pf, pg, po, dc0);
-    }
-    if (ok) store_gates(a.g_gates0, row, u0, pi, pf, pg, po);
+    if (has_drop) dh *= sv.m;
+    cell_bwd(dh, sv.a0[0], sv.a0[1], sv.a0[2], sv.a0[3], c0r, pi, pf, pg, po, dc0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       dg0T[(u0 + r) * TP + c] = pi[r], dg0T[(H + u0 + r) * TP + c] = pf[r];
       dg0T[(2 * H + u0 + r) * TP + c] = pg[r], dg0T[(3 * H + u0 + r) * TP + c] = po[r];
     }
-    __syncthreads();
+    store_gates(step_rows(a.g_gates0, t, B, G4), off4, pi, pf, pg, po);
+    lds_barrier();
     // ---- layer-0 input gradient = gradient of the previous step's output
     e0 = zero4(), e1 = zero4();
 #pragma unroll
@@ -287,6 +309,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
       e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0T[ks + 1], dg0T[(4 * ks + 4 + g) * TP + c], e1, 0, 0, 0);
     }
     dx = e0 + e1;
+    pin_all(nx);
   }
   if (ok) {
     *reinterpret_cast<f32x4 *>(a.g_c0 + (size_t)b * H + u0) = dc0;
@@ -300,7 +323,7 @@ using namespace p2c_s2s;
 
 static int fill(Args &a, const p2c_decoder_desc *d) {
   if (!d || !d->k0 || !d->c0 || !d->k1 || !d->c1 || !d->w_ih0 || !d->w_ih1 || !d->w_fc || !d->b_fc) return P2C_E_NULL;
-  if (d->T < 0 || d->B < 0 || d->H != H || d->O < 1 || d->O > OMAX) return P2C_E_SHAPE;
+  if (d->T < 0 || d->B < 0 || d->B > (1 << 20) || d->H != H || d->O < 1 || d->O > OMAX) return P2C_E_SHAPE;
   a = Args{};
   a.k0 = d->k0, a.c0 = d->c0, a.k1 = d->k1, a.c1 = d->c1, a.w_ih0 = d->w_ih0, a.w_ih1 = d->w_ih1, a.w_fc = d->w_fc;
   a.b_fc = d->b_fc, a.x0 = d->x0, a.drop = d->drop, a.out = d->out, a.acts0 = d->acts0, a.acts1 = d->acts1, a.h0d = d->h0d;
@@ -312,8 +335,10 @@ static int fill(Args &a, const p2c_decoder_desc *d) {
 static void allow_lds() {
   static bool done = false;
   if (done) return;
-  (void)hipFuncSetAttribute((const void *)decoder_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  (void)hipFuncSetAttribute((const void *)decoder_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)decoder_fwd_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)decoder_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)decoder_bwd_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)decoder_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   done = true;
 }
 static size_t image_bytes() { return sizeof(float) * (size_t)G4 * (H + 1); }   // the largest staged matrix (4H x H, O <= H)
@@ -325,7 +350,9 @@ extern "C" int p2c_decoder_fwd(const p2c_decoder_desc *d, void *stream) {
   if (!a.out || !a.acts0 || !a.acts1 || !a.h0d || !a.h1) return P2C_E_NULL;
   if (a.B == 0 || a.T == 0) return 0;
   allow_lds();
-  hipLaunchKernelGGL(decoder_fwd_kernel, dim3((unsigned)((a.B + TS - 1) / TS)), dim3(256), image_bytes(), (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((a.B + TS - 1) / TS));
+  if (a.O <= 52) hipLaunchKernelGGL(decoder_fwd_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(decoder_fwd_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -337,7 +364,9 @@ extern "C" int p2c_decoder_bwd(const p2c_decoder_desc *d, void *stream) {
   if (!a.g_out || !a.acts0 || !a.acts1 || !a.g_gates0 || !a.g_gates1 || !a.g_outtot || !a.g_c0 || !a.g_c1) return P2C_E_NULL;
   if (a.B == 0) return 0;
   allow_lds();
-  hipLaunchKernelGGL(decoder_bwd_kernel, dim3((unsigned)((a.B + TS - 1) / TS)), dim3(256), image_bytes(), (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((a.B + TS - 1) / TS));
+  if (a.O <= 52) hipLaunchKernelGGL(decoder_bwd_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(decoder_bwd_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

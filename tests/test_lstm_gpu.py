@@ -7,6 +7,14 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=['narrow', 'wide'])
+def rec_tile(request, monkeypatch):
+    """Every case runs on both tilings of the time-loop kernels: 4 sequences per workgroup (v_mfma_f32_4x4x1_16B, the default up
+    to B = 4096) and 16 (v_mfma_f32_16x16x4). The library reads the switch at each call."""
+    monkeypatch.setenv('P2C_REC_TILE', request.param)
+    return request.param
+
+
 def dev():
     assert torch.cuda.is_available(), 'these tests need the MI355X'
     return torch.device('cuda:0')
