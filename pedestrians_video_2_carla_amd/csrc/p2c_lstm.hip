@@ -328,7 +328,8 @@ __device__ __forceinline__ float dpp_add(float v) {
 
 template <int H>
 __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(const Args a) {
-  constexpr int GP = 4 * H + 4;                   // LDS pitch of one sequence's d-gates row
+  constexpr int HQ = H + 4, GP = 4 * HQ;          // LDS pitches: gate j of a sequence at j * HQ (the 16 (sequence, quarter) rows a
+                                                  // wave reads then start in different banks), sequences GP apart
   extern __shared__ float dyn_lds[];              // [4H][H+1] staging image of W_hh
   __shared__ __attribute__((aligned(16))) float dgs[2][NS][GP];
   const int lane = threadIdx.x & 63, s = lane & 3, blk = lane >> 2, ug = blk >> 2, q = blk & 3;
@@ -378,14 +379,14 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(cons
     dc = dct * af;
     ct = cp;
     float *d = dgs[cur][s];
-    d[u] = pi, d[H + u] = pf, d[2 * H + u] = pg, d[3 * H + u] = po;
+    d[u] = pi, d[HQ + u] = pf, d[2 * HQ + u] = pg, d[3 * HQ + u] = po;
     {
       const __amdgpu_buffer_rsrc_t rx = step_rows(a.g_gx, t, B, 4 * H);
       bstore1(rx, offg, pi), bstore1(rx, offg + H * 4, pf), bstore1(rx, offg + 2 * H * 4, pg), bstore1(rx, offg + 3 * H * 4, po);
     }
     lds_barrier();
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0, e3 = e0;
-    const f32x4 *dp = reinterpret_cast<const f32x4 *>(d + q * H);
+    const f32x4 *dp = reinterpret_cast<const f32x4 *>(d + q * HQ);
 #pragma unroll
     for (int k4 = 0; k4 < H / 4; ++k4) {
       const f32x4 dv = dp[k4];

@@ -18,6 +18,8 @@
 // H = 64, two layers, O <= 64 (pose_2d: 52); everything else takes the per-step path (ops.lstm_layer).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "../../include/p2c.h"
 #include "p2c_rec_dev.h"
@@ -317,6 +319,211 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
   }
 }
 
+// ---- narrow variants: 4 clips per workgroup (v_mfma_f32_4x4x1_16B_f32) -----------------------------------------------------
+// Same reasoning as p2c_lstm.hip's narrow kernels: at B = 512 the 16-clip tiling runs 32 workgroups, each queueing ~140
+// 32-cycle MFMAs per time step on its SIMDs. With 16 blocks of 4 x 4 x 1 per instruction a workgroup owns 4 clips (the 4
+// columns, shared by all blocks) and a wave 16 hidden units / output features (the blocks):
+//   gate products (forward): block = unit, the 4 rows = its gates i, f, g, o  -> lane (unit, clip) holds all four;
+//   transposed products (fc, and every product of the backward): block = (row group of 4, quarter of K); the quarters are
+//     summed across lanes with two row-rotate DPP adds and lane (group ug, quarter q) keeps row 4 ug + q -- so in every
+//     stage lane (block k, column s) owns element (16 w + k, clip s).
+constexpr int NS = 4, HP = H + 4, GP = 4 * HP, OP = OMAX + 4;   // LDS pitches (16-byte aligned): a clip's h row, its d-gates row
+// (gate j at j * HP: with the clip pitch 4 * HP = 16 banks mod 64 the 16 (clip, quarter) rows a wave reads start 4 banks apart)
+
+__device__ __forceinline__ f32x4 mfma4(float a_, float b_, f32x4 c_) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a_, b_, c_, 0, 0, 0); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return v + __builtin_bit_cast(float, r);
+}
+// init + sum_k fr[k] * brow[k] on every block, four interleaved accumulators; brow = this lane's clip row in LDS
+template <int N>
+__device__ __forceinline__ f32x4 block_product(const float (&fr)[N], const float *brow, f32x4 init) {
+  f32x4 e0 = init, e1 = zero4(), e2 = e1, e3 = e1;
+  const f32x4 *bp = reinterpret_cast<const f32x4 *>(brow);
+#pragma unroll
+  for (int k4 = 0; k4 < N / 4; ++k4) {
+    const f32x4 v = bp[k4];
+    e0 = mfma4(fr[4 * k4], v[0], e0), e1 = mfma4(fr[4 * k4 + 1], v[1], e1);
+    e2 = mfma4(fr[4 * k4 + 2], v[2], e2), e3 = mfma4(fr[4 * k4 + 3], v[3], e3);
+  }
+  return (e0 + e1) + (e2 + e3);
+}
+// the K-quarter form: blocks (ug, q) hold partial sums of rows 4 ug .. 4 ug + 3; returns row 4 ug + q of the full sum
+template <int N>
+__device__ __forceinline__ float quarter_product(const float (&fr)[N], const float *brow, int q) {
+  f32x4 e = block_product<N>(fr, brow, zero4());
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = dpp_add<0x128>(dpp_add<0x124>(e[i]));   // + row_ror:4, then + row_ror:8
+  return (q == 0) ? e[0] : (q == 1) ? e[1] : (q == 2) ? e[2] : e[3];
+}
+__device__ __forceinline__ void cell_fwd1(const f32x4 &acc, float c_enc, f32x4 &act, float &h) {
+  act[0] = sigmoidf_(acc[0]), act[1] = sigmoidf_(acc[1]), act[2] = tanhf_(acc[2]), act[3] = sigmoidf_(acc[3]);
+  h = act[3] * tanhf_(act[1] * c_enc + act[0] * act[2]);
+}
+__device__ __forceinline__ f32x4 cell_bwd1(float dh, const f32x4 &act, float c_enc, float &dc_acc) {
+  const float ai = act[0], af = act[1], ag = act[2], ao = act[3];
+  const float tc = tanhf_(af * c_enc + ai * ag);
+  const float dct = dh * ao * (1.f - tc * tc);
+  f32x4 p;
+  p[3] = dh * tc * ao * (1.f - ao);
+  p[0] = dct * ag * ai * (1.f - ai);
+  p[1] = dct * c_enc * af * (1.f - af);
+  p[2] = dct * ai * (1.f - ag * ag);
+  dc_acc += dct * af;
+  return p;
+}
+__device__ __forceinline__ void store_gates1(__amdgpu_buffer_rsrc_t rs, int offg, const f32x4 &v) {
+  bstore1(rs, offg, v[0]), bstore1(rs, offg + H * 4, v[1]), bstore1(rs, offg + 2 * H * 4, v[2]), bstore1(rs, offg + 3 * H * 4, v[3]);
+}
+__device__ __forceinline__ f32x4 load_gates1(__amdgpu_buffer_rsrc_t rs, int offg) {
+  f32x4 v;
+  v[0] = bload1(rs, offg), v[1] = bload1(rs, offg + H * 4), v[2] = bload1(rs, offg + 2 * H * 4), v[3] = bload1(rs, offg + 3 * H * 4);
+  return v;
+}
+
+template <int KS0>
+__global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
+  constexpr int K0 = 4 * KS0;
+  extern __shared__ float img[];                    // staging image of one weight matrix at a time
+  __shared__ __attribute__((aligned(16))) float xs[NS][OP], h0s[NS][HP], h1s[NS][HP];
+  const int lane = threadIdx.x & 63, s = lane & 3, blk = lane >> 2, q = blk & 3;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = w * 16 + blk;                       // this lane's hidden unit AND output feature
+  const int b = blockIdx.x * NS + s;
+  const bool ok = b < a.B;
+  const int O = a.O, B = a.B, T = a.T;
+  const int offg = (b * G4 + u) * 4, offh = (b * H + u) * 4, offo = (u < O) ? (b * O + u) * 4 : OOB;
+
+  float fa0[K0], fa1[H], ffc[16];
+  stage(a.w_ih0, G4, O, img);                       // gate products: row (lane & 3) = gate of block = unit u
+#pragma unroll
+  for (int k = 0; k < K0; ++k) fa0[k] = (k < O) ? img[(s * H + u) * (O + 1) + k] : 0.f;
+  stage(a.w_ih1, G4, H, img);
+#pragma unroll
+  for (int k = 0; k < H; ++k) fa1[k] = img[(s * H + u) * (H + 1) + k];
+  stage(a.w_fc, O, H, img);                         // fc: blocks (feature group, K quarter q): row (lane & 3) -> feature 16w + 4 (blk >> 2) + (lane & 3)
+  {
+    const int f = w * 16 + 4 * (blk >> 2) + s;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) ffc[kk] = (f < O) ? img[f * (H + 1) + q * 16 + kk] : 0.f;
+  }
+  f32x4 k0r, k1r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    k0r[j] = ok ? a.k0[(size_t)b * G4 + j * H + u] : 0.f;
+    k1r[j] = ok ? a.k1[(size_t)b * G4 + j * H + u] : 0.f;
+  }
+  const float c0r = ok ? a.c0[(size_t)b * H + u] : 0.f, c1r = ok ? a.c1[(size_t)b * H + u] : 0.f;
+  const float bfc = (u < O) ? a.b_fc[u] : 0.f;
+  xs[s][u] = (a.x0 && ok && u < O) ? a.x0[(size_t)b * O + u] : 0.f;    // features >= O stay zero
+  float mask = bload1(step_rows(a.drop, 0, B, H), offh);
+  __syncthreads();
+  asm volatile("" : "+v"(mask));
+  const bool has_drop = a.drop != nullptr;
+
+  for (int t = 0; t < T; ++t) {
+    const float m = mask;
+    mask = bload1(step_rows(a.drop, (t + 1 < T) ? t + 1 : t, B, H), offh);
+    f32x4 act;
+    float h;
+    // ---- layer 0
+    cell_fwd1(block_product<K0>(fa0, xs[s], k0r), c0r, act, h);
+    if (has_drop) h *= m;
+    h0s[s][u] = h;
+    asm volatile("" : "+v"(mask));                   // resident before the stores: the wait covers the one load only
+    store_gates1(step_rows(a.acts0, t, B, G4), offg, act);
+    bstore1(step_rows(a.h0d, t, B, H), offh, h);
+    lds_barrier();
+    // ---- layer 1
+    cell_fwd1(block_product<H>(fa1, h0s[s], k1r), c1r, act, h);
+    h1s[s][u] = h;
+    store_gates1(step_rows(a.acts1, t, B, G4), offg, act);
+    bstore1(step_rows(a.h1, t, B, H), offh, h);
+    lds_barrier();
+    // ---- fc
+    const float o = quarter_product<16>(ffc, h1s[s] + q * 16, q) + bfc;
+    xs[s][u] = o;                                    // next step's input (features >= O are exactly zero)
+    bstore1(step_rows(a.out, t, B, O), offo, o);
+    lds_barrier();
+  }
+}
+
+template <int KS0>
+__global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
+  extern __shared__ float img[];
+  __shared__ __attribute__((aligned(16))) float dos[NS][OP], dg1s[NS][GP], dg0s[NS][GP];
+  const int lane = threadIdx.x & 63, s = lane & 3, blk = lane >> 2, q = blk & 3;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int u = w * 16 + blk;                       // this lane's hidden unit AND output feature
+  const int ra_ = w * 16 + 4 * (blk >> 2) + s;      // the A-operand row of this lane (a unit or an output feature)
+  const int b = blockIdx.x * NS + s;
+  const bool ok = b < a.B;
+  const int O = a.O, B = a.B, T = a.T;
+  const int offg = (b * G4 + u) * 4, offh = (b * H + u) * 4, offo = (u < O) ? (b * O + u) * 4 : OOB;
+
+  float ffcT[16], f1T[H], f0T[H];
+  stage(a.w_fc, O, H, img);                          // dh1 = W_fc^T dout: rows = units, K quarter q = features 16 q .. 16 q + 15
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) ffcT[kk] = (q * 16 + kk < O) ? img[(q * 16 + kk) * (H + 1) + ra_] : 0.f;
+  stage(a.w_ih1, G4, H, img);                        // dh0 = W_ih1^T dgates1: rows = units, K quarter q = gate q's H rows
+#pragma unroll
+  for (int k = 0; k < H; ++k) f1T[k] = img[(q * H + k) * (H + 1) + ra_];
+  stage(a.w_ih0, G4, O, img);                        // dx = W_ih0^T dgates0: rows = output features
+#pragma unroll
+  for (int k = 0; k < H; ++k) f0T[k] = (ra_ < O) ? img[(q * H + k) * (O + 1) + ra_] : 0.f;
+
+  const float c0r = ok ? a.c0[(size_t)b * H + u] : 0.f, c1r = ok ? a.c1[(size_t)b * H + u] : 0.f;
+  float dc0 = 0.f, dc1 = 0.f, dx = 0.f;
+  const bool has_drop = a.drop != nullptr;
+
+  struct Saved { f32x4 a1, a0; float go, m; };
+  auto fetch = [&](int t, Saved &sv) {
+    sv.go = bload1(step_rows(a.g_out, t, B, O), offo);
+    sv.a1 = load_gates1(step_rows(a.acts1, t, B, G4), offg);
+    sv.a0 = load_gates1(step_rows(a.acts0, t, B, G4), offg);
+    sv.m = bload1(step_rows(a.drop, t, B, H), offh);
+  };
+  auto pin_all = [&](Saved &sv) {
+    pin(sv.a1), pin(sv.a0);
+    asm volatile("" : "+v"(sv.go), "+v"(sv.m));
+  };
+  Saved nx = {};
+  if (T > 0) fetch(T - 1, nx);
+  __syncthreads();
+  pin_all(nx);
+
+  for (int t = T - 1; t >= 0; --t) {
+    const Saved sv = nx;
+    fetch(t > 0 ? t - 1 : 0, nx);                    // (the last step re-reads its own rows: no branch in the body)
+    // ---- d out_t (loss + the next step's input gradient)
+    const float dout = dx + sv.go;                   // features >= O: zero fragments gave dx = 0, the OOB load 0
+    dos[s][u] = dout;
+    bstore1(step_rows(a.g_outtot, t, B, O), offo, dout);
+    lds_barrier();
+    // ---- fc backward, layer-1 cell
+    float dh = quarter_product<16>(ffcT, dos[s] + q * 16, q);
+    f32x4 p = cell_bwd1(dh, sv.a1, c1r, dc1);
+    dg1s[s][u] = p[0], dg1s[s][HP + u] = p[1], dg1s[s][2 * HP + u] = p[2], dg1s[s][3 * HP + u] = p[3];
+    store_gates1(step_rows(a.g_gates1, t, B, G4), offg, p);
+    lds_barrier();
+    // ---- layer-1 input gradient, layer-0 cell
+    dh = quarter_product<H>(f1T, dg1s[s] + q * HP, q);
+    if (has_drop) dh *= sv.m;
+    p = cell_bwd1(dh, sv.a0, c0r, dc0);
+    dg0s[s][u] = p[0], dg0s[s][HP + u] = p[1], dg0s[s][2 * HP + u] = p[2], dg0s[s][3 * HP + u] = p[3];
+    store_gates1(step_rows(a.g_gates0, t, B, G4), offg, p);
+    lds_barrier();
+    // ---- layer-0 input gradient = gradient of the previous step's output
+    dx = quarter_product<H>(f0T, dg0s[s] + q * HP, q);
+    pin_all(nx);
+  }
+  if (ok) {
+    a.g_c0[(size_t)b * H + u] = dc0;
+    a.g_c1[(size_t)b * H + u] = dc1;
+  }
+}
+
 }  // namespace p2c_s2s
 
 using namespace p2c_s2s;
@@ -332,6 +539,14 @@ static int fill(Args &a, const p2c_decoder_desc *d) {
   return 0;
 }
 
+// 4 clips per workgroup up to B = 4096, 16 above; P2C_REC_TILE=wide|narrow forces one (tests run both)
+static bool use_narrow(int B) {
+  const char *e = getenv("P2C_REC_TILE");
+  if (e && !strcmp(e, "wide")) return false;
+  if (e && !strcmp(e, "narrow")) return true;
+  return B <= 4096;
+}
+
 static void allow_lds() {
   static bool done = false;
   if (done) return;
@@ -339,6 +554,10 @@ static void allow_lds() {
   (void)hipFuncSetAttribute((const void *)decoder_fwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   (void)hipFuncSetAttribute((const void *)decoder_bwd_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   (void)hipFuncSetAttribute((const void *)decoder_bwd_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)decoder_fwd_narrow_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)decoder_fwd_narrow_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)decoder_bwd_narrow_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  (void)hipFuncSetAttribute((const void *)decoder_bwd_narrow_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
   done = true;
 }
 static size_t image_bytes() { return sizeof(float) * (size_t)G4 * (H + 1); }   // the largest staged matrix (4H x H, O <= H)
@@ -350,9 +569,15 @@ extern "C" int p2c_decoder_fwd(const p2c_decoder_desc *d, void *stream) {
   if (!a.out || !a.acts0 || !a.acts1 || !a.h0d || !a.h1) return P2C_E_NULL;
   if (a.B == 0 || a.T == 0) return 0;
   allow_lds();
-  const dim3 grid((unsigned)((a.B + TS - 1) / TS));
-  if (a.O <= 52) hipLaunchKernelGGL(decoder_fwd_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(decoder_fwd_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+  if (use_narrow(a.B)) {
+    const dim3 grid((unsigned)((a.B + NS - 1) / NS));
+    if (a.O <= 52) hipLaunchKernelGGL(decoder_fwd_narrow_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(decoder_fwd_narrow_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+  } else {
+    const dim3 grid((unsigned)((a.B + TS - 1) / TS));
+    if (a.O <= 52) hipLaunchKernelGGL(decoder_fwd_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(decoder_fwd_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -364,9 +589,15 @@ extern "C" int p2c_decoder_bwd(const p2c_decoder_desc *d, void *stream) {
   if (!a.g_out || !a.acts0 || !a.acts1 || !a.g_gates0 || !a.g_gates1 || !a.g_outtot || !a.g_c0 || !a.g_c1) return P2C_E_NULL;
   if (a.B == 0) return 0;
   allow_lds();
-  const dim3 grid((unsigned)((a.B + TS - 1) / TS));
-  if (a.O <= 52) hipLaunchKernelGGL(decoder_bwd_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(decoder_bwd_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+  if (use_narrow(a.B)) {
+    const dim3 grid((unsigned)((a.B + NS - 1) / NS));
+    if (a.O <= 52) hipLaunchKernelGGL(decoder_bwd_narrow_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(decoder_bwd_narrow_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+  } else {
+    const dim3 grid((unsigned)((a.B + TS - 1) / TS));
+    if (a.O <= 52) hipLaunchKernelGGL(decoder_bwd_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(decoder_bwd_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+  }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
