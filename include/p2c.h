@@ -267,6 +267,21 @@ P2C_API int p2c_embed_fwd(const float *x, const float *W, const float *b, int64_
 P2C_API int p2c_embed_bwd(const float *x, const float *gy, int64_t w_stride, int64_t b_stride, float *gW, float *gb,
                   float *partials, int32_t B, int32_t T, int32_t J, int32_t C, int32_t E, int32_t flip, void *stream);
 
+/* ---- folded input map (K7a') ------------------------------------------------------------------------------------------
+ * Seq2SeqEmbeddings feeds concat_j(W_j x_j + b_j) into the encoder LSTM's first input projection (seq2seq_embeddings.py:
+ * 53-78 -> seq2seq.py:36-58) with nothing non-linear in between; the train step composes the two linear maps instead of
+ * materialising the (T,B,J*E) embedding tensor:
+ *   w_eff[g, j*C + c] = sum_e w_ih[g, j*E + e] W_j[e, c]        b_eff[g] = b_ih[g] + b_hh[g] + sum_{j,e} w_ih[g, j*E+e] b_j[e]
+ * w_ih (G, J*E); W_j / b_j addressed with strides as in p2c_embed_*; b_ih / b_hh (G) optional. Backward: from g_eff
+ * (G, J*C) and g_b (G) it WRITES (accumulate_w = 0) or ADDS TO g_w_ih (G, J*E), ADDS to gW / gb (the strides of W / b)
+ * and, when given, ADDS g_b to g_b_ih / g_b_hh. One launch each, fixed summation order. C <= 4. */
+P2C_API int p2c_fold_fwd(const float *w_ih, const float *W, const float *b, int64_t w_stride, int64_t b_stride,
+                 const float *b_ih, const float *b_hh, float *w_eff, float *b_eff, int32_t G, int32_t J, int32_t E,
+                 int32_t C, void *stream);
+P2C_API int p2c_fold_bwd(const float *w_ih, const float *W, const float *b, int64_t w_stride, int64_t b_stride,
+                 const float *g_eff, const float *g_b, float *g_w_ih, int32_t accumulate_w, float *gW, float *gb,
+                 float *g_b_ih, float *g_b_hh, int32_t G, int32_t J, int32_t E, int32_t C, void *stream);
+
 /* ---- LSTM recurrence (K7b) ---------------------------------------------------------------------------------------------
  * The time loop of one torch.nn.LSTM layer (gate order i, f, g, o; reference seq2seq.py:36-58 Encoder / Decoder):
  *   gates[t] = gx[t] + h[t-1] W_hh^T ;  c[t] = f c[t-1] + i g ;  h[t] = o tanh(c[t])
@@ -312,6 +327,18 @@ typedef struct p2c_decoder_desc {
   float *g_gates0, *g_gates1;     /* (T,B,4H) */
   float *g_outtot;                /* (T,B,O) */
   float *g_c0, *g_c1;             /* (B,H) */
+  /* optional (zero-initialise the struct): the frame-invariant terms formed inside the launch. With hid0 != NULL,
+   * k_l = b{l}a + b{l}b + hid_l w_hh{l}^T is computed by the forward itself from the encoder hidden states hid_l (B,H),
+   * decoder.rnn.weight_hh_l{l} (4H,H) and the two bias vectors (4H; either may be NULL); k0 / k1 are then ignored and
+   * kw0 / kw1 (B,4H) are scratch the 16-clip tiling (B > 4096) writes k_l to. out_bt: a second copy of out laid out
+   * (B,T,O), the layout the model returns (saves the permute copy). Backward: g_out_bt != 0 says g_out is laid out (B,T,O);
+   * g_k0 / g_k1 (B,4H) receive sum_t d gates_l (= d k_l), g_hid0 / g_hid1 (B,H) receive d hid_l = g_k_l w_hh{l} (both or
+   * neither; they need w_hh{l} and, above B = 4096, g_k0 / g_k1). */
+  const float *hid0, *hid1, *w_hh0, *w_hh1, *b0a, *b0b, *b1a, *b1b;
+  float *kw0, *kw1;
+  float *out_bt;
+  float *g_k0, *g_k1, *g_hid0, *g_hid1;
+  int32_t g_out_bt;
 } p2c_decoder_desc;
 P2C_API int p2c_decoder_fwd(const p2c_decoder_desc *desc, void *stream);
 P2C_API int p2c_decoder_bwd(const p2c_decoder_desc *desc, void *stream);
@@ -406,6 +433,22 @@ P2C_API int p2c_collate_fwd(const p2c_collate_desc *desc, void *stream);
 P2C_API int64_t p2c_atb_workspace_floats(int64_t K, int32_t M, int32_t N, int32_t with_bias);
 P2C_API int p2c_atb(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int32_t M, int32_t N, float *C,
                     int64_t ldc, float *bias_out, int32_t accumulate, float *workspace, void *stream);
+
+/* Grouped form: up to 8 independent problems behind ONE launch pair (the backward of a Seq2Seq layer stack is a row of
+ * these contractions). Per problem the fields of p2c_atb; bias_out2 = a second vector that receives the same column sums
+ * (bias_ih / bias_hh of an LSTM layer), needs bias_out. flags = the `accumulate` bits of p2c_atb. workspace =
+ * p2c_atb_group_workspace_floats floats. Same kernels, same per-problem summation order as p2c_atb (bitwise equal results). */
+typedef struct p2c_atb_problem {
+  const float *a; int64_t a_stride;   /* (K, M) */
+  const float *b; int64_t b_stride;   /* (K, N) */
+  int64_t K;
+  int32_t M, N;
+  float *out; int64_t out_stride;     /* (M, N) */
+  float *bias_out, *bias_out2;        /* (M) or NULL */
+  int32_t flags;
+} p2c_atb_problem;
+P2C_API int64_t p2c_atb_group_workspace_floats(const p2c_atb_problem *problems, int32_t n);
+P2C_API int p2c_atb_group(const p2c_atb_problem *problems, int32_t n, float *workspace, void *stream);
 
 #ifdef __cplusplus
 }

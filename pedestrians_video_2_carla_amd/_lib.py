@@ -78,7 +78,15 @@ class DecoderDesc(ctypes.Structure):
     """p2c_decoder_desc (include/p2c.h)."""
     _fields_ = [('T', ctypes.c_int32), ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('O', ctypes.c_int32)] + [
         (n, _f32p) for n in ('k0', 'c0', 'k1', 'c1', 'w_ih0', 'w_ih1', 'w_fc', 'b_fc', 'x0', 'drop', 'out', 'acts0', 'acts1',
-                             'h0d', 'h1', 'g_out', 'g_gates0', 'g_gates1', 'g_outtot', 'g_c0', 'g_c1')]
+                             'h0d', 'h1', 'g_out', 'g_gates0', 'g_gates1', 'g_outtot', 'g_c0', 'g_c1',
+                             'hid0', 'hid1', 'w_hh0', 'w_hh1', 'b0a', 'b0b', 'b1a', 'b1b', 'kw0', 'kw1', 'out_bt',
+                             'g_k0', 'g_k1', 'g_hid0', 'g_hid1')] + [('g_out_bt', ctypes.c_int32)]
+
+
+class AtbProblem(ctypes.Structure):
+    """p2c_atb_problem (include/p2c.h)."""
+    _fields_ = [('a', _f32p), ('a_stride', _i64), ('b', _f32p), ('b_stride', _i64), ('K', _i64), ('M', _i32), ('N', _i32),
+                ('out', _f32p), ('out_stride', _i64), ('bias_out', _f32p), ('bias_out2', _f32p), ('flags', _i32)]
 
 
 class CollateDesc(ctypes.Structure):
@@ -128,8 +136,12 @@ SYMBOLS = {
     'p2c_embed_workspace_floats': (_i64, [ctypes.c_int32] * 5),
     'p2c_embed_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp] + [ctypes.c_int32] * 6 + [_vp]),
     'p2c_embed_bwd': (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp] + [ctypes.c_int32] * 6 + [_vp]),
+    'p2c_fold_fwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp]),
+    'p2c_fold_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp]),
     'p2c_atb_workspace_floats': (_i64, [_i64, _i32, _i32, _i32]),
     'p2c_atb': (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
+    'p2c_atb_group_workspace_floats': (_i64, [ctypes.POINTER(AtbProblem), _i32]),
+    'p2c_atb_group': (ctypes.c_int, [ctypes.POINTER(AtbProblem), _i32, _vp, _vp]),
     'p2c_mlp_fwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
     'p2c_mlp_bwd': (ctypes.c_int, [ctypes.POINTER(MlpDesc), _vp]),
     'p2c_train_step_supported': (ctypes.c_int, [ctypes.POINTER(TrainStepDesc)]),

@@ -24,18 +24,18 @@ struct Args {
   float *C, *bias, *ws;
   int64_t lda, ldb, ldc, K;
   int32_t M, N, ones, accumulate, ks, tiles;
+  float *bias2;                 // second destination of the bias gradient (b_ih and b_hh of an LSTM layer receive the same sums)
 };
 
 // One wave accumulates a 32x32 block of C as 2x2 MFMA tiles; lane (r, kk) loads the column PAIRS 2r, 2r+1 of row kk of
 // A and of B as one 8-byte access each (a whole 128-byte line per row and operand), so tile (h, g) of the block is the
 // interleaved set of rows m0 + 2i + h and columns n0 + 2j + g: two loads feed four MFMAs.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__global__ __launch_bounds__(64 * WAVES) void atb_kernel(const Args a) {
-  __shared__ f32x4 red[WAVES][4][64];
+__device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*red)[4][64]) {
   const int lane = threadIdx.x & 63, r = lane & 15, kk = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nb_count = (a.N + a.ones + 31) >> 5;
-  const int blk = blockIdx.x % a.tiles, slice = blockIdx.x / a.tiles;
+  const int blk = bid % a.tiles, slice = bid / a.tiles;
   const int mb = blk / nb_count, nb = blk - mb * nb_count;
   const int m = mb * 32 + 2 * r, n = nb * 32 + 2 * r;          // first column of this lane's pair
   const bool vec_a = (m + 1 < a.M) && ((a.lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 7) == 0);
@@ -85,9 +85,14 @@ __global__ __launch_bounds__(64 * WAVES) void atb_kernel(const Args a) {
   reinterpret_cast<f32x4 *>(a.ws)[(((size_t)slice * a.tiles + blk) * 4 + wave) * 64 + lane] = s;
 }
 
+__global__ __launch_bounds__(64 * WAVES) void atb_kernel(const Args a) {
+  __shared__ f32x4 red[WAVES][4][64];
+  atb_body(a, blockIdx.x, red);
+}
+
 // slices added in order, one thread per (block, tile, lane)
-__global__ __launch_bounds__(256) void atb_finish_kernel(const Args a) {
-  const int idx = blockIdx.x * 256 + threadIdx.x, lane = idx & 63, tile = (idx >> 6) & 3, blk = idx >> 8;
+__device__ __forceinline__ void finish_body(const Args &a, const int bid) {
+  const int idx = bid * 256 + threadIdx.x, lane = idx & 63, tile = (idx >> 6) & 3, blk = idx >> 8;
   if (blk >= a.tiles) return;
   const f32x4 *p = reinterpret_cast<const f32x4 *>(a.ws) + ((size_t)blk * 4 + tile) * 64 + lane;
   const size_t stride = (size_t)a.tiles * 256;
@@ -113,8 +118,32 @@ __global__ __launch_bounds__(256) void atb_finish_kernel(const Args a) {
       *c = (a.accumulate & 1) ? *c + s[i] : s[i];
     } else if (a.ones && col == a.N && a.bias) {
       a.bias[row] = (a.accumulate & 2) ? a.bias[row] + s[i] : s[i];
+      if (a.bias2) a.bias2[row] = (a.accumulate & 2) ? a.bias2[row] + s[i] : s[i];
     }
   }
+}
+__global__ __launch_bounds__(256) void atb_finish_kernel(const Args a) { finish_body(a, blockIdx.x); }
+
+// ---- grouped form: up to MAXG independent problems behind one launch pair. The backward of a Seq2Seq layer stack is a
+// row of such contractions (decoder: dW_ih0, dW_ih1, dW_fc + db_fc, dW_hh0 + db, dW_hh1 + db); launched one by one each
+// pair costs ~2 x 2-5 us of launch + tail on top of its ~10 us of work. The problems ride in the kernel arguments; a
+// workgroup finds its problem by a scan over at most MAXG prefix sums.
+constexpr int MAXG = 8;
+struct Group {
+  Args p[MAXG];
+  int32_t first[MAXG + 1], ffirst[MAXG + 1];      // first workgroup of problem i in the main / the finish launch
+  int32_t n;
+};
+__global__ __launch_bounds__(64 * WAVES) void atb_group_kernel(const Group g) {
+  __shared__ f32x4 red[WAVES][4][64];
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
+  atb_body(g.p[i], blockIdx.x - g.first[i], red);
+}
+__global__ __launch_bounds__(256) void atb_group_finish_kernel(const Group g) {
+  int i = 0;
+  while (i + 1 < g.n && (int)blockIdx.x >= g.ffirst[i + 1]) ++i;
+  finish_body(g.p[i], blockIdx.x - g.ffirst[i]);
 }
 
 }  // namespace p2c_atb_impl
@@ -137,11 +166,54 @@ extern "C" int p2c_atb(const float *A, int64_t lda, const float *B, int64_t ldb,
   using namespace p2c_atb_impl;
   if (!A || !B || !C || !workspace) return P2C_E_NULL;
   if (K < 0 || M < 1 || N < 1 || lda < M || ldb < N || ldc < N) return P2C_E_SHAPE;
-  Args a{A, B, C, bias_out, workspace, lda, ldb, ldc, K, M, N, bias_out ? 1 : 0, accumulate & 3, 1, 0};
+  Args a{A, B, C, bias_out, workspace, lda, ldb, ldc, K, M, N, bias_out ? 1 : 0, accumulate & 3, 1, 0, nullptr};
   a.tiles = ((M + 31) / 32) * ((N + a.ones + 31) / 32);      // 32x32 blocks of C
   a.ks = slices_for(a.tiles, K);
   hipLaunchKernelGGL(atb_kernel, dim3((unsigned)(a.tiles * a.ks)), dim3(64 * WAVES), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(atb_finish_kernel, dim3((unsigned)a.tiles), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+static int group_fill(const p2c_atb_problem *p, int32_t n, float *workspace, p2c_atb_impl::Group &g, int64_t *ws_total) {
+  using namespace p2c_atb_impl;
+  if (!p) return P2C_E_NULL;
+  if (n < 1 || n > MAXG) return P2C_E_SHAPE;
+  g.n = n, g.first[0] = g.ffirst[0] = 0;
+  int64_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    const p2c_atb_problem &q = p[i];
+    if (!q.a || !q.b || !q.out) return P2C_E_NULL;
+    if (q.K < 0 || q.M < 1 || q.N < 1 || q.a_stride < q.M || q.b_stride < q.N || q.out_stride < q.N) return P2C_E_SHAPE;
+    if (q.bias_out2 && !q.bias_out) return P2C_E_NULL;
+    Args &a = g.p[i];
+    a = Args{q.a, q.b, q.out, q.bias_out, workspace ? workspace + off : nullptr, q.a_stride, q.b_stride, q.out_stride, q.K,
+             q.M, q.N, q.bias_out ? 1 : 0, q.flags & 3, 1, 0, q.bias_out2};
+    a.tiles = ((q.M + 31) / 32) * ((q.N + a.ones + 31) / 32);
+    a.ks = slices_for(a.tiles, q.K);
+    g.first[i + 1] = g.first[i] + a.tiles * a.ks;
+    g.ffirst[i + 1] = g.ffirst[i] + a.tiles;
+    off += (int64_t)a.ks * a.tiles * 1024;
+  }
+  *ws_total = off;
+  return 0;
+}
+
+extern "C" int64_t p2c_atb_group_workspace_floats(const p2c_atb_problem *p, int32_t n) {
+  p2c_atb_impl::Group g;
+  int64_t total = 0;
+  return group_fill(p, n, nullptr, g, &total) ? 0 : total;
+}
+
+extern "C" int p2c_atb_group(const p2c_atb_problem *p, int32_t n, float *workspace, void *stream) {
+  using namespace p2c_atb_impl;
+  if (!workspace) return P2C_E_NULL;
+  Group g;
+  int64_t total = 0;
+  int rc = group_fill(p, n, workspace, g, &total);
+  if (rc) return rc;
+  hipLaunchKernelGGL(atb_group_kernel, dim3((unsigned)g.first[n]), dim3(64 * WAVES), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(atb_group_finish_kernel, dim3((unsigned)g.ffirst[n]), dim3(256), 0, (hipStream_t)stream, g);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

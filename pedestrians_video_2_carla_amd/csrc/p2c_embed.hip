@@ -188,3 +188,142 @@ extern "C" int p2c_embed_bwd(const float *x, const float *gy, int64_t w_stride, 
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+
+// ---- folded input map (K7a'): embeddings composed with the encoder's first input projection -------------------------------
+// Seq2SeqEmbeddings with fold_embeddings: nothing non-linear sits between the per-joint Linear(C, E) and W_ih0 of the
+// encoder LSTM, so the train step runs the encoder on the raw keypoints through
+//     w_eff[g, j, c] = sum_e W_ih0[g, jE + e] W_j[e, c]          b_eff[g] = b_ih0[g] + b_hh0[g] + sum_{j,e} W_ih0[g, jE + e] b_j[e]
+// As framework ops that is 2 broadcast products + 2 reductions + 2 adds forward and 11 launches backward, each 4-15 us
+// for 0.85 MFLOP. Here: one launch each way, fixed summation orders (bitwise reproducible).
+namespace p2c_fold {
+
+constexpr int MAXC = 4;
+
+struct Args {
+  const float *w_ih;            // (G, J*E)
+  const float *W, *b;           // joint j: W + j * w_stride (E, C), b + j * b_stride (E)
+  const float *b_ih, *b_hh;     // (G) or NULL
+  float *w_eff, *b_eff;         // (G, J*C), (G)
+  const float *g_eff, *g_b;     // gradients of the two outputs
+  float *g_w_ih;                // (G, J*E): written, or added to when acc_w
+  float *gW, *gb;               // strides of W / b: ADDED to
+  float *g_b_ih, *g_b_hh;       // (G) or NULL: ADDED to
+  int64_t w_stride, b_stride;
+  int32_t G, J, E, C, acc_w;
+};
+
+// one workgroup per gate row g: its J*E weights pass through LDS (coalesced), thread (j, c) forms one output
+__global__ __launch_bounds__(256) void fold_fwd_kernel(const Args a) {
+  extern __shared__ float row[];                  // [J*E] + [J] partial bias sums
+  const int g = blockIdx.x, JE = a.J * a.E;
+  for (int i = threadIdx.x; i < JE; i += blockDim.x) row[i] = a.w_ih[(size_t)g * JE + i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < a.J * a.C; i += blockDim.x) {
+    const int j = i / a.C, c = i - j * a.C;
+    const float *w = a.W + j * a.w_stride + c, *r = row + j * a.E;
+    float s = 0.f;
+    for (int e = 0; e < a.E; ++e) s = fmaf(r[e], w[(size_t)e * a.C], s);
+    a.w_eff[(size_t)g * a.J * a.C + i] = s;
+  }
+  float *pb = row + JE;
+  for (int j = threadIdx.x; j < a.J; j += blockDim.x) {
+    const float *bj = a.b + j * a.b_stride, *r = row + j * a.E;
+    float s = 0.f;
+    for (int e = 0; e < a.E; ++e) s = fmaf(r[e], bj[e], s);
+    pb[j] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int j = 0; j < a.J; ++j) s += pb[j];
+    if (a.b_ih) s += a.b_ih[g];
+    if (a.b_hh) s += a.b_hh[g];
+    a.b_eff[g] = s;
+  }
+}
+
+// one workgroup per joint j, thread (e, quarter of the G rows): the joint's slice of d W_ih0 is written row by row while
+// the sums over g for d W_j / d b_j run in registers; the four quarters meet in LDS in a fixed order
+__global__ __launch_bounds__(256) void fold_bwd_kernel(const Args a) {
+  __shared__ float part[4][64][MAXC + 1];
+  const int j = blockIdx.x, JE = a.J * a.E, JC = a.J * a.C;
+  const int qg = threadIdx.x >> 6;
+  const int gq = (a.G + 3) / 4, g0 = qg * gq, g1 = (g0 + gq < a.G) ? g0 + gq : a.G;
+  for (int e0 = 0; e0 < a.E; e0 += 64) {
+    const int e = e0 + (threadIdx.x & 63);
+    const bool ok = e < a.E;
+    float wj[MAXC], acc[MAXC + 1];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) wj[c] = (ok && c < a.C) ? a.W[j * a.w_stride + (size_t)e * a.C + c] : 0.f, acc[c] = 0.f;
+    acc[MAXC] = 0.f;
+    const float bj = ok ? a.b[j * a.b_stride + e] : 0.f;
+    if (ok)
+      for (int g = g0; g < g1; ++g) {
+        const size_t iw = (size_t)g * JE + j * a.E + e;
+        const float w = a.w_ih[iw], gbv = a.g_b[g];
+        float s = gbv * bj;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < a.C) {
+            const float ge = a.g_eff[(size_t)g * JC + j * a.C + c];
+            s = fmaf(ge, wj[c], s);
+            acc[c] = fmaf(ge, w, acc[c]);
+          }
+        acc[MAXC] = fmaf(gbv, w, acc[MAXC]);
+        a.g_w_ih[iw] = a.acc_w ? a.g_w_ih[iw] + s : s;
+      }
+    __syncthreads();                               // (previous round's readers are done)
+#pragma unroll
+    for (int c = 0; c <= MAXC; ++c) part[qg][threadIdx.x & 63][c] = acc[c];
+    __syncthreads();
+    if (qg == 0 && ok) {
+      const int l = threadIdx.x & 63;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < a.C) a.gW[j * a.w_stride + (size_t)e * a.C + c] += (part[0][l][c] + part[1][l][c]) + (part[2][l][c] + part[3][l][c]);
+      a.gb[j * a.b_stride + e] += (part[0][l][MAXC] + part[1][l][MAXC]) + (part[2][l][MAXC] + part[3][l][MAXC]);
+    }
+  }
+  if (j == 0)
+    for (int g = threadIdx.x; g < a.G; g += blockDim.x) {
+      if (a.g_b_ih) a.g_b_ih[g] += a.g_b[g];
+      if (a.g_b_hh) a.g_b_hh[g] += a.g_b[g];
+    }
+}
+
+static int check(int32_t G, int32_t J, int32_t E, int32_t C) {
+  if (G < 0 || J < 1 || E < 1 || C < 1 || C > MAXC) return P2C_E_SHAPE;
+  if ((size_t)(J * E + J) * sizeof(float) > 60 * 1024) return P2C_E_SHAPE;
+  return 0;
+}
+
+}  // namespace p2c_fold
+
+extern "C" int p2c_fold_fwd(const float *w_ih, const float *W, const float *b, int64_t w_stride, int64_t b_stride,
+                            const float *b_ih, const float *b_hh, float *w_eff, float *b_eff, int32_t G, int32_t J, int32_t E,
+                            int32_t C, void *stream) {
+  if (!w_ih || !W || !b || !w_eff || !b_eff) return P2C_E_NULL;
+  int rc = p2c_fold::check(G, J, E, C);
+  if (rc) return rc;
+  if (G == 0) return 0;
+  p2c_fold::Args a{};
+  a.w_ih = w_ih, a.W = W, a.b = b, a.b_ih = b_ih, a.b_hh = b_hh, a.w_eff = w_eff, a.b_eff = b_eff;
+  a.w_stride = w_stride, a.b_stride = b_stride, a.G = G, a.J = J, a.E = E, a.C = C;
+  hipLaunchKernelGGL(p2c_fold::fold_fwd_kernel, dim3((unsigned)G), dim3(256), (size_t)(J * E + J) * sizeof(float), (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int p2c_fold_bwd(const float *w_ih, const float *W, const float *b, int64_t w_stride, int64_t b_stride,
+                            const float *g_eff, const float *g_b, float *g_w_ih, int32_t accumulate_w, float *gW, float *gb,
+                            float *g_b_ih, float *g_b_hh, int32_t G, int32_t J, int32_t E, int32_t C, void *stream) {
+  if (!w_ih || !W || !b || !g_eff || !g_b || !g_w_ih || !gW || !gb) return P2C_E_NULL;
+  int rc = p2c_fold::check(G, J, E, C);
+  if (rc) return rc;
+  p2c_fold::Args a{};
+  a.w_ih = w_ih, a.W = W, a.b = b, a.g_eff = g_eff, a.g_b = g_b, a.g_w_ih = g_w_ih, a.acc_w = accumulate_w, a.gW = gW, a.gb = gb;
+  a.g_b_ih = g_b_ih, a.g_b_hh = g_b_hh, a.w_stride = w_stride, a.b_stride = b_stride, a.G = G, a.J = J, a.E = E, a.C = C;
+  hipLaunchKernelGGL(p2c_fold::fold_bwd_kernel, dim3((unsigned)J), dim3(256), 0, (hipStream_t)stream, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

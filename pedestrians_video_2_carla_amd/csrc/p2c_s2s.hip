@@ -39,8 +39,19 @@ struct Args {
   const float *g_out;                    // (T,B,O)
   float *g_gates0, *g_gates1, *g_outtot; // (T,B,4H) x2, (T,B,O)
   float *g_c0, *g_c1;                    // (B,H) x2
-  int32_t T, B, O;
+  // frame-invariant terms formed by the kernels themselves (hid0 != NULL): k_l = ba_l + bb_l + hid_l W_hh_l^T
+  const float *hid0, *hid1, *w_hh0, *w_hh1, *b0a, *b0b, *b1a, *b1b;
+  float *kw0, *kw1;                      // (B,4H) scratch for k_l (16-clip tiling only)
+  float *out_bt;                         // (B,T,O) second copy of out in the model's output layout, or NULL
+  float *g_k0, *g_k1, *g_hid0, *g_hid1;  // (B,4H) = sum_t d gates_l, (B,H) = g_k_l W_hh_l; or NULL
+  int32_t T, B, O, g_out_bt;             // g_out_bt: g_out is laid out (B,T,O)
 };
+
+// rows of step t of a (B,T,O) tensor: lane offset (b T O + o) * 4, b >= B out of range by construction
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bt_rows(const float *base, int t, int B, int T, int O) {
+  const uintptr_t p = reinterpret_cast<uintptr_t>(base) + (size_t)t * O * 4;
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p), 0, base ? ((B - 1) * T + 1) * O * 4 : 0, 0x00020000);
+}
 
 __device__ __forceinline__ f32x4 load4(const float *p, bool ok) {
   return ok ? *reinterpret_cast<const f32x4 *>(p) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -136,11 +147,12 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
   }
   const f32x4 c0r = load4(a.c0 + (size_t)b * H + u0, ok), c1r = load4(a.c1 + (size_t)b * H + u0, ok);
   f32x4 bfc;
-  int offo[4];                                       // byte offsets of this lane's four output features (OOB beyond O)
+  int offo[4], offb[4];                              // byte offsets of this lane's four output features (OOB beyond O)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     bfc[r] = (u0 + r < O) ? a.b_fc[u0 + r] : 0.f;
     offo[r] = (u0 + r < O) ? (b * O + u0 + r) * 4 : OOB;
+    offb[r] = (u0 + r < O) ? (b * T * O + u0 + r) * 4 : OOB;
   }
   {   // x_0 (rows >= O stay zero: they only ever meet zero weight fragments)
 #pragma unroll
@@ -195,11 +207,12 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
       o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ffc[ks + 1], h1T[(4 * ks + 4 + g) * TP + c], o2, 0, 0, 0);
     }
     o += o2;
-    const __amdgpu_buffer_rsrc_t ro = step_rows(a.out, t, B, O);
+    const __amdgpu_buffer_rsrc_t ro = step_rows(a.out, t, B, O), rb = bt_rows(a.out_bt, t, B, T, O);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       xT[(u0 + r) * TP + c] = o[r];                // next step's input (features >= O are exactly zero)
       bstore1(ro, offo[r], o[r]);
+      bstore1(rb, offb[r], o[r]);
     }
     lds_barrier();
   }
@@ -235,9 +248,12 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
 
   const f32x4 c0r = load4(a.c0 + (size_t)b * H + u0, ok), c1r = load4(a.c1 + (size_t)b * H + u0, ok);
   f32x4 dc0 = zero4(), dc1 = zero4(), dx = zero4();
-  int offo[4];
+  int offo[4], offi[4];                              // d out_total rows (T,B,O); g_out rows in the layout the caller has
 #pragma unroll
-  for (int r = 0; r < 4; ++r) offo[r] = (u0 + r < O) ? (b * O + u0 + r) * 4 : OOB;
+  for (int r = 0; r < 4; ++r) {
+    offo[r] = (u0 + r < O) ? (b * O + u0 + r) * 4 : OOB;
+    offi[r] = (u0 + r < O) ? ((a.g_out_bt ? b * T * O : b * O) + u0 + r) * 4 : OOB;
+  }
   const bool has_drop = a.drop != nullptr;
 
   // The rows a step reads (loss gradient, saved gates of both layers, dropout mask) are requested at the top of the previous
@@ -245,9 +261,10 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
   // requested at their use, each of the three groups would put that round trip on the critical path of the step.
   struct Saved { f32x4 go, a1[4], a0[4], m; };
   auto fetch = [&](int t, Saved &s) {
-    const __amdgpu_buffer_rsrc_t rg = step_rows(a.g_out, t, B, O), r1 = step_rows(a.acts1, t, B, G4), r0 = step_rows(a.acts0, t, B, G4);
+    const __amdgpu_buffer_rsrc_t rg = a.g_out_bt ? bt_rows(a.g_out, t, B, T, O) : step_rows(a.g_out, t, B, O);
+    const __amdgpu_buffer_rsrc_t r1 = step_rows(a.acts1, t, B, G4), r0 = step_rows(a.acts0, t, B, G4);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s.go[r] = bload1(rg, offo[r]);
+    for (int r = 0; r < 4; ++r) s.go[r] = bload1(rg, offi[r]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) s.a1[q] = bload4(r1, off4 + q * H * 4), s.a0[q] = bload4(r0, off4 + q * H * 4);
     s.m = bload4(step_rows(a.drop, t, B, H), off1);
@@ -394,6 +411,32 @@ __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
   const bool ok = b < a.B;
   const int O = a.O, B = a.B, T = a.T;
   const int offg = (b * G4 + u) * 4, offh = (b * H + u) * 4, offo = (u < O) ? (b * O + u) * 4 : OOB;
+  const int offb = (u < O) ? (b * a.T * O + u) * 4 : OOB;
+
+  f32x4 k0r, k1r;
+  if (a.hid0) {   // k_l = ba_l + bb_l + hid_l W_hh_l^T: two gate products over K = H before the loop's fragments are loaded
+    float tmp[H];
+    h0s[s][u] = ok ? a.hid0[(size_t)b * H + u] : 0.f, h1s[s][u] = ok ? a.hid1[(size_t)b * H + u] : 0.f;
+    stage(a.w_hh0, G4, H, img);
+#pragma unroll
+    for (int k = 0; k < H; ++k) tmp[k] = img[(s * H + u) * (H + 1) + k];
+    f32x4 init;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) init[j] = (a.b0a ? a.b0a[j * H + u] : 0.f) + (a.b0b ? a.b0b[j * H + u] : 0.f);
+    k0r = block_product<H>(tmp, h0s[s], init);
+    stage(a.w_hh1, G4, H, img);
+#pragma unroll
+    for (int k = 0; k < H; ++k) tmp[k] = img[(s * H + u) * (H + 1) + k];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) init[j] = (a.b1a ? a.b1a[j * H + u] : 0.f) + (a.b1b ? a.b1b[j * H + u] : 0.f);
+    k1r = block_product<H>(tmp, h1s[s], init);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      k0r[j] = ok ? a.k0[(size_t)b * G4 + j * H + u] : 0.f;
+      k1r[j] = ok ? a.k1[(size_t)b * G4 + j * H + u] : 0.f;
+    }
+  }
 
   float fa0[K0], fa1[H], ffc[16];
   stage(a.w_ih0, G4, O, img);                       // gate products: row (lane & 3) = gate of block = unit u
@@ -407,12 +450,6 @@ __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
     const int f = w * 16 + 4 * (blk >> 2) + s;
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) ffc[kk] = (f < O) ? img[f * (H + 1) + q * 16 + kk] : 0.f;
-  }
-  f32x4 k0r, k1r;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    k0r[j] = ok ? a.k0[(size_t)b * G4 + j * H + u] : 0.f;
-    k1r[j] = ok ? a.k1[(size_t)b * G4 + j * H + u] : 0.f;
   }
   const float c0r = ok ? a.c0[(size_t)b * H + u] : 0.f, c1r = ok ? a.c1[(size_t)b * H + u] : 0.f;
   const float bfc = (u < O) ? a.b_fc[u] : 0.f;
@@ -445,6 +482,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
     const float o = quarter_product<16>(ffc, h1s[s] + q * 16, q) + bfc;
     xs[s][u] = o;                                    // next step's input (features >= O are exactly zero)
     bstore1(step_rows(a.out, t, B, O), offo, o);
+    bstore1(bt_rows(a.out_bt, t, B, T, O), offb, o);
     lds_barrier();
   }
 }
@@ -461,6 +499,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
   const bool ok = b < a.B;
   const int O = a.O, B = a.B, T = a.T;
   const int offg = (b * G4 + u) * 4, offh = (b * H + u) * 4, offo = (u < O) ? (b * O + u) * 4 : OOB;
+  const int offi = (u < O) ? ((a.g_out_bt ? b * a.T * O : b * O) + u) * 4 : OOB;
 
   float ffcT[16], f1T[H], f0T[H];
   stage(a.w_fc, O, H, img);                          // dh1 = W_fc^T dout: rows = units, K quarter q = features 16 q .. 16 q + 15
@@ -475,11 +514,12 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
 
   const float c0r = ok ? a.c0[(size_t)b * H + u] : 0.f, c1r = ok ? a.c1[(size_t)b * H + u] : 0.f;
   float dc0 = 0.f, dc1 = 0.f, dx = 0.f;
+  f32x4 dk0 = zero4(), dk1 = zero4();                // sum_t d gates_l = the gradient of k_l
   const bool has_drop = a.drop != nullptr;
 
   struct Saved { f32x4 a1, a0; float go, m; };
   auto fetch = [&](int t, Saved &sv) {
-    sv.go = bload1(step_rows(a.g_out, t, B, O), offo);
+    sv.go = bload1(a.g_out_bt ? bt_rows(a.g_out, t, B, T, O) : step_rows(a.g_out, t, B, O), offi);
     sv.a1 = load_gates1(step_rows(a.acts1, t, B, G4), offg);
     sv.a0 = load_gates1(step_rows(a.acts0, t, B, G4), offg);
     sv.m = bload1(step_rows(a.drop, t, B, H), offh);
@@ -504,6 +544,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
     // ---- fc backward, layer-1 cell
     float dh = quarter_product<16>(ffcT, dos[s] + q * 16, q);
     f32x4 p = cell_bwd1(dh, sv.a1, c1r, dc1);
+    dk1 += p;
     dg1s[s][u] = p[0], dg1s[s][HP + u] = p[1], dg1s[s][2 * HP + u] = p[2], dg1s[s][3 * HP + u] = p[3];
     store_gates1(step_rows(a.g_gates1, t, B, G4), offg, p);
     lds_barrier();
@@ -511,6 +552,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
     dh = quarter_product<H>(f1T, dg1s[s] + q * HP, q);
     if (has_drop) dh *= sv.m;
     p = cell_bwd1(dh, sv.a0, c0r, dc0);
+    dk0 += p;
     dg0s[s][u] = p[0], dg0s[s][HP + u] = p[1], dg0s[s][2 * HP + u] = p[2], dg0s[s][3 * HP + u] = p[3];
     store_gates1(step_rows(a.g_gates0, t, B, G4), offg, p);
     lds_barrier();
@@ -521,7 +563,53 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
   if (ok) {
     a.g_c0[(size_t)b * H + u] = dc0;
     a.g_c1[(size_t)b * H + u] = dc1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (a.g_k0) a.g_k0[(size_t)b * G4 + j * H + u] = dk0[j];
+      if (a.g_k1) a.g_k1[(size_t)b * G4 + j * H + u] = dk1[j];
+    }
   }
+  if (a.g_hid0) {   // d hid_l = g_k_l W_hh_l: the transposed (K-quarter) product once more, on the summed d gates
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dg0s[s][j * HP + u] = dk0[j], dg1s[s][j * HP + u] = dk1[j];
+    stage(a.w_hh0, G4, H, img);
+#pragma unroll
+    for (int k = 0; k < H; ++k) f1T[k] = img[(q * H + k) * (H + 1) + ra_];
+    const float gh0 = quarter_product<H>(f1T, dg0s[s] + q * HP, q);
+    stage(a.w_hh1, G4, H, img);
+#pragma unroll
+    for (int k = 0; k < H; ++k) f1T[k] = img[(q * H + k) * (H + 1) + ra_];
+    const float gh1 = quarter_product<H>(f1T, dg1s[s] + q * HP, q);
+    if (ok) a.g_hid0[(size_t)b * H + u] = gh0, a.g_hid1[(size_t)b * H + u] = gh1;
+  }
+}
+
+// ---- helpers of the 16-clip tiling for the in-library k_l / d k_l / d hid_l (B > 4096: three more launches are noise there)
+__global__ void decoder_k_kernel(const float *hid, const float *w_hh, const float *ba, const float *bb, float *k, int B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * G4) return;
+  const int64_t b = i / G4;
+  const int row = (int)(i - b * G4);
+  float s = (ba ? ba[row] : 0.f) + (bb ? bb[row] : 0.f);
+  for (int kk = 0; kk < H; ++kk) s = fmaf(hid[b * H + kk], w_hh[row * H + kk], s);
+  k[i] = s;
+}
+__global__ void decoder_gk_kernel(const float *gg, float *gk, int T, int B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, n = (int64_t)B * G4;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += gg[(int64_t)t * n + i];
+  gk[i] = s;
+}
+__global__ void decoder_ghid_kernel(const float *gk, const float *w_hh, float *ghid, int B) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * H) return;
+  const int64_t b = i / H;
+  const int u = (int)(i - b * H);
+  float s = 0.f;
+  for (int row = 0; row < G4; ++row) s = fmaf(gk[b * G4 + row], w_hh[row * H + u], s);
+  ghid[i] = s;
 }
 
 }  // namespace p2c_s2s
@@ -529,13 +617,19 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
 using namespace p2c_s2s;
 
 static int fill(Args &a, const p2c_decoder_desc *d) {
-  if (!d || !d->k0 || !d->c0 || !d->k1 || !d->c1 || !d->w_ih0 || !d->w_ih1 || !d->w_fc || !d->b_fc) return P2C_E_NULL;
+  if (!d || !d->c0 || !d->c1 || !d->w_ih0 || !d->w_ih1 || !d->w_fc || !d->b_fc) return P2C_E_NULL;
+  if (d->hid0 ? (!d->hid1 || !d->w_hh0 || !d->w_hh1) : (!d->k0 || !d->k1)) return P2C_E_NULL;
+  if ((d->g_hid0 || d->g_hid1) && (!d->g_hid0 || !d->g_hid1 || !d->w_hh0 || !d->w_hh1)) return P2C_E_NULL;
   if (d->T < 0 || d->B < 0 || d->B > (1 << 20) || d->H != H || d->O < 1 || d->O > OMAX) return P2C_E_SHAPE;
+  if ((d->out_bt || d->g_out_bt) && (int64_t)d->B * d->T * d->O * 4 >= (int64_t)1 << 31) return P2C_E_SHAPE;
   a = Args{};
   a.k0 = d->k0, a.c0 = d->c0, a.k1 = d->k1, a.c1 = d->c1, a.w_ih0 = d->w_ih0, a.w_ih1 = d->w_ih1, a.w_fc = d->w_fc;
   a.b_fc = d->b_fc, a.x0 = d->x0, a.drop = d->drop, a.out = d->out, a.acts0 = d->acts0, a.acts1 = d->acts1, a.h0d = d->h0d;
   a.h1 = d->h1, a.g_out = d->g_out, a.g_gates0 = d->g_gates0, a.g_gates1 = d->g_gates1, a.g_outtot = d->g_outtot;
   a.g_c0 = d->g_c0, a.g_c1 = d->g_c1, a.T = d->T, a.B = d->B, a.O = d->O;
+  a.hid0 = d->hid0, a.hid1 = d->hid1, a.w_hh0 = d->w_hh0, a.w_hh1 = d->w_hh1, a.b0a = d->b0a, a.b0b = d->b0b, a.b1a = d->b1a;
+  a.b1b = d->b1b, a.kw0 = d->kw0, a.kw1 = d->kw1, a.out_bt = d->out_bt, a.g_k0 = d->g_k0, a.g_k1 = d->g_k1;
+  a.g_hid0 = d->g_hid0, a.g_hid1 = d->g_hid1, a.g_out_bt = d->g_out_bt;
   return 0;
 }
 
@@ -574,6 +668,13 @@ extern "C" int p2c_decoder_fwd(const p2c_decoder_desc *d, void *stream) {
     if (a.O <= 52) hipLaunchKernelGGL(decoder_fwd_narrow_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(decoder_fwd_narrow_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
   } else {
+    if (a.hid0) {                                  // k_l through two helper launches into the caller's scratch
+      if (!a.kw0 || !a.kw1) return P2C_E_NULL;
+      const unsigned nb = (unsigned)(((int64_t)a.B * G4 + 255) / 256);
+      hipLaunchKernelGGL(decoder_k_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a.hid0, a.w_hh0, a.b0a, a.b0b, a.kw0, a.B);
+      hipLaunchKernelGGL(decoder_k_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, a.hid1, a.w_hh1, a.b1a, a.b1b, a.kw1, a.B);
+      a.k0 = a.kw0, a.k1 = a.kw1;
+    }
     const dim3 grid((unsigned)((a.B + TS - 1) / TS));
     if (a.O <= 52) hipLaunchKernelGGL(decoder_fwd_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(decoder_fwd_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
@@ -597,6 +698,14 @@ extern "C" int p2c_decoder_bwd(const p2c_decoder_desc *d, void *stream) {
     const dim3 grid((unsigned)((a.B + TS - 1) / TS));
     if (a.O <= 52) hipLaunchKernelGGL(decoder_bwd_kernel<13>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
     else hipLaunchKernelGGL(decoder_bwd_kernel<16>, grid, dim3(256), image_bytes(), (hipStream_t)stream, a);
+    if (a.g_hid0 && (!a.g_k0 || !a.g_k1)) return P2C_E_NULL;      // (d hid_l is formed from the stored d k_l here)
+    const unsigned nk = (unsigned)(((int64_t)a.B * G4 + 255) / 256), nh = (unsigned)(((int64_t)a.B * H + 255) / 256);
+    if (a.g_k0) hipLaunchKernelGGL(decoder_gk_kernel, dim3(nk), dim3(256), 0, (hipStream_t)stream, a.g_gates0, a.g_k0, a.T, a.B);
+    if (a.g_k1) hipLaunchKernelGGL(decoder_gk_kernel, dim3(nk), dim3(256), 0, (hipStream_t)stream, a.g_gates1, a.g_k1, a.T, a.B);
+    if (a.g_hid0) {
+      hipLaunchKernelGGL(decoder_ghid_kernel, dim3(nh), dim3(256), 0, (hipStream_t)stream, a.g_k0, a.w_hh0, a.g_hid0, a.B);
+      hipLaunchKernelGGL(decoder_ghid_kernel, dim3(nh), dim3(256), 0, (hipStream_t)stream, a.g_k1, a.w_hh1, a.g_hid1, a.B);
+    }
   }
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

@@ -158,7 +158,7 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         needs_forcing, forced, force_idx = self._teacher_forcing(targets)
         if not needs_forcing and type(self)._decode_frame is Seq2Seq._decode_frame and self._decoder_loop_fusable(x):
             # K7c: the T decoder steps (frozen encoder state, output fed back) are ONE HIP launch
-            return self._format_output(original_shape, self._fused_decoder(hidden, cell, clip_length))
+            return self._format_output(original_shape, self._fused_decoder(hidden, cell, clip_length), batch_first=True)
         step_in = torch.zeros((batch_size, self.decoder.output_size), device=x.device, dtype=x.dtype)     # <sos>
         outputs = []
         for t in range(clip_length):
@@ -193,20 +193,19 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
     def _fused_decoder(self, hidden: Tensor, cell: Tensor, clip_length: int) -> Tensor:
         from pedestrians_video_2_carla_amd import ops
         rnn, fc = self.decoder.rnn, self.decoder.fc_out
-        lin = torch.nn.functional.linear
-        # the decoder state is the encoder's for every frame: its recurrent terms are per-clip constants
-        k0 = lin(hidden[0], rnn.weight_hh_l0, rnn.bias_ih_l0 + rnn.bias_hh_l0)
-        k1 = lin(hidden[1], rnn.weight_hh_l1, rnn.bias_ih_l1 + rnn.bias_hh_l1)
+        # (the decoder state is the encoder's for every frame: its recurrent terms k_l = b_ih_l + b_hh_l + W_hh_l hidden_l are
+        # per-clip constants, formed inside the launch)
         drop = None
         if rnn.dropout > 0 and rnn.training:      # nn.LSTM's inter-layer dropout, one mask tensor for all frames
             keep = 1.0 - rnn.dropout
             drop = torch.empty(clip_length, hidden.shape[1], rnn.hidden_size, device=hidden.device,
                                dtype=hidden.dtype).bernoulli_(keep).div_(keep)
-        return ops.decoder_loop(k0, cell[0].contiguous(), k1, cell[1].contiguous(), rnn.weight_ih_l0, rnn.weight_ih_l1,
-                                fc.weight, fc.bias, clip_length, drop)
+        return ops.decoder_stack(hidden, cell, rnn, fc, clip_length, drop)            # (B,T,O)
 
-    def _format_output(self, original_shape, outputs):
-        outputs = outputs.permute(1, 0, 2).reshape(*original_shape[:2], len(self.output_nodes), self.output_features)
+    def _format_output(self, original_shape, outputs, batch_first: bool = False):
+        if not batch_first:
+            outputs = outputs.permute(1, 0, 2)
+        outputs = outputs.reshape(*original_shape[:2], len(self.output_nodes), self.output_features)
         return super()._format_output(outputs)
 
     def _format_input(self, x: Tensor) -> Tensor:

@@ -35,33 +35,51 @@ def _block_view(tensors):
 
 
 class _FoldedInputMap(torch.autograd.Function):
-    """(w_eff (G, J*C), b_fold (G)) = (W_ih0 restricted to joint j) @ (W_j | b_j) for all joints, with the embedding
-    parameters and their gradients addressed as ONE strided block each: the backward adds dW / db into the gradient block
-    (two launches) instead of 52 per-parameter accumulations behind a 52-way ``torch.stack``. Contractions are written as
-    broadcast-multiply + sum: the library's batched GEMM for 26 x (256x64x2) takes ~19 us per call."""
+    """(w_eff (G, J*C), b_eff (G)) = W_ih0 composed with the J embeddings, plus the two LSTM biases -- ``p2c_fold_fwd`` /
+    ``p2c_fold_bwd`` (K7a'), one launch each way, with the embedding parameters and their gradients addressed as ONE strided
+    block each (views of the trainer's flat buffers). The backward adds dW_j / db_j into the gradient block and, inside the
+    trainer's ``grad_sinks`` context, d W_ih0 and the two bias gradients straight into their ``.grad``. (As framework ops the
+    same map is 6 launches forward and 11 backward of 4-15 us each.)"""
 
     @staticmethod
-    def forward(ctx, w_ih, anchor, W, b, gW, gb):
+    def forward(ctx, w_ih, b_ih, b_hh, anchor, W, b, gW, gb):
+        import ctypes
+        from pedestrians_video_2_carla_amd import _lib, ops
         G = w_ih.shape[0]
         J, E, C = W.shape
-        w3 = w_ih.view(G, J, E)
-        w_eff = (w3.unsqueeze(-1) * W.unsqueeze(0)).sum(2)                  # (G,J,C)
-        b_fold = (w3 * b.unsqueeze(0)).sum((1, 2))                           # (G)
-        ctx.save_for_backward(w_ih)
+        if W.stride(1) != C or W.stride(2) != 1 or b.stride(1) != 1 or gW.stride() != W.stride() or gb.stride() != b.stride():
+            raise RuntimeError('folded input map: the embedding blocks must be (J, E, C) / (J, E) views with dense rows')
+        w_ih, b_ih, b_hh = (ops._require_device(t, n) for t, n in ((w_ih, 'weight_ih_l0'), (b_ih, 'bias_ih_l0'), (b_hh, 'bias_hh_l0')))
+        w_eff = torch.empty(G, J * C, dtype=torch.float32, device=w_ih.device)
+        b_eff = torch.empty(G, dtype=torch.float32, device=w_ih.device)
+        with torch.cuda.device(w_ih.device):
+            _lib.check(_lib.lib().p2c_fold_fwd(w_ih.data_ptr(), W.data_ptr(), b.data_ptr(), W.stride(0), b.stride(0),
+                                                b_ih.data_ptr(), b_hh.data_ptr(), w_eff.data_ptr(), b_eff.data_ptr(),
+                                                G, J, E, C, ops._stream()), 'p2c_fold_fwd')
+        ctx.save_for_backward(w_ih, b_ih, b_hh)
         ctx.blocks = (W, b, gW, gb)
-        return w_eff.reshape(G, J * C), b_fold
+        return w_eff, b_eff
 
     @staticmethod
     def backward(ctx, g_eff, g_b):
-        (w_ih,) = ctx.saved_tensors
+        from pedestrians_video_2_carla_amd import _lib, ops
+        w_ih, b_ih, b_hh = ctx.saved_tensors
         W, b, gW, gb = ctx.blocks
         G = w_ih.shape[0]
         J, E, C = W.shape
-        w3, g3 = w_ih.view(G, J, E), g_eff.reshape(G, J, 1, C)
-        g_w = (g3 * W.unsqueeze(0)).sum(-1) + g_b.view(G, 1, 1) * b.unsqueeze(0)          # (G,J,E)
-        gW.add_((g3 * w3.unsqueeze(-1)).sum(0))                                           # (J,E,C)
-        gb.add_((g_b.view(G, 1, 1) * w3).sum(0))                                          # (J,E)
-        return g_w.reshape(G, J * E), None, None, None, None, None
+        g_eff = torch.zeros(G, J * C, dtype=torch.float32, device=w_ih.device) if g_eff is None else ops._require_device(g_eff, 'grad w_eff')
+        g_b = torch.zeros(G, dtype=torch.float32, device=w_ih.device) if g_b is None else ops._require_device(g_b, 'grad b_eff')
+        sw, si, sh = ops._sink(w_ih), ops._sink(b_ih), ops._sink(b_hh)
+        if sw is not None and not sw.is_contiguous():
+            sw = None
+        g_w = sw if sw is not None else torch.empty_like(w_ih)
+        with torch.cuda.device(w_ih.device):
+            _lib.check(_lib.lib().p2c_fold_bwd(w_ih.data_ptr(), W.data_ptr(), b.data_ptr(), W.stride(0), b.stride(0),
+                                                g_eff.data_ptr(), g_b.data_ptr(), g_w.data_ptr(), int(sw is not None),
+                                                gW.data_ptr(), gb.data_ptr(), ops._ptr(si), ops._ptr(sh),
+                                                G, J, E, C, ops._stream()), 'p2c_fold_bwd')
+        return (None if sw is not None else g_w, None if si is not None else g_b, None if sh is not None else g_b,
+                None, None, None, None, None)
 
 
 class Seq2SeqEmbeddings(Seq2Seq):
@@ -94,13 +112,12 @@ class Seq2SeqEmbeddings(Seq2Seq):
         if self.grad_sink and torch.is_grad_enabled() and all(p.grad is not None for p in ws + bs):
             blocks = [_block_view(t) for t in (ws, bs, [p.grad for p in ws], [p.grad for p in bs])]
         if blocks is not None and all(v is not None for v in blocks):
-            w_eff, b_fold = _FoldedInputMap.apply(rnn.weight_ih_l0, ws[0], *blocks)
+            w_eff, b_eff = _FoldedInputMap.apply(rnn.weight_ih_l0, rnn.bias_ih_l0, rnn.bias_hh_l0, ws[0], *blocks)
         else:                                                                     # any parameter layout: autograd
             weight, bias = torch.stack(ws), torch.stack(bs)                       # (J, E, C), (J, E)
             w_ih = rnn.weight_ih_l0.view(G, J, E)
             w_eff = (w_ih.unsqueeze(-1) * weight.unsqueeze(0)).sum(2).reshape(G, J * weight.shape[-1])
-            b_fold = (w_ih * bias.unsqueeze(0)).sum((1, 2))
-        b_eff = b_fold + rnn.bias_ih_l0 + rnn.bias_hh_l0
+            b_eff = (w_ih * bias.unsqueeze(0)).sum((1, 2)) + rnn.bias_ih_l0 + rnn.bias_hh_l0
         seq = x.permute(1, 0, 2, 3).reshape(T, B, -1)                             # sequence first, raw keypoints
         if self.invert_sequence:
             seq = seq.flip(0)

@@ -937,7 +937,8 @@ class LSTMRecurrenceFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, h0, c0, w_hh):
         lib = _lib.lib()
-        gx, w_hh = _require_device(gx, 'gx'), _require_device(w_hh, 'weight_hh')
+        ctx.set_materialize_grads(False)                      # an unused output (out of the last layer, hT / cT) stays None:
+        gx, w_hh = _require_device(gx, 'gx'), _require_device(w_hh, 'weight_hh')   # the kernel reads nothing for it
         ctx.zero_state = h0 is None and c0 is None           # nn.LSTM's default initial state: nothing to read or to return
         T, B, G = gx.shape
         H = w_hh.shape[1]
@@ -1084,6 +1085,44 @@ def atb(a: Tensor, b: Tensor, bias: bool = False, out: Optional[Tensor] = None, 
     return out, (bias_out if bias else None)
 
 
+def atb_group(problems: Sequence[dict]) -> list:
+    """Up to 8 ``atb`` problems behind one launch pair (p2c_atb_group). Each problem: dict(a=(K,M), b=(K,N), out=None,
+    accumulate=False, bias=False, bias_out=None, bias_out2=None); returns [(out, bias_out), ...] like ``atb``. ``bias_out2``
+    receives the same column sums as ``bias_out`` (the two bias vectors of an LSTM layer)."""
+    lib = _lib.lib()
+    n = len(problems)
+    if n == 0:
+        return []
+    if n > 8:
+        return atb_group(problems[:8]) + atb_group(problems[8:])
+    arr = (_lib.AtbProblem * n)()
+    keep, results = [], []
+    for q, pr in zip(arr, problems):
+        a, b = (t if (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1) else _require_device(t, 'operand')
+                for t in (pr['a'], pr['b']))
+        K, M, N = a.shape[0], a.shape[1], b.shape[1]
+        if b.shape[0] != K:
+            raise RuntimeError('atb_group: row counts differ')
+        out, acc = pr.get('out'), bool(pr.get('accumulate', False))
+        if out is None:
+            out, acc = torch.empty(M, N, dtype=torch.float32, device=a.device), False
+        bias, bias_out, bias_out2 = bool(pr.get('bias', False)), pr.get('bias_out'), pr.get('bias_out2')
+        flags = (1 if acc else 0) | (2 if (acc and bias_out is not None) else 0)
+        if bias and bias_out is None:
+            bias_out = torch.empty(M, dtype=torch.float32, device=a.device)
+        q.a, q.a_stride, q.b, q.b_stride, q.K, q.M, q.N = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), K, M, N
+        q.out, q.out_stride, q.flags = out.data_ptr(), out.stride(0), flags
+        q.bias_out = _ptr(bias_out) if bias else None
+        q.bias_out2 = _ptr(bias_out2) if (bias and bias_out2 is not None) else None
+        keep.append((a, b, out, bias_out, bias_out2))
+        results.append((out, bias_out if bias else None))
+    dev = keep[0][0].device
+    ws = torch.empty(max(1, lib.p2c_atb_group_workspace_floats(arr, n)), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.p2c_atb_group(arr, n, ws.data_ptr(), _stream()), 'p2c_atb_group')
+    return results
+
+
 class DenseFunction(torch.autograd.Function):
     """y = x W^T + b over (rows, in) with the library GEMM forward and p2c_atb for the weight + bias gradient."""
 
@@ -1188,3 +1227,107 @@ def decoder_loop(k0: Tensor, c0: Tensor, k1: Tensor, c1: Tensor, w_ih0: Tensor, 
                  T: int, drop: Optional[Tensor] = None) -> Tensor:
     _prefer_rocblas_once()
     return DecoderLoopFunction.apply(k0, c0, k1, c1, w_ih0, w_ih1, w_fc, b_fc, drop, T)
+
+
+class DecoderStackFunction(torch.autograd.Function):
+    """The whole decoder of Seq2Seq for one clip batch, frame-invariant terms included: from the encoder state
+    (hidden, cell (2,B,H)) and the decoder parameters to the model output (B,T,O) in ONE launch, and back in one launch plus
+    one grouped weight-gradient launch pair. Compared with ``decoder_loop`` behind framework ops this drops, per step, the
+    two k_l GEMMs + bias adds forward and their five-launch backwards, the select / stack copies around the state tensors,
+    the two sum_t reductions and the two permute copies of the output and its gradient (cfg3: ~30 launches)."""
+
+    @staticmethod
+    def forward(ctx, hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc, drop, T: int):
+        lib = _lib.lib()
+        names = ('hidden', 'cell', 'weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l1', 'weight_hh_l1',
+                 'bias_ih_l1', 'bias_hh_l1', 'fc_out.weight', 'fc_out.bias')
+        hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc = (
+            _require_device(t, n) for t, n in zip((hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc), names))
+        drop = None if drop is None else _require_device(drop, 'dropout mask')
+        L, B, H = hidden.shape
+        O = w_fc.shape[0]
+        G = 4 * H
+        if L != 2 or cell.shape != hidden.shape or not decoder_loop_supported(H, 2, O) or w_ih0.shape != (G, O) \
+                or w_ih1.shape != (G, H) or w_hh0.shape != (G, H) or w_hh1.shape != (G, H) or w_fc.shape != (O, H):
+            raise RuntimeError('decoder stack: unsupported or inconsistent shapes')
+        f32 = dict(dtype=torch.float32, device=hidden.device)
+        out, out_bt = torch.empty(T, B, O, **f32), torch.empty(B, T, O, **f32)
+        acts0, acts1 = torch.empty(T, B, G, **f32), torch.empty(T, B, G, **f32)
+        h0d, h1 = torch.empty(T, B, H, **f32), torch.empty(T, B, H, **f32)
+        kw = torch.empty(2, B, G, **f32)                                 # scratch of the 16-clip tiling (B > 4096)
+        d = _lib.DecoderDesc()
+        d.T, d.B, d.H, d.O = T, B, H, O
+        d.hid0, d.hid1, d.c0, d.c1 = hidden[0].data_ptr(), hidden[1].data_ptr(), cell[0].data_ptr(), cell[1].data_ptr()
+        d.w_ih0, d.w_ih1, d.w_fc, d.b_fc = w_ih0.data_ptr(), w_ih1.data_ptr(), w_fc.data_ptr(), b_fc.data_ptr()
+        d.w_hh0, d.w_hh1, d.b0a, d.b0b, d.b1a, d.b1b = (t.data_ptr() for t in (w_hh0, w_hh1, b_ih0, b_hh0, b_ih1, b_hh1))
+        if kw is not None:
+            d.kw0, d.kw1 = kw[0].data_ptr(), kw[1].data_ptr()
+        d.drop = _ptr(drop)
+        d.out, d.out_bt, d.acts0, d.acts1, d.h0d, d.h1 = (t.data_ptr() for t in (out, out_bt, acts0, acts1, h0d, h1))
+        with torch.cuda.device(hidden.device):
+            _lib.check(lib.p2c_decoder_fwd(ctypes.byref(d), _stream()), 'p2c_decoder_fwd')
+        ctx.save_for_backward(hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc, drop,
+                              out, acts0, acts1, h0d, h1)
+        return out_bt
+
+    @staticmethod
+    def backward(ctx, g_out_bt):
+        lib = _lib.lib()
+        (hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc, drop,
+         out, acts0, acts1, h0d, h1) = ctx.saved_tensors
+        T, B, O = out.shape
+        H = hidden.shape[2]
+        G = 4 * H
+        g_out_bt = _require_device(g_out_bt, 'grad out')
+        f32 = dict(dtype=torch.float32, device=out.device)
+        gg0, gg1, gtot = torch.empty(T, B, G, **f32), torch.empty(T, B, G, **f32), torch.empty(T, B, O, **f32)
+        g_hidden, g_cell, g_k = torch.empty(2, B, H, **f32), torch.empty(2, B, H, **f32), torch.empty(2, B, G, **f32)
+        d = _lib.DecoderDesc()
+        d.T, d.B, d.H, d.O = T, B, H, O
+        d.hid0, d.hid1, d.c0, d.c1 = hidden[0].data_ptr(), hidden[1].data_ptr(), cell[0].data_ptr(), cell[1].data_ptr()
+        d.w_ih0, d.w_ih1, d.w_fc, d.b_fc = w_ih0.data_ptr(), w_ih1.data_ptr(), w_fc.data_ptr(), b_fc.data_ptr()
+        d.w_hh0, d.w_hh1 = w_hh0.data_ptr(), w_hh1.data_ptr()
+        d.drop = _ptr(drop)
+        d.acts0, d.acts1, d.h0d, d.h1 = acts0.data_ptr(), acts1.data_ptr(), h0d.data_ptr(), h1.data_ptr()
+        d.g_out, d.g_out_bt = g_out_bt.data_ptr(), 1
+        d.g_gates0, d.g_gates1, d.g_outtot = gg0.data_ptr(), gg1.data_ptr(), gtot.data_ptr()
+        d.g_c0, d.g_c1, d.g_hid0, d.g_hid1 = g_cell[0].data_ptr(), g_cell[1].data_ptr(), g_hidden[0].data_ptr(), g_hidden[1].data_ptr()
+        d.g_k0, d.g_k1 = g_k[0].data_ptr(), g_k[1].data_ptr()
+        with torch.cuda.device(out.device):
+            _lib.check(lib.p2c_decoder_bwd(ctypes.byref(d), _stream()), 'p2c_decoder_bwd')
+        # all weight / bias gradients: five contractions over rows, one grouped launch pair
+        sinks = {n: _sink(p) for n, p in (('w_ih0', w_ih0), ('w_hh0', w_hh0), ('b_ih0', b_ih0), ('b_hh0', b_hh0), ('w_ih1', w_ih1),
+                                          ('w_hh1', w_hh1), ('b_ih1', b_ih1), ('b_hh1', b_hh1), ('w_fc', w_fc), ('b_fc', b_fc))}
+        for group in (('w_hh0', 'b_ih0', 'b_hh0'), ('w_hh1', 'b_ih1', 'b_hh1'), ('w_fc', 'b_fc')):
+            if any(sinks[n] is None for n in group):        # a weight and its biases leave through one problem: all or none
+                for n in group:
+                    sinks[n] = None
+
+        def prob(a, b, w, bias=None, bias2=None, with_bias=False):
+            return dict(a=a, b=b, out=sinks[w], accumulate=sinks[w] is not None, bias=with_bias,
+                        bias_out=sinks[bias] if bias else None, bias_out2=sinks[bias2] if bias2 else None)
+        problems, order = [], []
+        if T > 1:                                            # x_0 = <sos> = 0: the first frame adds nothing to dW_ih0
+            problems.append(prob(gg0.view(T * B, G)[B:], out[:-1].reshape(-1, O), 'w_ih0')), order.append('w_ih0')
+        problems.append(prob(gg1.view(T * B, G), h0d.view(T * B, H), 'w_ih1')), order.append('w_ih1')
+        problems.append(prob(gtot.view(T * B, O), h1.view(T * B, H), 'w_fc', 'b_fc', None, True)), order.append('w_fc')
+        problems.append(prob(g_k[0], hidden[0], 'w_hh0', 'b_ih0', 'b_hh0', True)), order.append('w_hh0')
+        problems.append(prob(g_k[1], hidden[1], 'w_hh1', 'b_ih1', 'b_hh1', True)), order.append('w_hh1')
+        res = dict(zip(order, atb_group(problems)))
+        ret = {n: None for n in sinks}                       # what autograd still has to accumulate itself
+        for w, biases in (('w_ih0', ()), ('w_ih1', ()), ('w_fc', ('b_fc',)), ('w_hh0', ('b_ih0', 'b_hh0')), ('w_hh1', ('b_ih1', 'b_hh1'))):
+            if sinks[w] is None:
+                ret[w] = res[w][0] if w in res else torch.zeros_like(w_ih0)
+                for bn in biases:
+                    ret[bn] = res[w][1]
+        return (g_hidden, g_cell, ret['w_ih0'], ret['w_hh0'], ret['b_ih0'], ret['b_hh0'], ret['w_ih1'], ret['w_hh1'],
+                ret['b_ih1'], ret['b_hh1'], ret['w_fc'], ret['b_fc'], None, None)
+
+
+def decoder_stack(hidden: Tensor, cell: Tensor, rnn, fc, T: int, drop: Optional[Tensor] = None) -> Tensor:
+    """Seq2Seq's decoder (2-layer ``nn.LSTM`` ``rnn`` with biases + ``nn.Linear`` ``fc``) unrolled over T frames from the
+    encoder state; returns the frames batch-first, (B,T,O)."""
+    _prefer_rocblas_once()
+    return DecoderStackFunction.apply(hidden, cell, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0,
+                                      rnn.weight_ih_l1, rnn.weight_hh_l1, rnn.bias_ih_l1, rnn.bias_hh_l1, fc.weight, fc.bias,
+                                      drop, T)

@@ -127,6 +127,85 @@ def test_decoder_loop_matches_the_per_step_formula(T, B, O, with_drop):
         close(D[k].grad, R[k].grad, 'grad ' + k, rtol=2e-4)
 
 
+@pytest.mark.parametrize('T,B,O,with_drop,sinks', [(1, 1, 52, False, False), (16, 37, 52, True, True), (5, 16, 64, False, False),
+                                                    (16, 130, 12, True, False)])
+def test_decoder_stack_from_the_encoder_state(T, B, O, with_drop, sinks):
+    """The decoder in one launch each way WITH its frame-invariant terms (k_l = b_ih_l + b_hh_l + hidden_l W_hh_l^T formed in
+    the kernel, d k_l / d hidden_l in the backward, output and its gradient batch-first) against the per-frame formula of
+    the reference in fp64: output, d hidden, d cell and all ten parameter gradients -- returned to autograd, or added into
+    existing .grad tensors inside ``grad_sinks`` (the flat trainer's mode; they start from ones here)."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    H = 64
+    g = torch.Generator().manual_seed(T * 11 + B)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64) * 0.3
+    dec64 = torch.nn.LSTM(O, H, num_layers=2).double()
+    fc64 = torch.nn.Linear(H, O).double()
+    hidden64, cell64 = rnd(2, B, H).requires_grad_(True), rnd(2, B, H).requires_grad_(True)
+    drop = (torch.rand(T, B, H, generator=g) < 0.8).double() / 0.8 if with_drop else None
+    up = torch.randn(B, T, O, generator=g, dtype=torch.float64)
+
+    def cell(gates, c_enc):
+        i, f, gg, o = gates.chunk(4, -1)
+        return torch.sigmoid(o) * torch.tanh(torch.sigmoid(f) * c_enc + torch.sigmoid(i) * torch.tanh(gg))
+
+    k0 = hidden64[0] @ dec64.weight_hh_l0.t() + dec64.bias_ih_l0 + dec64.bias_hh_l0
+    k1 = hidden64[1] @ dec64.weight_hh_l1.t() + dec64.bias_ih_l1 + dec64.bias_hh_l1
+    x, outs = torch.zeros(B, O, dtype=torch.float64), []
+    for t in range(T):
+        h0 = cell(x @ dec64.weight_ih_l0.t() + k0, cell64[0])
+        if drop is not None:
+            h0 = h0 * drop[t]
+        h1 = cell(h0 @ dec64.weight_ih_l1.t() + k1, cell64[1])
+        x = fc64(h1)
+        outs.append(x)
+    ref = torch.stack(outs, 1)                                        # (B,T,O)
+    (ref * up).sum().backward()
+
+    dec = torch.nn.LSTM(O, H, num_layers=2).to(d)
+    fc = torch.nn.Linear(H, O).to(d)
+    dec.load_state_dict({k: v.float() for k, v in dec64.state_dict().items()})
+    fc.load_state_dict({k: v.float() for k, v in fc64.state_dict().items()})
+    params = list(dec.parameters()) + list(fc.parameters())
+    if sinks:
+        for p_ in params:
+            p_.grad = torch.ones_like(p_)
+    hidden, cellg = hidden64.detach().float().to(d).requires_grad_(True), cell64.detach().float().to(d).requires_grad_(True)
+    with ops.grad_sinks(sinks):
+        out = ops.decoder_stack(hidden, cellg, dec, fc, T, None if drop is None else drop.float().to(d))
+        (out * up.float().to(d)).sum().backward()
+    assert out.shape == (B, T, O)
+    close(out, ref, 'out')
+    close(hidden.grad, hidden64.grad, 'grad hidden', rtol=2e-4), close(cellg.grad, cell64.grad, 'grad cell', rtol=2e-4)
+    for (name, p_), q in zip(list(dec.named_parameters()) + list(fc.named_parameters()), list(dec64.parameters()) + list(fc64.parameters())):
+        want = q.grad + 1 if sinks else q.grad
+        close(p_.grad, want, 'grad ' + name, rtol=2e-4)
+
+
+def test_atb_group_equals_the_single_launches():
+    """p2c_atb_group: five problems of different shapes (strided rows, bias, second bias destination, accumulate) behind one
+    launch pair give bit for bit what p2c_atb gives one by one."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    torch.manual_seed(5)
+    shapes = [(8192 - 512, 256, 52), (8192, 256, 64), (8192, 52, 64), (512, 256, 64), (300, 7, 3)]
+    A = [torch.randn(K, M, device=d) for K, M, N in shapes]
+    Bm = [torch.randn(K, N + 3, device=d)[:, 1:1 + N] for K, M, N in shapes]
+    single = [ops.atb(a, b, bias=(i >= 2)) for i, (a, b) in enumerate(zip(A, Bm))]
+    acc0 = torch.randn(256, 52, device=d)
+    want0 = acc0.clone()
+    ops.atb(A[0], Bm[0], out=want0, accumulate=True)
+    got0, b3, b3b = acc0.clone(), torch.zeros(256, device=d), torch.zeros(256, device=d)
+    res = ops.atb_group([dict(a=A[0], b=Bm[0], out=got0, accumulate=True), dict(a=A[1], b=Bm[1]),
+                         dict(a=A[2], b=Bm[2], bias=True), dict(a=A[3], b=Bm[3], bias=True, bias_out=b3, bias_out2=b3b),
+                         dict(a=A[4], b=Bm[4], bias=True)])
+    assert torch.equal(got0, want0)
+    for i in (1, 2, 3, 4):
+        assert torch.equal(res[i][0], single[i][0]), i
+    assert torch.equal(res[2][1], single[2][1]) and torch.equal(res[4][1], single[4][1])
+    assert torch.equal(b3, single[3][1]) and torch.equal(b3b, single[3][1])
+
+
 def test_folded_embeddings_with_the_flat_trainer_match_the_unfolded_model():
     """Seq2SeqEmbeddings under the flat trainer (embedding parameters / gradients addressed as strided blocks of the flat
     buffers, ``_FoldedInputMap``): loss and the whole flat gradient of one train step vs the same model with the fold

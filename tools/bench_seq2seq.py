@@ -24,8 +24,9 @@ if os.environ.get('P2C_NO_FOLD'):
 flow = LitAutoencoderFlow(movements_model=model, loss_modes=['loc_2d'], transform='hips_neck_bbox')
 trainer = Trainer(device=d, use_graph=use_graph).setup(flow, dm)
 batch = dm.generate_batch(d)
+first = []
 for i in range(5):
-    trainer.train_step(flow, batch, i)
+    first.append(float(trainer.train_step(flow, batch, i)))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(steps):
@@ -33,4 +34,4 @@ for i in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 print(json.dumps({'config': 'autoencoder Seq2SeqEmbeddings pose_2d', 'B': B, 'hip_graph': use_graph, 'ms_per_step': round(dt * 1e3, 3),
-                  'clips_per_s': round(B / dt, 1), 'loss': float(loss)}))
+                  'clips_per_s': round(B / dt, 1), 'loss': float(loss), 'first_losses': first}))
