@@ -218,19 +218,28 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(const Args a) {
   const int g = blockIdx.x, JE = a.J * a.E;
   for (int i = threadIdx.x; i < JE; i += blockDim.x) row[i] = a.w_ih[(size_t)g * JE + i];
   __syncthreads();
-  for (int i = threadIdx.x; i < a.J * a.C; i += blockDim.x) {
-    const int j = i / a.C, c = i - j * a.C;
-    const float *w = a.W + j * a.w_stride + c, *r = row + j * a.E;
-    float s = 0.f;
-    for (int e = 0; e < a.E; ++e) s = fmaf(r[e], w[(size_t)e * a.C], s);
-    a.w_eff[(size_t)g * a.J * a.C + i] = s;
-  }
   float *pb = row + JE;
-  for (int j = threadIdx.x; j < a.J; j += blockDim.x) {
-    const float *bj = a.b + j * a.b_stride, *r = row + j * a.E;
-    float s = 0.f;
-    for (int e = 0; e < a.E; ++e) s = fmaf(r[e], bj[e], s);
-    pb[j] = s;
+  // threads [0, J*C): one w_eff element; threads [J*C, J*C + J): one joint's share of the bias sum (all waves busy at once)
+  for (int i = threadIdx.x; i < a.J * a.C + a.J; i += blockDim.x) {
+    if (i < a.J * a.C) {
+      const int j = i / a.C, c = i - j * a.C;
+      const float *__restrict__ w = a.W + j * a.w_stride + c;
+      const float *r = row + j * a.E;
+      float s0 = 0.f, s1 = 0.f;                   // two chains: the loads of W_j are independent of the sums
+      int e = 0;
+      for (; e + 1 < a.E; e += 2) s0 = fmaf(r[e], w[(size_t)e * a.C], s0), s1 = fmaf(r[e + 1], w[(size_t)(e + 1) * a.C], s1);
+      if (e < a.E) s0 = fmaf(r[e], w[(size_t)e * a.C], s0);
+      a.w_eff[(size_t)g * a.J * a.C + i] = s0 + s1;
+    } else {
+      const int j = i - a.J * a.C;
+      const float *__restrict__ bj = a.b + j * a.b_stride;
+      const float *r = row + j * a.E;
+      float s0 = 0.f, s1 = 0.f;
+      int e = 0;
+      for (; e + 1 < a.E; e += 2) s0 = fmaf(r[e], bj[e], s0), s1 = fmaf(r[e + 1], bj[e + 1], s1);
+      if (e < a.E) s0 = fmaf(r[e], bj[e], s0);
+      pb[j] = s0 + s1;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -242,52 +251,74 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(const Args a) {
   }
 }
 
-// one workgroup per joint j, thread (e, quarter of the G rows): the joint's slice of d W_ih0 is written row by row while
-// the sums over g for d W_j / d b_j run in registers; the four quarters meet in LDS in a fixed order
-__global__ __launch_bounds__(256) void fold_bwd_kernel(const Args a) {
-  __shared__ float part[4][64][MAXC + 1];
-  const int j = blockIdx.x, JE = a.J * a.E, JC = a.J * a.C;
-  const int qg = threadIdx.x >> 6;
-  const int gq = (a.G + 3) / 4, g0 = qg * gq, g1 = (g0 + gq < a.G) ? g0 + gq : a.G;
+// one workgroup per joint j, 1024 threads = (channel e, one of 16 groups of gate rows): the joint's slice of d W_ih0 is
+// written row by row while the sums over g for d W_j / d b_j run in registers; the 16 groups meet in LDS in a fixed order.
+// The gradients of the two outputs for this joint sit in LDS, and the loop is unrolled with its loads in front: 16 rows per
+// thread is two round trips, where 64 rows with a load-use-store body each were 64 (57 us measured at G = 256).
+constexpr int GG = 16;                             // gate-row groups per workgroup
+__global__ __launch_bounds__(64 * GG) void fold_bwd_kernel(const Args a) {
+  extern __shared__ float lds[];                   // [G][C + 1]: g_eff[g, j, :], g_b[g]; then [GG][64][C + 1] partial sums
+  const int j = blockIdx.x, JE = a.J * a.E, JC = a.J * a.C, C1 = a.C + 1;
+  float *ge = lds, *part = lds + a.G * C1;
+  for (int i = threadIdx.x; i < a.G * C1; i += blockDim.x) {
+    const int g = i / C1, c = i - g * C1;
+    ge[i] = (c < a.C) ? a.g_eff[(size_t)g * JC + j * a.C + c] : a.g_b[g];
+  }
+  __syncthreads();
+  const int grp = threadIdx.x >> 6, l = threadIdx.x & 63;
+  const int per = (a.G + GG - 1) / GG, g0 = grp * per, g1 = (g0 + per < a.G) ? g0 + per : a.G;
   for (int e0 = 0; e0 < a.E; e0 += 64) {
-    const int e = e0 + (threadIdx.x & 63);
+    const int e = e0 + l;
     const bool ok = e < a.E;
     float wj[MAXC], acc[MAXC + 1];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) wj[c] = (ok && c < a.C) ? a.W[j * a.w_stride + (size_t)e * a.C + c] : 0.f, acc[c] = 0.f;
     acc[MAXC] = 0.f;
     const float bj = ok ? a.b[j * a.b_stride + e] : 0.f;
-    if (ok)
-      for (int g = g0; g < g1; ++g) {
-        const size_t iw = (size_t)g * JE + j * a.E + e;
-        const float w = a.w_ih[iw], gbv = a.g_b[g];
+    constexpr int U = 8;
+    for (int gb = g0; gb < g1 && ok; gb += U) {
+      float w[U], old[U];
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        const bool in = gb + r < g1;
+        const size_t iw = (size_t)(gb + r) * JE + j * a.E + e;
+        w[r] = in ? a.w_ih[iw] : 0.f;
+        old[r] = (in && a.acc_w) ? a.g_w_ih[iw] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < U; ++r) {
+        if (gb + r >= g1) continue;
+        const float *gr = ge + (gb + r) * C1;
+        const float gbv = gr[a.C];
         float s = gbv * bj;
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
-          if (c < a.C) {
-            const float ge = a.g_eff[(size_t)g * JC + j * a.C + c];
-            s = fmaf(ge, wj[c], s);
-            acc[c] = fmaf(ge, w, acc[c]);
-          }
-        acc[MAXC] = fmaf(gbv, w, acc[MAXC]);
-        a.g_w_ih[iw] = a.acc_w ? a.g_w_ih[iw] + s : s;
+          if (c < a.C) s = fmaf(gr[c], wj[c], s), acc[c] = fmaf(gr[c], w[r], acc[c]);
+        acc[MAXC] = fmaf(gbv, w[r], acc[MAXC]);
+        a.g_w_ih[(size_t)(gb + r) * JE + j * a.E + e] = old[r] + s;
       }
+    }
     __syncthreads();                               // (previous round's readers are done)
 #pragma unroll
-    for (int c = 0; c <= MAXC; ++c) part[qg][threadIdx.x & 63][c] = acc[c];
+    for (int c = 0; c <= MAXC; ++c) part[(grp * 64 + l) * (MAXC + 1) + c] = acc[c];
     __syncthreads();
-    if (qg == 0 && ok) {
-      const int l = threadIdx.x & 63;
+    if (grp == 0 && ok) {
+      float tot[MAXC + 1];
+#pragma unroll
+      for (int c = 0; c <= MAXC; ++c) tot[c] = 0.f;
+      for (int q = 0; q < GG; ++q)
+#pragma unroll
+        for (int c = 0; c <= MAXC; ++c) tot[c] += part[(q * 64 + l) * (MAXC + 1) + c];
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
-        if (c < a.C) a.gW[j * a.w_stride + (size_t)e * a.C + c] += (part[0][l][c] + part[1][l][c]) + (part[2][l][c] + part[3][l][c]);
-      a.gb[j * a.b_stride + e] += (part[0][l][MAXC] + part[1][l][MAXC]) + (part[2][l][MAXC] + part[3][l][MAXC]);
+        if (c < a.C) a.gW[j * a.w_stride + (size_t)e * a.C + c] += tot[c];
+      a.gb[j * a.b_stride + e] += tot[MAXC];
     }
   }
   if (j == 0)
     for (int g = threadIdx.x; g < a.G; g += blockDim.x) {
-      if (a.g_b_ih) a.g_b_ih[g] += a.g_b[g];
-      if (a.g_b_hh) a.g_b_hh[g] += a.g_b[g];
+      if (a.g_b_ih) a.g_b_ih[g] += ge[g * C1 + a.C];
+      if (a.g_b_hh) a.g_b_hh[g] += ge[g * C1 + a.C];
     }
 }
 
@@ -323,7 +354,9 @@ extern "C" int p2c_fold_bwd(const float *w_ih, const float *W, const float *b, i
   p2c_fold::Args a{};
   a.w_ih = w_ih, a.W = W, a.b = b, a.g_eff = g_eff, a.g_b = g_b, a.g_w_ih = g_w_ih, a.acc_w = accumulate_w, a.gW = gW, a.gb = gb;
   a.g_b_ih = g_b_ih, a.g_b_hh = g_b_hh, a.w_stride = w_stride, a.b_stride = b_stride, a.G = G, a.J = J, a.E = E, a.C = C;
-  hipLaunchKernelGGL(p2c_fold::fold_bwd_kernel, dim3((unsigned)J), dim3(256), 0, (hipStream_t)stream, a);
+  const size_t lds = ((size_t)G * (C + 1) + (size_t)p2c_fold::GG * 64 * (p2c_fold::MAXC + 1)) * sizeof(float);
+  if (lds > 60 * 1024) return P2C_E_SHAPE;
+  hipLaunchKernelGGL(p2c_fold::fold_bwd_kernel, dim3((unsigned)J), dim3(64 * p2c_fold::GG), lds, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

@@ -52,11 +52,20 @@ template <int H>
 __device__ __forceinline__ void stage_w(const float *w_hh, float *wl) {
   constexpr int N4 = 4 * H * H / 4;
   const f32x4 *src = reinterpret_cast<const f32x4 *>(w_hh);
-  for (int i = threadIdx.x; i < N4; i += blockDim.x) {
-    const f32x4 v = src[i];
-    const int e = i * 4, row = e / H, col = e - row * H;
-    float *p = wl + row * (H + 1) + col;
-    p[0] = v[0], p[1] = v[1], p[2] = v[2], p[3] = v[3];
+  constexpr int SB = 8;                           // loads in flight per thread: the 64 KB image is two round trips, not 16
+  const int nt = blockDim.x;
+  for (int i0 = threadIdx.x; i0 < N4; i0 += nt * SB) {
+    f32x4 v[SB];
+#pragma unroll
+    for (int r = 0; r < SB; ++r) v[r] = (i0 + r * nt < N4) ? src[i0 + r * nt] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < SB; ++r) {
+      const int i = i0 + r * nt;
+      if (i >= N4) continue;
+      const int e = i * 4, row = e / H, col = e - row * H;
+      float *p = wl + row * (H + 1) + col;
+      p[0] = v[r][0], p[1] = v[r][1], p[2] = v[r][2], p[3] = v[r][3];
+    }
   }
   __syncthreads();
 }

@@ -64,11 +64,20 @@ __device__ __forceinline__ void stage(const float *src, int rows, int cols, floa
   const int n = rows * cols;
   if ((cols & 3) == 0) {
     const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
-    for (int i = threadIdx.x; i < (n >> 2); i += blockDim.x) {
-      const f32x4 v = s4[i];
-      const int e = i * 4, r = e / cols, cc = e - r * cols;
-      float *p = img + r * (cols + 1) + cc;
-      p[0] = v[0], p[1] = v[1], p[2] = v[2], p[3] = v[3];
+    constexpr int SB = 8;                            // loads in flight per thread: a 64 KB image is two round trips, not 16
+    const int n4 = n >> 2, nt = blockDim.x;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += nt * SB) {
+      f32x4 v[SB];
+#pragma unroll
+      for (int r = 0; r < SB; ++r) v[r] = (i0 + r * nt < n4) ? s4[i0 + r * nt] : zero4();
+#pragma unroll
+      for (int r = 0; r < SB; ++r) {
+        const int i = i0 + r * nt;
+        if (i >= n4) continue;
+        const int e = i * 4, rr = e / cols, cc = e - rr * cols;
+        float *p = img + rr * (cols + 1) + cc;
+        p[0] = v[r][0], p[1] = v[r][1], p[2] = v[r][2], p[3] = v[r][3];
+      }
     }
   } else {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
