@@ -302,6 +302,10 @@ typedef struct p2c_lstm_desc {
   const float *g_hT, *g_cT;     /* (B,H) or NULL */
   float *g_gx;                  /* (T,B,4H) */
   float *g_h0, *g_c0;           /* (B,H) or NULL */
+  /* optional (zero-initialise the struct): */
+  const float *bias_a, *bias_b; /* (4H) or NULL: fwd adds them to gx as it reads it (b_ih, b_hh), so the projection GEMM runs bias-free */
+  float *g_gx_bt;               /* (B,T,4H) or NULL: bwd writes a second, batch-first copy of g_gx (pairs with a batch-first layer input) */
+  int32_t gx_bt;                /* fwd: gx is laid out (B,T,4H) -- the projection of a batch-first input, no permute copy */
 } p2c_lstm_desc;
 P2C_API int p2c_lstm_rec_fwd(const p2c_lstm_desc *desc, void *stream);
 P2C_API int p2c_lstm_rec_bwd(const p2c_lstm_desc *desc, void *stream);

@@ -71,7 +71,7 @@ class LstmDesc(ctypes.Structure):
     _fields_ = [('T', ctypes.c_int32), ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('gx', _f32p), ('h0', _f32p),
                 ('c0', _f32p), ('w_hh', _f32p), ('out', _f32p), ('hT', _f32p), ('cT', _f32p), ('acts', _f32p),
                 ('cs', _f32p), ('g_out', _f32p), ('g_hT', _f32p), ('g_cT', _f32p), ('g_gx', _f32p), ('g_h0', _f32p),
-                ('g_c0', _f32p)]
+                ('g_c0', _f32p), ('bias_a', _f32p), ('bias_b', _f32p), ('g_gx_bt', _f32p), ('gx_bt', ctypes.c_int32)]
 
 
 class DecoderDesc(ctypes.Structure):

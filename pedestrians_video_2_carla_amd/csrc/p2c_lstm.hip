@@ -38,7 +38,9 @@ struct Args {
   const float *g_hT, *g_cT;   // (B, H) or NULL   }
   float *g_gx;          // (T, B, 4H)             } backward outputs
   float *g_h0, *g_c0;   // (B, H) or NULL         }
-  int32_t T, B, H;
+  const float *bias_a, *bias_b;   // (4H) or NULL: added to gx as it is read (b_ih, b_hh: the projection GEMM then runs bias-free)
+  float *g_gx_bt;       // (B, T, 4H) or NULL: second copy of g_gx, batch-first (pairs with a batch-first layer input)
+  int32_t T, B, H, gx_bt;         // gx_bt: gx is laid out (B, T, 4H)
 };
 
 __device__ __forceinline__ f32x4 load4(const float *p, bool ok) {
@@ -96,11 +98,18 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
 #pragma unroll
     for (int r = 0; r < 4; ++r) hbuf[0][(u0 + r) * TP + c] = h[r];
   }
-  f32x4 nxt[4];
-  {
-    const __amdgpu_buffer_rsrc_t rg = step_rows(a.gx, 0, B, 4 * H);
+  f32x4 nxt[4], bsum[4];
+  const int offx = a.gx_bt ? (b * T * 4 * H + u0) * 4 : off4;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) nxt[q] = bload4(rg, off4 + q * H * 4);
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)                    // (scalar reads: a bias inside a flat parameter buffer is only 4-byte aligned)
+      bsum[q][r] = (a.bias_a ? a.bias_a[q * H + u0 + r] : 0.f) + (a.bias_b ? a.bias_b[q * H + u0 + r] : 0.f);
+  }
+  {
+    const __amdgpu_buffer_rsrc_t rg = a.gx_bt ? bt_rows(a.gx, 0, B, T, 4 * H) : step_rows(a.gx, 0, B, 4 * H);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = bload4(rg, offx + q * H * 4);
   }
   __syncthreads();
 #pragma unroll
@@ -110,11 +119,12 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
   for (int t = 0; t < T; ++t) {
     f32x4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) acc[q] = nxt[q];
+    for (int q = 0; q < 4; ++q) acc[q] = nxt[q] + bsum[q];
     {   // the next step's input projection is in flight during this step (the last step re-reads its own rows: no branch)
-      const __amdgpu_buffer_rsrc_t rg = step_rows(a.gx, (t + 1 < T) ? t + 1 : t, B, 4 * H);
+      const int tn = (t + 1 < T) ? t + 1 : t;
+      const __amdgpu_buffer_rsrc_t rg = a.gx_bt ? bt_rows(a.gx, tn, B, T, 4 * H) : step_rows(a.gx, tn, B, 4 * H);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) nxt[q] = bload4(rg, off4 + q * H * 4);
+      for (int q = 0; q < 4; ++q) nxt[q] = bload4(rg, offx + q * H * 4);
     }
     const float *hb = hbuf[cur] + g * TP + c;
     float bv[KS];
@@ -226,6 +236,9 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
     {
       const __amdgpu_buffer_rsrc_t rx = step_rows(a.g_gx, t, B, 4 * H);
       bstore4(rx, off4, pi), bstore4(rx, off4 + H * 4, pf), bstore4(rx, off4 + 2 * H * 4, pg), bstore4(rx, off4 + 3 * H * 4, po);
+      const __amdgpu_buffer_rsrc_t rb = bt_rows(a.g_gx_bt, t, B, T, 4 * H);
+      const int ob = (b * T * 4 * H + u0) * 4;
+      bstore4(rb, ob, pi), bstore4(rb, ob + H * 4, pf), bstore4(rb, ob + 2 * H * 4, pg), bstore4(rb, ob + 3 * H * 4, po);
     }
     lds_barrier();
     // dh[t-1] = W_hh^T d gates: two accumulators (even / odd k-steps) halve the dependent MFMA chain
@@ -279,22 +292,26 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_narrow_kernel(cons
 
   float cst = (a.c0 && ok) ? a.c0[(size_t)b * H + u] : 0.f;
   hs[0][s][u] = (a.h0 && ok) ? a.h0[(size_t)b * H + u] : 0.f;
-  f32x4 nxt;
-  {
-    const __amdgpu_buffer_rsrc_t rg = step_rows(a.gx, 0, B, 4 * H);
+  f32x4 nxt, bsum;
+  const int offx = a.gx_bt ? (b * T * 4 * H + u) * 4 : offg;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) nxt[q] = bload1(rg, offg + q * H * 4);
+  for (int q = 0; q < 4; ++q) bsum[q] = (a.bias_a ? a.bias_a[q * H + u] : 0.f) + (a.bias_b ? a.bias_b[q * H + u] : 0.f);
+  {
+    const __amdgpu_buffer_rsrc_t rg = a.gx_bt ? bt_rows(a.gx, 0, B, T, 4 * H) : step_rows(a.gx, 0, B, 4 * H);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) nxt[q] = bload1(rg, offx + q * H * 4);
   }
   __syncthreads();
   pin(nxt);
   int cur = 0;
   float hlast = 0.f;
   for (int t = 0; t < T; ++t) {
-    f32x4 acc0 = nxt, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1, acc3 = acc1;
+    f32x4 acc0 = nxt + bsum, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = acc1, acc3 = acc1;
     {
-      const __amdgpu_buffer_rsrc_t rg = step_rows(a.gx, (t + 1 < T) ? t + 1 : t, B, 4 * H);
+      const int tn = (t + 1 < T) ? t + 1 : t;
+      const __amdgpu_buffer_rsrc_t rg = a.gx_bt ? bt_rows(a.gx, tn, B, T, 4 * H) : step_rows(a.gx, tn, B, 4 * H);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) nxt[q] = bload1(rg, offg + q * H * 4);
+      for (int q = 0; q < 4; ++q) nxt[q] = bload1(rg, offx + q * H * 4);
     }
     const f32x4 *hp = reinterpret_cast<const f32x4 *>(hs[cur][s]);
 #pragma unroll
@@ -392,6 +409,9 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(cons
     {
       const __amdgpu_buffer_rsrc_t rx = step_rows(a.g_gx, t, B, 4 * H);
       bstore1(rx, offg, pi), bstore1(rx, offg + H * 4, pf), bstore1(rx, offg + 2 * H * 4, pg), bstore1(rx, offg + 3 * H * 4, po);
+      const __amdgpu_buffer_rsrc_t rb = bt_rows(a.g_gx_bt, t, B, T, 4 * H);
+      const int ob = (b * T * 4 * H + u) * 4;
+      bstore1(rb, ob, pi), bstore1(rb, ob + H * 4, pf), bstore1(rb, ob + 2 * H * 4, pg), bstore1(rb, ob + 3 * H * 4, po);
     }
     lds_barrier();
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0, e3 = e0;
@@ -428,6 +448,8 @@ static int check(const p2c_lstm_desc *d, Args &a) {
   a.gx = d->gx, a.h0 = d->h0, a.c0 = d->c0, a.w_hh = d->w_hh, a.out = d->out, a.hT = d->hT, a.cT = d->cT;
   a.acts = d->acts, a.cs = d->cs, a.g_out = d->g_out, a.g_hT = d->g_hT, a.g_cT = d->g_cT, a.g_gx = d->g_gx;
   a.g_h0 = d->g_h0, a.g_c0 = d->g_c0, a.T = d->T, a.B = d->B, a.H = d->H;
+  a.bias_a = d->bias_a, a.bias_b = d->bias_b, a.g_gx_bt = d->g_gx_bt, a.gx_bt = d->gx_bt;
+  if ((a.gx_bt || a.g_gx_bt) && (int64_t)a.B * a.T * 4 * a.H * 4 >= (int64_t)1 << 31) return P2C_E_SHAPE;
   return 0;
 }
 

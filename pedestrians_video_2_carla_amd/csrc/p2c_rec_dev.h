@@ -31,6 +31,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t step_rows(const float *base, i
   const uintptr_t p = reinterpret_cast<uintptr_t>(base) + (size_t)t * B * row_floats * 4;   // (NULL: no records, never used)
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p), 0, base ? B * row_floats * 4 : 0, 0x00020000);
 }
+// rows of step t of a batch-first (B, T, row_floats) tensor: lane offset (b T row_floats + column) * 4; b >= B is out of range
+// by construction (records end with row (B-1, t)). The host bounds B T row_floats * 4 below 2^31.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bt_rows(const float *base, int t, int B, int T, int row_floats) {
+  const uintptr_t p = reinterpret_cast<uintptr_t>(base) + (size_t)t * row_floats * 4;
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p), 0, base ? ((B - 1) * T + 1) * row_floats * 4 : 0, 0x00020000);
+}
 __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, int byte_off) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }

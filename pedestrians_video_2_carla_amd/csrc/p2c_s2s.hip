@@ -47,11 +47,6 @@ struct Args {
   int32_t T, B, O, g_out_bt;             // g_out_bt: g_out is laid out (B,T,O)
 };
 
-// rows of step t of a (B,T,O) tensor: lane offset (b T O + o) * 4, b >= B out of range by construction
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t bt_rows(const float *base, int t, int B, int T, int O) {
-  const uintptr_t p = reinterpret_cast<uintptr_t>(base) + (size_t)t * O * 4;
-  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(p), 0, base ? ((B - 1) * T + 1) * O * 4 : 0, 0x00020000);
-}
 
 __device__ __forceinline__ f32x4 load4(const float *p, bool ok) {
   return ok ? *reinterpret_cast<const f32x4 *>(p) : (f32x4){0.f, 0.f, 0.f, 0.f};

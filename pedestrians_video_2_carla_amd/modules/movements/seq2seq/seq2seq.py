@@ -182,6 +182,12 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         return out, out
 
     def _encode(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+        from pedestrians_video_2_carla_amd import ops
+        rnn = self.encoder.rnn
+        if (type(self)._format_input is Seq2Seq._format_input and isinstance(rnn, nn.LSTM) and _fused_ok(rnn, x)
+                and ops.encoder_stack_supported(rnn, x, self.invert_sequence)):
+            # the 2-layer encoder over the batch-first rows as one explicit launch sequence (ops.EncoderStackFunction)
+            return ops.encoder_stack(x.reshape(*x.shape[:2], self.encoder.input_size), rnn)
         return self.encoder(self._format_input(x))
 
     def _decoder_loop_fusable(self, x: Tensor) -> bool:

@@ -1060,7 +1060,7 @@ class grad_sinks:
 def _sink(p: Tensor) -> Optional[Tensor]:
     """``p.grad`` if gradients may be accumulated into it directly (same result as returning the gradient to autograd, minus
     the temporary and the per-parameter accumulate launch; parameter hooks do not fire)."""
-    g = p.grad if GRAD_SINKS else None
+    g = p.grad if (GRAD_SINKS and p.is_leaf) else None
     return g if (g is not None and g.is_cuda and g.dtype == torch.float32 and g.stride(-1) == 1) else None
 
 
@@ -1095,6 +1095,23 @@ def atb_group(problems: Sequence[dict]) -> list:
         return []
     if n > 8:
         return atb_group(problems[:8]) + atb_group(problems[8:])
+    if any(pr['a'].shape[0] == 0 for pr in problems):           # no rows: zeros (or an untouched accumulator), no launch
+        live = [pr for pr in problems if pr['a'].shape[0] > 0]
+        done = iter(atb_group(live))
+        results = []
+        for pr in problems:
+            if pr['a'].shape[0] > 0:
+                results.append(next(done))
+                continue
+            M, N = pr['a'].shape[1], pr['b'].shape[1]
+            out = pr.get('out')
+            if out is None:
+                out = torch.zeros(M, N, dtype=torch.float32, device=pr['a'].device)
+            bias_out = pr.get('bias_out')
+            if pr.get('bias', False) and bias_out is None:
+                bias_out = torch.zeros(M, dtype=torch.float32, device=pr['a'].device)
+            results.append((out, bias_out if pr.get('bias', False) else None))
+        return results
     arr = (_lib.AtbProblem * n)()
     keep, results = [], []
     for q, pr in zip(arr, problems):
@@ -1331,3 +1348,131 @@ def decoder_stack(hidden: Tensor, cell: Tensor, rnn, fc, T: int, drop: Optional[
     return DecoderStackFunction.apply(hidden, cell, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0,
                                       rnn.weight_ih_l1, rnn.weight_hh_l1, rnn.bias_ih_l1, rnn.bias_hh_l1, fc.weight, fc.bias,
                                       drop, T)
+
+
+def encoder_stack_supported(rnn, x: Tensor, flip: bool = False) -> bool:
+    return (rnn.num_layers == 2 and rnn.bias and not rnn.bidirectional and rnn.proj_size == 0 and lstm_supported(rnn.hidden_size)
+            and not flip and x.is_cuda and x.dtype == torch.float32
+            and x.shape[0] * x.shape[1] * 4 * rnn.hidden_size * 4 < 2 ** 31)
+
+
+class EncoderStackFunction(torch.autograd.Function):
+    """Seq2Seq's encoder -- a 2-layer ``nn.LSTM`` from the zero state over a BATCH-FIRST input -- as an explicit launch
+    sequence: (hidden, cell) (2,B,H) from x (B,T,I), layer 0's input map (w_in (4H,I), up to two bias vectors) and the other
+    LSTM parameters. Forward: projection GEMM of the batch-first rows (no permute copy; the recurrence reads gx batch-first
+    and adds the biases itself), recurrence, inter-layer dropout, projection GEMM, recurrence; the final states are written
+    straight into the stacked (2,B,H) tensors. Backward: two recurrence launches around one input-gradient GEMM and the
+    dropout backward, then ALL weight / bias gradients in one grouped launch pair. Compared with the same layers as separate
+    autograd nodes: no stack / select copies, no bias adds and their backwards, no zero-filled placeholder gradients, four
+    weight-gradient launch pairs less."""
+
+    @staticmethod
+    def forward(ctx, x, w_in, b_in_a, b_in_b, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1, p_drop: float, train: bool):
+        lib = _lib.lib()
+        ctx.set_materialize_grads(False)
+        x = _require_device(x, 'x')
+        w_in, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1 = (_require_device(t, n) for t, n in (
+            (w_in, 'layer-0 input map'), (w_hh0, 'weight_hh_l0'), (w_ih1, 'weight_ih_l1'), (w_hh1, 'weight_hh_l1'),
+            (b_ih1, 'bias_ih_l1'), (b_hh1, 'bias_hh_l1')))
+        b_in_a = None if b_in_a is None else _require_device(b_in_a, 'layer-0 bias')
+        b_in_b = None if b_in_b is None else _require_device(b_in_b, 'layer-0 bias')
+        B, T, I = x.shape
+        H = w_hh0.shape[1]
+        G = 4 * H
+        if w_in.shape != (G, I) or w_hh0.shape != (G, H) or w_ih1.shape != (G, H) or w_hh1.shape != (G, H) or not lstm_supported(H):
+            raise RuntimeError('encoder stack: unsupported or inconsistent shapes')
+        f32 = dict(dtype=torch.float32, device=x.device)
+        hidden, cell = torch.empty(2, B, H, **f32), torch.empty(2, B, H, **f32)
+        out0, out1 = torch.empty(T, B, H, **f32), torch.empty(T, B, H, **f32)
+        acts0, acts1 = torch.empty(T, B, G, **f32), torch.empty(T, B, G, **f32)
+        cs0, cs1 = torch.empty(T, B, H, **f32), torch.empty(T, B, H, **f32)
+
+        def rec(gx, gx_bt, ba, bb, w_hh, out, acts, cs, k):
+            d = _lib.LstmDesc()
+            d.T, d.B, d.H, d.gx_bt = T, B, H, int(gx_bt)
+            d.gx, d.w_hh, d.bias_a, d.bias_b = gx.data_ptr(), w_hh.data_ptr(), _ptr(ba), _ptr(bb)
+            d.out, d.hT, d.cT, d.acts, d.cs = out.data_ptr(), hidden[k].data_ptr(), cell[k].data_ptr(), acts.data_ptr(), cs.data_ptr()
+            _lib.check(lib.p2c_lstm_rec_fwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_fwd')
+
+        with torch.cuda.device(x.device):
+            gx0 = torch.mm(x.view(B * T, I), w_in.t())                     # (B,T,4H) rows, bias-free
+            rec(gx0, True, b_in_a, b_in_b, w_hh0, out0, acts0, cs0, 0)
+            mask = None
+            x1 = out0
+            if train and p_drop > 0:
+                x1, mask = torch.native_dropout(out0, p_drop, True)
+            gx1 = torch.mm(x1.view(T * B, H), w_ih1.t())
+            rec(gx1, False, b_ih1, b_hh1, w_hh1, out1, acts1, cs1, 1)
+        ctx.save_for_backward(x, w_in, b_in_a, b_in_b, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1, out0, x1, mask, out1, acts0, cs0, acts1, cs1)
+        ctx.p_drop = p_drop
+        return hidden, cell
+
+    @staticmethod
+    def backward(ctx, g_hidden, g_cell):
+        lib = _lib.lib()
+        x, w_in, b_in_a, b_in_b, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1, out0, x1, mask, out1, acts0, cs0, acts1, cs1 = ctx.saved_tensors
+        B, T, I = x.shape
+        H = w_hh0.shape[1]
+        G = 4 * H
+        f32 = dict(dtype=torch.float32, device=x.device)
+        g_hidden = None if g_hidden is None else _require_device(g_hidden, 'grad hidden')
+        g_cell = None if g_cell is None else _require_device(g_cell, 'grad cell')
+        g_gx1, g_gx0, g_gx0_bt = torch.empty(T, B, G, **f32), torch.empty(T, B, G, **f32), torch.empty(B, T, G, **f32)
+
+        def rec(w_hh, acts, cs, g_out, k, g_gx, g_gx_bt=None):
+            d = _lib.LstmDesc()
+            d.T, d.B, d.H = T, B, H
+            d.w_hh, d.acts, d.cs = w_hh.data_ptr(), acts.data_ptr(), cs.data_ptr()
+            d.g_out = _ptr(g_out)
+            d.g_hT = None if g_hidden is None else g_hidden[k].data_ptr()
+            d.g_cT = None if g_cell is None else g_cell[k].data_ptr()
+            d.g_gx, d.g_gx_bt = g_gx.data_ptr(), _ptr(g_gx_bt)
+            _lib.check(lib.p2c_lstm_rec_bwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_bwd')
+
+        with torch.cuda.device(x.device):
+            rec(w_hh1, acts1, cs1, None, 1, g_gx1)
+            g_x1 = torch.mm(g_gx1.view(T * B, G), w_ih1).view(T, B, H)
+            if mask is not None:
+                g_x1 = torch.ops.aten.native_dropout_backward(g_x1, mask, 1.0 / (1.0 - ctx.p_drop))
+            rec(w_hh0, acts0, cs0, g_x1, 0, g_gx0, g_gx0_bt)
+        names = ('w_in', 'b_in_a', 'b_in_b', 'w_hh0', 'w_ih1', 'w_hh1', 'b_ih1', 'b_hh1')
+        params = dict(zip(names, (w_in, b_in_a, b_in_b, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1)))
+        sinks = {n: (None if p is None else _sink(p)) for n, p in params.items()}
+        for group in (('w_in', 'b_in_a', 'b_in_b'), ('w_ih1', 'b_ih1', 'b_hh1')):
+            if any(sinks[n] is None for n in group if params[n] is not None):
+                for n in group:
+                    sinks[n] = None
+
+        def prob(a, b, w, bias=None, bias2=None):
+            return dict(a=a, b=b, out=sinks[w], accumulate=sinks[w] is not None, bias=bias is not None,
+                        bias_out=sinks[bias] if bias else None, bias_out2=sinks[bias2] if bias2 else None)
+        res = atb_group([
+            prob(g_gx1[1:].reshape(-1, G), out1[:-1].reshape(-1, H), 'w_hh1'),
+            prob(g_gx1.view(T * B, G), x1.reshape(T * B, H), 'w_ih1', 'b_ih1', 'b_hh1'),
+            prob(g_gx0[1:].reshape(-1, G), out0[:-1].reshape(-1, H), 'w_hh0'),
+            prob(g_gx0_bt.view(B * T, G), x.view(B * T, I), 'w_in', 'b_in_a' if b_in_a is not None else None,
+                 'b_in_b' if (b_in_a is not None and b_in_b is not None) else None)])
+        g = {n: None for n in names}
+        if sinks['w_hh1'] is None:
+            g['w_hh1'] = res[0][0]
+        if sinks['w_ih1'] is None:
+            g['w_ih1'], g['b_ih1'], g['b_hh1'] = res[1][0], res[1][1], res[1][1]
+        if sinks['w_hh0'] is None:
+            g['w_hh0'] = res[2][0]
+        if sinks['w_in'] is None:
+            g['w_in'] = res[3][0]
+            g['b_in_a'] = res[3][1] if b_in_a is not None else None
+            g['b_in_b'] = res[3][1] if (b_in_a is not None and b_in_b is not None) else None
+        return (None, g['w_in'], g['b_in_a'], g['b_in_b'], g['w_hh0'], g['w_ih1'], g['w_hh1'], g['b_ih1'], g['b_hh1'], None, None)
+
+
+def encoder_stack(x: Tensor, rnn, input_map=None) -> Tuple[Tensor, Tensor]:
+    """(hidden, cell) (2,B,H) of the 2-layer ``nn.LSTM`` ``rnn`` run from the zero state over the batch-first x (B,T,I).
+    ``input_map`` = (weight (4H,I), bias (4H)) replaces layer 0's (weight_ih_l0, bias_ih_l0 + bias_hh_l0)."""
+    _prefer_rocblas_once()
+    if input_map is not None:
+        w_in, b_a, b_b = input_map[0], input_map[1], None
+    else:
+        w_in, b_a, b_b = rnn.weight_ih_l0, rnn.bias_ih_l0, rnn.bias_hh_l0
+    return EncoderStackFunction.apply(x, w_in, b_a, b_b, rnn.weight_hh_l0, rnn.weight_ih_l1, rnn.weight_hh_l1,
+                                      rnn.bias_ih_l1, rnn.bias_hh_l1, float(rnn.dropout), bool(rnn.training))

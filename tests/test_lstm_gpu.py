@@ -182,6 +182,72 @@ def test_decoder_stack_from_the_encoder_state(T, B, O, with_drop, sinks):
         close(p_.grad, want, 'grad ' + name, rtol=2e-4)
 
 
+@pytest.mark.parametrize('T,B,I,H,sinks', [(1, 3, 5, 16, False), (16, 37, 52, 64, True), (9, 130, 20, 32, False), (16, 64, 52, 64, False)])
+def test_encoder_stack_matches_torch_lstm(T, B, I, H, sinks):
+    """The 2-layer encoder as one explicit launch sequence (batch-first input, biases added in the recurrence, final states
+    written into the stacked tensors, one grouped weight-gradient launch) against torch.nn.LSTM(num_layers=2) in fp64: final
+    hidden / cell of both layers and all eight parameter gradients (returned to autograd, or added into .grad = ones)."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    torch.manual_seed(T * 3 + B)
+    ref = torch.nn.LSTM(I, H, num_layers=2).double()
+    x64 = torch.randn(B, T, I, dtype=torch.float64)
+    up_h, up_c = torch.randn(2, B, H, dtype=torch.float64), torch.randn(2, B, H, dtype=torch.float64)
+    _, (h64, c64) = ref(x64.transpose(0, 1))
+    ((h64 * up_h).sum() + (c64 * up_c).sum()).backward()
+
+    rnn = torch.nn.LSTM(I, H, num_layers=2).to(d)
+    rnn.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    if sinks:
+        for p_ in rnn.parameters():
+            p_.grad = torch.ones_like(p_)
+    with ops.grad_sinks(sinks):
+        hidden, cell = ops.encoder_stack(x64.float().to(d), rnn)
+        ((hidden * up_h.float().to(d)).sum() + (cell * up_c.float().to(d)).sum()).backward()
+    close(hidden, h64, 'hidden'), close(cell, c64, 'cell')
+    for (name, p_), q in zip(rnn.named_parameters(), ref.parameters()):
+        close(p_.grad, q.grad + 1 if sinks else q.grad, 'grad ' + name, rtol=2e-4)
+    # only the cell state used downstream: the unused output's gradient stays None inside the function
+    rnn.zero_grad()
+    hidden, cell = ops.encoder_stack(x64.float().to(d), rnn)
+    (cell * up_c.float().to(d)).sum().backward()
+    ref.zero_grad()
+    _, (h64, c64) = ref(x64.transpose(0, 1))
+    (c64 * up_c).sum().backward()
+    close(rnn.weight_ih_l0.grad, ref.weight_ih_l0.grad, 'grad weight_ih_l0 (cell only)', rtol=2e-4)
+
+
+def test_encoder_stack_inter_layer_dropout():
+    """Training mode with nn.LSTM's inter-layer dropout: the explicit sequence draws the mask with torch's generator (same
+    seed -> same result) and its backward is the derivative of that forward (directional finite difference in fp32)."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    torch.manual_seed(3)
+    rnn = torch.nn.LSTM(20, 32, num_layers=2, dropout=0.3).to(d).train()
+    x = torch.randn(33, 7, 20, device=d)
+    up = torch.randn(2, 33, 32, device=d)
+
+    def run(seed, w=None):
+        torch.manual_seed(seed)
+        if w is not None:
+            with torch.no_grad():
+                rnn.weight_ih_l0.copy_(w)
+        hidden, cell = ops.encoder_stack(x, rnn)
+        return ((hidden + cell) * up).sum()
+
+    rnn.zero_grad()
+    a = run(11)
+    a.backward()
+    g = rnn.weight_ih_l0.grad.clone()
+    assert torch.equal(run(11), a) and not torch.equal(run(12), a)
+    w0, direction = rnn.weight_ih_l0.detach().clone(), torch.randn_like(rnn.weight_ih_l0)
+    eps = 1e-2
+    with torch.no_grad():
+        fd = (run(11, w0 + eps * direction) - run(11, w0 - eps * direction)) / (2 * eps)
+        run(11, w0)
+    assert abs(fd.item() - (g * direction).sum().item()) <= 2e-2 * max(1.0, abs(fd.item()))
+
+
 def test_atb_group_equals_the_single_launches():
     """p2c_atb_group: five problems of different shapes (strided rows, bias, second bias destination, accumulate) behind one
     launch pair give bit for bit what p2c_atb gives one by one."""
