@@ -555,8 +555,11 @@ def extra_config(device, name, steps=100, warmup=10):
         # LSTM layer and direction of the data flow (forward; the backward kernels do the same again with W^T)
         rt, rflops = recurrence_times(device, B)
         out['roofline'] = [mfma_entry(k, B, rt[k], fl) for k, fl in rflops.items()]
-        out['note'] = ('the four recurrence launches are latency chains (one workgroup barrier per time step, 16 sequences per '
-                       'workgroup = 32 workgroups on 256 CUs): their MFMA fraction says so; the rest of the step is glue launches')
+        out['note'] = ('the time-loop launches are latency chains (one to three workgroup barriers per time step); at B <= 4096 they '
+                       'run 4 sequences per workgroup on v_mfma_f32_4x4x1_16B (128 workgroups at B = 512), above that 16 on '
+                       'v_mfma_f32_16x16x4. The step is 25 launches: fold, 2 projection GEMMs, 2 + 2 encoder recurrences, '
+                       'dropout, decoder fwd / bwd with the frame-invariant terms inside, 2 grouped weight-gradient pairs, '
+                       'loss, AdamW')
     return out
 
 
