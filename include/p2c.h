@@ -454,6 +454,20 @@ typedef struct p2c_atb_problem {
 P2C_API int64_t p2c_atb_group_workspace_floats(const p2c_atb_problem *problems, int32_t n);
 P2C_API int p2c_atb_group(const p2c_atb_problem *problems, int32_t n, float *workspace, void *stream);
 
+/* ---- multi-head self-attention over short token sequences (K14) --------------------------------------------------------------
+ * The attention of the build's PoseTransformer (reference modules/movements/pose_former/pose_former.py:33-76 binds the
+ * third-party PoseTransformer: 26 joint tokens x 8 heads of 4 channels in the spatial blocks, 9 frame tokens x 8 heads of
+ * 104 in the temporal ones). qkv (S, N, 3, heads, head_dim) = the qkv projection's output viewed; out (S, N, heads*head_dim)
+ * = softmax(scale * q k^T) v per head, heads concatenated. Backward: from qkv and g_out (S, N, heads*head_dim) to g_qkv (the
+ * layout of qkv); the probabilities are recomputed. One launch each; one workgroup per sequence with everything in LDS:
+ * N <= 64, heads*head_dim % 4 == 0 and (4 N heads head_dim + 2 heads N^2) floats <= 156 KB (p2c_attn_small_supported). No
+ * attention dropout, no mask. */
+P2C_API int p2c_attn_small_supported(int32_t N, int32_t heads, int32_t head_dim);
+P2C_API int p2c_attn_small_fwd(const float *qkv, float *out, float scale, int32_t S, int32_t N, int32_t heads, int32_t head_dim,
+                       void *stream);
+P2C_API int p2c_attn_small_bwd(const float *qkv, const float *g_out, float *g_qkv, float scale, int32_t S, int32_t N,
+                       int32_t heads, int32_t head_dim, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

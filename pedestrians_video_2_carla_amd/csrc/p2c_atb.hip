@@ -152,7 +152,7 @@ static inline int slices_for(int tiles, int64_t K) {
   int ks = 1024 / (tiles < 1 ? 1 : tiles);                     // ~1024 workgroups: four per CU
   const int64_t max_ks = (K + 255) / 256;                      // at least 256 rows per slice
   if (ks > max_ks) ks = (int)max_ks;
-  return ks < 1 ? 1 : (ks > 64 ? 64 : ks);
+  return ks < 1 ? 1 : (ks > 256 ? 256 : ks);   // (few tiles over very many rows: the transformer's 546 624 x 96 x 32)
 }
 
 extern "C" int64_t p2c_atb_workspace_floats(int64_t K, int32_t M, int32_t N, int32_t with_bias) {

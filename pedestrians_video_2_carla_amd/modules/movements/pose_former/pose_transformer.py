@@ -15,11 +15,26 @@ original loads: ``Spatial_patch_to_embedding``, ``Spatial_pos_embed``, ``Tempora
       -> a learned weighted mean over the F frames (Conv1d(F, 1, 1)) -> LayerNorm + Linear(J*E, 3 J)
     returns (B, 1, J, 3): the 3-D pose of the CENTRE frame.
 
-Attention runs through ``torch.nn.functional.scaled_dot_product_attention`` (library kernels): 26-token / 9-token sequences.
+Attention: fp32 on the GPU through K14 (``ops.small_attention``, csrc/p2c_attn.hip: one launch each way, a workgroup per 26- or
+9-token sequence); under bf16 autocast, with attention dropout, or on the host through
+``torch.nn.functional.scaled_dot_product_attention``.
 """
 import torch
 import torch.nn.functional as F
 from torch import nn
+
+
+def _linear(layer: nn.Linear, x):
+    """``layer(x)``; fp32 on the GPU it runs through ``ops.dense``: library GEMM forward / input gradient, K12 (p2c_atb) for the
+    weight + bias gradient. The spatial blocks contract 546 624 rows (cfg5: 2 336 windows x 9 frames x 26 joints) into 32..96
+    x 32..64 outputs -- the BLAS pick for that shape took 0.99 ms per layer (16 per step), K12 streams it in 0.22. The
+    temporal blocks (21 024 rows, 832 x 2 496 outputs) are ordinary GEMMs and stay with the library."""
+    if (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and layer.in_features <= 128 and layer.out_features <= 128):
+        from pedestrians_video_2_carla_amd import ops
+        shp = x.shape
+        return ops.dense(x.reshape(-1, shp[-1]), layer.weight, layer.bias).view(*shp[:-1], layer.out_features)
+    return layer(x)
 
 
 class _DropPath(nn.Module):
@@ -48,9 +63,15 @@ class _Attention(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        q, k, v = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        qkv = _linear(self.qkv, x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
+        if (x.is_cuda and qkv.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and (self.attn_drop == 0.0 or not self.training)):
+            from pedestrians_video_2_carla_amd import ops
+            if ops.small_attention_supported(N, self.num_heads, C // self.num_heads):      # K14: one launch each way
+                return self.proj_drop(_linear(self.proj, ops.small_attention(qkv, self.scale)))
+        q, k, v = qkv.permute(2, 0, 3, 1, 4)
         out = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop if self.training else 0.0, scale=self.scale)
-        return self.proj_drop(self.proj(out.transpose(1, 2).reshape(B, N, C)))
+        return self.proj_drop(_linear(self.proj, out.transpose(1, 2).reshape(B, N, C)))
 
 
 class _Mlp(nn.Module):
@@ -59,7 +80,7 @@ class _Mlp(nn.Module):
         self.fc1, self.act, self.fc2, self.drop = nn.Linear(dim, hidden), nn.GELU(), nn.Linear(hidden, dim), nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        return self.drop(_linear(self.fc2, self.drop(self.act(_linear(self.fc1, x)))))
 
 
 class _Block(nn.Module):
@@ -107,7 +128,7 @@ class PoseTransformer(nn.Module):
 
     def _forward(self, x):
         B, Fr, J, C = x.shape
-        t = self.Spatial_patch_to_embedding(x.reshape(B * Fr, J, C)) + self.Spatial_pos_embed
+        t = _linear(self.Spatial_patch_to_embedding, x.reshape(B * Fr, J, C)) + self.Spatial_pos_embed
         t = self.pos_drop(t)
         for blk in self.Spatial_blocks:
             t = blk(t)
@@ -115,5 +136,8 @@ class PoseTransformer(nn.Module):
         t = self.pos_drop(t)
         for blk in self.blocks:
             t = blk(t)
-        t = self.weighted_mean(self.Temporal_norm(t))                                # (B, 1, J*E): learned mean over the frames
+        # the learned mean over the frames, Conv1d(F, 1, kernel 1), written as the weighted sum it is (the convolution library
+        # spends seconds searching kernels for this shape at the first step and then runs four launches for it)
+        wm = self.weighted_mean
+        t = (torch.einsum('bfc,f->bc', self.Temporal_norm(t), wm.weight.view(-1)) + wm.bias).unsqueeze(1)      # (B, 1, J*E)
         return self.head(t).view(B, 1, J, 3)

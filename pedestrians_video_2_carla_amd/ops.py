@@ -1476,3 +1476,45 @@ def encoder_stack(x: Tensor, rnn, input_map=None) -> Tuple[Tensor, Tensor]:
         w_in, b_a, b_b = rnn.weight_ih_l0, rnn.bias_ih_l0, rnn.bias_hh_l0
     return EncoderStackFunction.apply(x, w_in, b_a, b_b, rnn.weight_hh_l0, rnn.weight_ih_l1, rnn.weight_hh_l1,
                                       rnn.bias_ih_l1, rnn.bias_hh_l1, float(rnn.dropout), bool(rnn.training))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# multi-head self-attention over short token sequences (K14, csrc/p2c_attn.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+def small_attention_supported(N: int, heads: int, head_dim: int) -> bool:
+    return bool(_lib.lib().p2c_attn_small_supported(int(N), int(heads), int(head_dim)))
+
+
+class SmallAttentionFunction(torch.autograd.Function):
+    """out (S,N,heads*head_dim) = concat_h softmax(scale q_h k_h^T) v_h from qkv (S,N,3,heads,head_dim): one launch forward, one
+    backward (probabilities recomputed), one workgroup per sequence."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale: float):
+        lib = _lib.lib()
+        qkv = _require_device(qkv, 'qkv')
+        S, N, three, Hh, D = qkv.shape
+        if three != 3 or not small_attention_supported(N, Hh, D):
+            raise RuntimeError(f'small attention: unsupported shape {tuple(qkv.shape)}')
+        out = torch.empty(S, N, Hh * D, dtype=torch.float32, device=qkv.device)
+        with torch.cuda.device(qkv.device):
+            _lib.check(lib.p2c_attn_small_fwd(qkv.data_ptr(), out.data_ptr(), float(scale), S, N, Hh, D, _stream()), 'p2c_attn_small_fwd')
+        ctx.save_for_backward(qkv)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        lib = _lib.lib()
+        (qkv,) = ctx.saved_tensors
+        S, N, _, Hh, D = qkv.shape
+        g_out = _require_device(g_out, 'grad out')
+        g_qkv = torch.empty_like(qkv)
+        with torch.cuda.device(qkv.device):
+            _lib.check(lib.p2c_attn_small_bwd(qkv.data_ptr(), g_out.data_ptr(), g_qkv.data_ptr(), ctx.scale, S, N, Hh, D, _stream()),
+                       'p2c_attn_small_bwd')
+        return g_qkv, None
+
+
+def small_attention(qkv: Tensor, scale: float) -> Tensor:
+    return SmallAttentionFunction.apply(qkv, scale)

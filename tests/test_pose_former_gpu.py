@@ -83,3 +83,29 @@ def test_cfg5_train_steps_through_the_flow_with_lr_schedule():
         assert abs(lr - 4e-4 * 0.99 ** 2) < 1e-12, lr               # two epoch ends
     assert torch.isfinite(curves[False]).all() and curves[False][-1] < curves[False][0]
     assert torch.allclose(curves[True], curves[False], rtol=2e-3), (curves[True], curves[False])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S,N,heads,hd', [(37, 26, 8, 4), (11, 9, 8, 104), (5, 1, 2, 6), (3, 17, 3, 12)])
+def test_small_attention_matches_fp64(S, N, heads, hd):
+    """K14 (p2c_attn_small_fwd/_bwd) on PoseTransformer's two shapes (26 joint tokens x 8 heads x 4, 9 frame tokens x 8 x 104) and
+    two odd ones against softmax(scale q k^T) v written out in fp64: output and the gradient of qkv, 1e-5 relative."""
+    import torch
+    from pedestrians_video_2_carla_amd import ops
+    d = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(S * 31 + N)
+    qkv64 = torch.randn(S, N, 3, heads, hd, generator=g, dtype=torch.float64, requires_grad=True)
+    up = torch.randn(S, N, heads * hd, generator=g, dtype=torch.float64)
+    scale = hd ** -0.5
+    q, k, v = qkv64.permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(S, N, heads * hd)
+    (ref * up).sum().backward()
+    qkv = qkv64.detach().float().to(d).requires_grad_(True)
+    out = ops.small_attention(qkv, scale)
+    (out * up.float().to(d)).sum().backward()
+
+    def close(a, b, what):
+        a, b = a.detach().double().cpu(), b.detach()
+        err, sc = (a - b).abs().max().item(), b.abs().max().item()
+        assert err <= 1e-5 * sc, f'{what}: {err:.3e} vs scale {sc:.3e}'
+    close(out, ref, 'out'), close(qkv.grad, qkv64.grad, 'grad qkv')
