@@ -468,6 +468,20 @@ P2C_API int p2c_attn_small_fwd(const float *qkv, float *out, float scale, int32_
 P2C_API int p2c_attn_small_bwd(const float *qkv, const float *g_out, float *g_qkv, float scale, int32_t S, int32_t N,
                        int32_t heads, int32_t head_dim, void *stream);
 
+/* ---- LayerNorm over the last dimension of many short rows (K15) ----------------------------------------------------------------
+ * torch.nn.LayerNorm(D) (biased variance, eps inside the root) as the build's PoseTransformer applies it (546 624 rows of 32,
+ * 21 024 rows of 832; reference binding: modules/movements/pose_former/pose_former.py:33-76). x, y, gy, gx (rows, D)
+ * row-major and 16-byte aligned, D % 4 == 0, D <= 1024; gamma / beta (D), any 4-byte alignment. Forward also writes mean and
+ * rstd (rows) for the backward. Backward: gx, and g_gamma / g_beta written (accumulate = 0) or added to; partials =
+ * p2c_layernorm_workspace_floats floats; two launches, fixed summation order. */
+P2C_API int p2c_layernorm_supported(int32_t D);
+P2C_API int64_t p2c_layernorm_workspace_floats(int64_t rows, int32_t D);
+P2C_API int p2c_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                      int64_t rows, int32_t D, float eps, void *stream);
+P2C_API int p2c_layernorm_bwd(const float *x, const float *gamma, const float *mean, const float *rstd, const float *gy,
+                      float *gx, float *g_gamma, float *g_beta, int32_t accumulate, float *partials, int64_t rows,
+                      int32_t D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

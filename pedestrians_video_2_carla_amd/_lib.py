@@ -140,6 +140,10 @@ SYMBOLS = {
     'p2c_fold_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp]),
     'p2c_atb_workspace_floats': (_i64, [_i64, _i32, _i32, _i32]),
     'p2c_atb': (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
+    'p2c_layernorm_supported': (ctypes.c_int, [_i32]),
+    'p2c_layernorm_workspace_floats': (_i64, [_i64, _i32]),
+    'p2c_layernorm_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _vp]),
+    'p2c_layernorm_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
     'p2c_attn_small_supported': (ctypes.c_int, [_i32, _i32, _i32]),
     'p2c_attn_small_fwd': (ctypes.c_int, [_vp, _vp, ctypes.c_float, _i32, _i32, _i32, _i32, _vp]),
     'p2c_attn_small_bwd': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _i32, _i32, _i32, _i32, _vp]),

@@ -30,55 +30,154 @@ struct Args {
   int32_t S, N, Hh, D;
 };
 
-__device__ __forceinline__ void copy_in(float *dst, const float *src, int n) {      // n % 4 == 0, both 16-byte aligned
+// Index arithmetic: every phase is a flat loop whose index splits into (row, column) by a RUNTIME divisor that is uniform
+// over the launch; a 32-bit integer division is ~40 instructions on this ISA, the float reciprocal below 3 (exact for the
+// index ranges here: indices < 2^20, divisors < 2^13).
+struct Div {
+  float inv;
+  int d;
+  __device__ __forceinline__ explicit Div(int d_) : inv(1.f / (float)d_), d(d_) {}
+  __device__ __forceinline__ int quot(int x) const { return (int)(((float)x + 0.5f) * inv); }
+};
+
+// Token rows in LDS carry a pitch of (row + 4) floats: 16-byte aligned, and the row stride is no longer a multiple of 32
+// banks (3E = 96 / 2 496 floats: lanes that walk over tokens would all hit one or two banks).
+__device__ __forceinline__ void copy_rows(float *dst, int pitch, const float *src, int rows, int row_floats, const Div &per_row) {
   const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
-  f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
-  for (int i = threadIdx.x; i < (n >> 2); i += blockDim.x) d4[i] = s4[i];
+  const int r4 = row_floats >> 2;
+  for (int i = threadIdx.x; i < rows * r4; i += blockDim.x) {
+    const int n = per_row.quot(i), c = i - n * r4;
+    *reinterpret_cast<f32x4 *>(dst + n * pitch + 4 * c) = s4[i];
+  }
 }
 
-// P[h][i][j] = softmax_j(scale * <q_i, k_j>_h) into `P` (Hh * N * N floats); rows = the qkv image in LDS, row pitch 3E
-__device__ __forceinline__ void probabilities(const float *rows, float *P, float scale, int N, int Hh, int D) {
-  const int E = Hh * D, NN = N * N;
-  for (int idx = threadIdx.x; idx < Hh * NN; idx += blockDim.x) {
-    const int h = idx / NN, r = idx - h * NN, i = r / N, j = r - i * N;
-    const float *q = rows + i * 3 * E + h * D, *k = rows + j * 3 * E + E + h * D;
-    float s0 = 0.f, s1 = 0.f;
-    int d = 0;
-    for (; d + 1 < D; d += 2) s0 = fmaf(q[d], k[d], s0), s1 = fmaf(q[d + 1], k[d + 1], s1);
-    if (d < D) s0 = fmaf(q[d], k[d], s0);
-    P[idx] = (s0 + s1) * scale;
-  }
-  __syncthreads();
-  for (int row = threadIdx.x; row < Hh * N; row += blockDim.x) {
-    float *p = P + row * N;
-    float m = p[0];
-    for (int j = 1; j < N; ++j) m = fmaxf(m, p[j]);
-    float sum = 0.f;
-    for (int j = 0; j < N; ++j) {
-      const float e = __expf(p[j] - m);
-      p[j] = e, sum += e;
+// S[h][i][j] = <a_i, b_j>_h for all heads: a rows at `ar` (pitch ap, head h at column h D), b rows at `br` (pitch bp)
+__device__ __forceinline__ void head_dots(float *S, const float *ar, int ap, const float *br, int bp, float scale, int N, int Hh,
+                                          int D, const Div &dN) {
+  const int NN = N * N;
+  for (int h = 0; h < Hh; ++h)
+    for (int r = threadIdx.x; r < NN; r += blockDim.x) {
+      const int i = dN.quot(r), j = r - i * N;
+      const float *a = ar + i * ap + h * D, *b = br + j * bp + h * D;
+      float s0 = 0.f, s1 = 0.f;
+      int d = 0;
+      for (; d + 3 < D; d += 4) {
+        const f32x4 av = *reinterpret_cast<const f32x4 *>(a + d), bv = *reinterpret_cast<const f32x4 *>(b + d);
+        s0 = fmaf(av[0], bv[0], s0), s1 = fmaf(av[1], bv[1], s1), s0 = fmaf(av[2], bv[2], s0), s1 = fmaf(av[3], bv[3], s1);
+      }
+      for (; d < D; ++d) s0 = fmaf(a[d], b[d], s0);
+      S[h * NN + r] = (s0 + s1) * scale;
     }
+}
+
+// A thread owns a row of N <= 64 scores: all of it is read into registers by one burst of LDS loads (compile-time bound NB,
+// guarded by the runtime N), reduced there and written back -- a loop with a load-use-store body per element pays one LDS
+// round trip per element, and only Hh * N of the 256 threads have a row.
+template <int NB>
+__device__ __forceinline__ void softmax_rows_nb(float *P, int rows, int N) {
+  for (int row = threadIdx.x; row < rows; row += blockDim.x) {
+    float *p = P + row * N;
+    float v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = (j < N) ? p[j] : -3.0e38f;
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < NB; ++j) m = fmaxf(m, v[j]);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = __expf(v[j] - m), sum += v[j];       // (padding: exp(-huge) = 0)
     const float inv = 1.f / sum;
-    for (int j = 0; j < N; ++j) p[j] *= inv;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j < N) p[j] = v[j] * inv;
   }
-  __syncthreads();
+}
+__device__ __forceinline__ void softmax_rows(float *P, int rows, int N) {
+  if (N <= 16) softmax_rows_nb<16>(P, rows, N);
+  else if (N <= 32) softmax_rows_nb<32>(P, rows, N);
+  else softmax_rows_nb<64>(P, rows, N);
+}
+// dS = P * (dP - sum_j dP P) * scale, row by row, same register scheme
+template <int NB>
+__device__ __forceinline__ void ds_rows_nb(float *dS, const float *P, int rows, int N, float scale) {
+  for (int row = threadIdx.x; row < rows; row += blockDim.x) {
+    float *ds = dS + row * N;
+    const float *p = P + row * N;
+    float dv[NB], pv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dv[j] = (j < N) ? ds[j] : 0.f, pv[j] = (j < N) ? p[j] : 0.f;
+    float rs = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rs = fmaf(dv[j], pv[j], rs);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j < N) ds[j] = pv[j] * (dv[j] - rs) * scale;
+  }
+}
+__device__ __forceinline__ void ds_rows(float *dS, const float *P, int rows, int N, float scale) {
+  if (N <= 16) ds_rows_nb<16>(dS, P, rows, N, scale);
+  else if (N <= 32) ds_rows_nb<32>(dS, P, rows, N, scale);
+  else ds_rows_nb<64>(dS, P, rows, N, scale);
+}
+
+// y[n] = sum_k m[n * sn + k * sk] * x[k * xp] for n < N, written to y[n * yp]: the thread's N values of x are read into
+// registers once (compile-time bound NB), the matrix entries are wave-uniform LDS broadcasts. For wide rows (E >= the
+// workgroup) this replaces "one output per thread and round": 9 + 81 LDS reads per 9 outputs instead of 162, and the index
+// split once per channel instead of once per output.
+template <int NB>
+__device__ __forceinline__ void channel_contract(const float *m, int sn, int sk, const float *x, int xp, float *y, int yp, int N) {
+  float xv[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) xv[k] = (k < N) ? x[k * xp] : 0.f;
+  for (int n = 0; n < N; ++n) {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NB; k += 2) {
+      if (k < N) a0 = fmaf(m[n * sn + k * sk], xv[k], a0);
+      if (k + 1 < N) a1 = fmaf(m[n * sn + (k + 1) * sk], xv[k + 1], a1);
+    }
+    y[n * yp] = a0 + a1;
+  }
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int N = a.N, Hh = a.Hh, D = a.D, E = Hh * D;
-  float *rows = lds, *P = lds + N * 3 * E;
+  const int N = a.N, Hh = a.Hh, D = a.D, E = Hh * D, RP = 3 * E + 4, NN = N * N;
+  const bool vec = (D & 3) == 0;                  // head columns 16-byte aligned: 128-bit LDS reads in the dot products
+  float *rows = lds, *P = lds + N * RP;
+  const Div dN(N), dRow(3 * E >> 2), dD(D), dE(E);
   for (int s = blockIdx.x; s < a.S; s += gridDim.x) {
-    copy_in(rows, a.qkv + (size_t)s * N * 3 * E, N * 3 * E);
+    copy_rows(rows, RP, a.qkv + (size_t)s * N * 3 * E, N, 3 * E, dRow);
     __syncthreads();
-    probabilities(rows, P, a.scale, N, Hh, D);
+    if (vec) {
+      head_dots(P, rows, RP, rows + E, RP, a.scale, N, Hh, D, dN);
+    } else {                                      // (odd head widths: scalar path)
+      for (int h = 0; h < Hh; ++h)
+        for (int r = threadIdx.x; r < NN; r += blockDim.x) {
+          const int i = dN.quot(r), j = r - i * N;
+          float acc = 0.f;
+          for (int d = 0; d < D; ++d) acc = fmaf(rows[i * RP + h * D + d], rows[j * RP + E + h * D + d], acc);
+          P[h * NN + r] = acc * a.scale;
+        }
+    }
+    __syncthreads();
+    softmax_rows(P, Hh * N, N);
+    __syncthreads();
+    // out[i][e] = sum_j P[h(e)][i][j] v[j][e], one output per thread and round (lanes walk over e: conflict-free v reads,
+    // broadcast P reads)
     float *o = a.out + (size_t)s * N * E;
+    if (E >= (int)blockDim.x && N <= 16) {
+      for (int e = threadIdx.x; e < E; e += blockDim.x)
+        channel_contract<16>(P + dD.quot(e) * NN, N, 1, rows + 2 * E + e, RP, o + e, E, N);
+    } else
     for (int idx = threadIdx.x; idx < N * E; idx += blockDim.x) {
-      const int i = idx / E, e = idx - i * E, h = e / D;
-      const float *p = P + (h * N + i) * N, *v = rows + 2 * E + e;
-      float acc = 0.f;
-      for (int j = 0; j < N; ++j) acc = fmaf(p[j], v[j * 3 * E], acc);
-      o[idx] = acc;
+      const int i = dE.quot(idx), e = idx - i * E, h = dD.quot(e);
+      const float *v = rows + 2 * E + e, *p = P + h * NN + i * N;
+      float a0 = 0.f, a1 = 0.f;
+      int j = 0;
+      for (; j + 1 < N; j += 2) a0 = fmaf(p[j], v[j * RP], a0), a1 = fmaf(p[j + 1], v[(j + 1) * RP], a1);
+      if (j < N) a0 = fmaf(p[j], v[j * RP], a0);
+      o[idx] = a0 + a1;
     }
     __syncthreads();                               // the image is rewritten by the next sequence
   }
@@ -86,48 +185,56 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const Args a) {
 
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int N = a.N, Hh = a.Hh, D = a.D, E = Hh * D, NN = N * N;
-  float *rows = lds, *dO = rows + N * 3 * E, *P = dO + N * E, *dS = P + Hh * NN;
+  const int N = a.N, Hh = a.Hh, D = a.D, E = Hh * D, RP = 3 * E + 4, GP = E + 4, NN = N * N;
+  const bool vec = (D & 3) == 0;
+  float *rows = lds, *dO = rows + N * RP, *P = dO + N * GP, *dS = P + Hh * NN;
+  const Div dN(N), dRow(3 * E >> 2), dG(E >> 2), dD(D), d3E(3 * E);
   for (int s = blockIdx.x; s < a.S; s += gridDim.x) {
-    copy_in(rows, a.qkv + (size_t)s * N * 3 * E, N * 3 * E);
-    copy_in(dO, a.g_out + (size_t)s * N * E, N * E);
+    copy_rows(rows, RP, a.qkv + (size_t)s * N * 3 * E, N, 3 * E, dRow);
+    copy_rows(dO, GP, a.g_out + (size_t)s * N * E, N, E, dG);
     __syncthreads();
-    probabilities(rows, P, a.scale, N, Hh, D);
-    // dP[h][i][j] = <dO_i, v_j>_h
-    for (int idx = threadIdx.x; idx < Hh * NN; idx += blockDim.x) {
-      const int h = idx / NN, r = idx - h * NN, i = r / N, j = r - i * N;
-      const float *g = dO + i * E + h * D, *v = rows + j * 3 * E + 2 * E + h * D;
-      float s0 = 0.f, s1 = 0.f;
-      int d = 0;
-      for (; d + 1 < D; d += 2) s0 = fmaf(g[d], v[d], s0), s1 = fmaf(g[d + 1], v[d + 1], s1);
-      if (d < D) s0 = fmaf(g[d], v[d], s0);
-      dS[idx] = s0 + s1;
+    if (vec) {
+      head_dots(P, rows, RP, rows + E, RP, a.scale, N, Hh, D, dN);            // scores
+      head_dots(dS, dO, GP, rows + 2 * E, RP, 1.f, N, Hh, D, dN);              // dP[h][i][j] = <dO_i, v_j>_h
+    } else {
+      for (int h = 0; h < Hh; ++h)
+        for (int r = threadIdx.x; r < NN; r += blockDim.x) {
+          const int i = dN.quot(r), j = r - i * N;
+          float sc = 0.f, dp = 0.f;
+          for (int d = 0; d < D; ++d) {
+            sc = fmaf(rows[i * RP + h * D + d], rows[j * RP + E + h * D + d], sc);
+            dp = fmaf(dO[i * GP + h * D + d], rows[j * RP + 2 * E + h * D + d], dp);
+          }
+          P[h * NN + r] = sc * a.scale, dS[h * NN + r] = dp;
+        }
     }
     __syncthreads();
-    // dS = P * (dP - sum_j dP P), times the score scale
-    for (int row = threadIdx.x; row < Hh * N; row += blockDim.x) {
-      float *ds = dS + row * N;
-      const float *p = P + row * N;
-      float rs = 0.f;
-      for (int j = 0; j < N; ++j) rs = fmaf(ds[j], p[j], rs);
-      for (int j = 0; j < N; ++j) ds[j] = p[j] * (ds[j] - rs) * a.scale;
-    }
+    softmax_rows(P, Hh * N, N);
     __syncthreads();
+    ds_rows(dS, P, Hh * N, N, a.scale);            // dS = P * (dP - sum_j dP P), times the score scale
+    __syncthreads();
+    // one gradient element per thread and round (lanes walk over the 3E channels c of token n):
+    //   dQ[n][e] = sum_j dS[n][j] k[j][e];  dK[n][e] = sum_i dS[i][n] q[i][e];  dV[n][e] = sum_i P[i][n] dO[i][e]
     float *g = a.g_qkv + (size_t)s * N * 3 * E;
-    for (int idx = threadIdx.x; idx < N * 3 * E; idx += blockDim.x) {
-      const int n = idx / (3 * E), r = idx - n * 3 * E, which = r / E, e = r - which * E, h = e / D;
-      float acc = 0.f;
-      if (which == 0) {                            // dQ_n = sum_j dS[n][j] k_j
-        const float *ds = dS + (h * N + n) * N, *k = rows + E + e;
-        for (int j = 0; j < N; ++j) acc = fmaf(ds[j], k[j * 3 * E], acc);
-      } else if (which == 1) {                     // dK_n = sum_i dS[i][n] q_i
-        const float *ds = dS + h * NN + n, *q = rows + e;
-        for (int i = 0; i < N; ++i) acc = fmaf(ds[i * N], q[i * 3 * E], acc);
-      } else {                                     // dV_n = sum_i P[i][n] dO_i
-        const float *p = P + h * NN + n, *go = dO + e;
-        for (int i = 0; i < N; ++i) acc = fmaf(p[i * N], go[i * E], acc);
+    if (E >= (int)blockDim.x && N <= 16) {
+      for (int c = threadIdx.x; c < 3 * E; c += blockDim.x) {
+        const int which = (c >= 2 * E) ? 2 : (c >= E ? 1 : 0), e = c - which * E, h = dD.quot(e);
+        const float *m = (which == 2 ? P : dS) + h * NN;
+        const float *x = (which == 0) ? rows + E + e : (which == 1 ? rows + e : dO + e);
+        channel_contract<16>(m, which == 0 ? N : 1, which == 0 ? 1 : N, x, which == 2 ? GP : RP, g + c, 3 * E, N);
       }
-      g[idx] = acc;
+    } else
+    for (int idx = threadIdx.x; idx < N * 3 * E; idx += blockDim.x) {
+      const int n = d3E.quot(idx), c = idx - n * 3 * E;
+      const int which = (c >= 2 * E) ? 2 : (c >= E ? 1 : 0), e = c - which * E, h = dD.quot(e);
+      const float *m = (which == 2 ? P : dS) + h * NN + (which == 0 ? n * N : n);
+      const float *x = (which == 0) ? rows + E + e : (which == 1 ? rows + e : dO + e);
+      const int xp = (which == 2) ? GP : RP, sk = (which == 0) ? 1 : N;
+      float a0 = 0.f, a1 = 0.f;
+      int k = 0;
+      for (; k + 1 < N; k += 2) a0 = fmaf(m[k * sk], x[k * xp], a0), a1 = fmaf(m[(k + 1) * sk], x[(k + 1) * xp], a1);
+      if (k < N) a0 = fmaf(m[k * sk], x[k * xp], a0);
+      g[idx] = a0 + a1;
     }
     __syncthreads();
   }
@@ -136,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const Args a) {
 static int check(const Args &a, bool bwd, size_t *lds) {
   if (a.S < 0 || a.N < 1 || a.N > 64 || a.Hh < 1 || a.D < 1 || ((a.Hh * a.D) & 3)) return P2C_E_SHAPE;
   const size_t E = (size_t)a.Hh * a.D, NN = (size_t)a.N * a.N;
-  *lds = sizeof(float) * (bwd ? a.N * 4 * E + 2 * a.Hh * NN : a.N * 3 * E + a.Hh * NN);
+  *lds = sizeof(float) * (bwd ? a.N * (4 * E + 8) + 2 * a.Hh * NN : a.N * (3 * E + 4) + a.Hh * NN);
   return *lds <= 156 * 1024 ? 0 : P2C_E_SHAPE;
 }
 

@@ -1518,3 +1518,53 @@ class SmallAttentionFunction(torch.autograd.Function):
 
 def small_attention(qkv: Tensor, scale: float) -> Tensor:
     return SmallAttentionFunction.apply(qkv, scale)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# LayerNorm over many short rows (K15, csrc/p2c_norm.hip)
+# ----------------------------------------------------------------------------------------------------------------------
+def layer_norm_supported(x: Tensor, D: int) -> bool:
+    return bool(x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == D and _lib.lib().p2c_layernorm_supported(int(D)))
+
+
+class LayerNormFunction(torch.autograd.Function):
+    """torch.nn.functional.layer_norm over the last dimension, one launch forward, two backward (p2c_layernorm_*). Inside the
+    trainer's ``grad_sinks`` context the gamma / beta gradients are added straight into their ``.grad``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float):
+        lib = _lib.lib()
+        x, weight, bias = _require_device(x, 'x'), _require_device(weight, 'weight'), _require_device(bias, 'bias')
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        stats = torch.empty(2, rows, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.p2c_layernorm_fwd(x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                             stats[1].data_ptr(), rows, D, float(eps), _stream()), 'p2c_layernorm_fwd')
+        ctx.save_for_backward(x, weight, bias, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.lib()
+        x, weight, bias, stats = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        gy = _require_device(gy, 'grad')
+        gx = torch.empty_like(x)
+        sw, sb = _sink(weight), _sink(bias)
+        if sw is None or sb is None:
+            sw = sb = None
+        gw = sw if sw is not None else torch.empty_like(weight)
+        gb = sb if sb is not None else torch.empty_like(bias)
+        ws = torch.empty(max(1, lib.p2c_layernorm_workspace_floats(rows, D)), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.p2c_layernorm_bwd(x.data_ptr(), weight.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gy.data_ptr(),
+                                             gx.data_ptr(), gw.data_ptr(), gb.data_ptr(), int(sw is not None), ws.data_ptr(),
+                                             rows, D, _stream()), 'p2c_layernorm_bwd')
+        return gx, (None if sw is not None else gw), (None if sb is not None else gb), None
+
+
+def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    return LayerNormFunction.apply(x, weight, bias, eps)

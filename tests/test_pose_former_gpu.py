@@ -109,3 +109,37 @@ def test_small_attention_matches_fp64(S, N, heads, hd):
         err, sc = (a - b).abs().max().item(), b.abs().max().item()
         assert err <= 1e-5 * sc, f'{what}: {err:.3e} vs scale {sc:.3e}'
     close(out, ref, 'out'), close(qkv.grad, qkv64.grad, 'grad qkv')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('rows,D,sinks', [(5000, 32, False), (777, 832, True), (3, 4, False), (1025, 64, False), (130, 100, True),
+                                           (64, 1024, False), (100, 260, False)])
+def test_layer_norm_matches_fp64(rows, D, sinks):
+    """K15 (p2c_layernorm_fwd/_bwd) against torch.nn.functional.layer_norm in fp64 on PoseTransformer's two widths and
+    every lane grouping of the kernel: output, input gradient, gamma / beta gradients (returned, or added into .grad = ones)."""
+    import torch
+    from pedestrians_video_2_carla_amd import ops
+    d = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(rows + D)
+    x64 = (torch.randn(rows, D, generator=g, dtype=torch.float64) * 2 + 0.5).requires_grad_(True)
+    w64 = torch.randn(D, generator=g, dtype=torch.float64).requires_grad_(True)
+    b64 = torch.randn(D, generator=g, dtype=torch.float64).requires_grad_(True)
+    up = torch.randn(rows, D, generator=g, dtype=torch.float64)
+    ref = torch.nn.functional.layer_norm(x64, (D,), w64, b64, 1e-6)
+    (ref * up).sum().backward()
+    x = x64.detach().float().to(d).requires_grad_(True)
+    w = torch.nn.Parameter(w64.detach().float().to(d))
+    b = torch.nn.Parameter(b64.detach().float().to(d))
+    if sinks:
+        w.grad, b.grad = torch.ones_like(w), torch.ones_like(b)
+    with ops.grad_sinks(sinks):
+        y = ops.layer_norm(x.view(1, rows, D), w, b, 1e-6).view(rows, D)
+        (y * up.float().to(d)).sum().backward()
+
+    def close(a, ref_, what, rtol=2e-5):
+        a, ref_ = a.detach().double().cpu(), ref_.detach()
+        err, sc = (a - ref_).abs().max().item(), ref_.abs().max().item()
+        assert err <= rtol * sc, f'{what}: {err:.3e} vs scale {sc:.3e}'
+    close(y, ref, 'y'), close(x.grad, x64.grad, 'grad x', 5e-5)
+    close(w.grad, w64.grad + (1 if sinks else 0), 'grad gamma', 5e-5 * max(1.0, rows ** 0.5))
+    close(b.grad, b64.grad + (1 if sinks else 0), 'grad beta', 5e-5 * max(1.0, rows ** 0.5))
