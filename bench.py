@@ -458,7 +458,7 @@ def extra_config(device, name, steps=100, warmup=10):
         B, clip = 32, 81                      # configs[4]: 256 clips of 81 frames over 8 GPUs -> 32 per GPU
         model = PoseFormer(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, clip_length=clip)
         flow = LitPoseLiftingFlow(movements_model=model, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
-        workload = ('flow=pose_lifting PoseFormer(9 frames, 26 joints, E=32, depth 4, 8 heads; restated, library attention) '
+        workload = ('flow=pose_lifting PoseFormer(9 frames, 26 joints, E=32, depth 4, 8 heads; restated; K14 attention, K15 LayerNorm) '
                     'clip_length=81 absolute_loc head batch_size=32 = one GPU\'s share of BASELINE.json configs[4] (256 over 8 GPUs)')
     else:
         from pedestrians_video_2_carla_amd.modules.flow.autoencoder import LitAutoencoderFlow
@@ -547,8 +547,10 @@ def extra_config(device, name, steps=100, warmup=10):
             out['bf16_autocast'] = {'ms_per_step': round(ms16, 3), 'clips_per_s': round(B / ms16 * 1e3, 1), 'final_loss': float(l16)}
         except Exception as e:                                      # noqa: BLE001
             out['bf16_autocast'] = {'error': repr(e)[:200]}
-        out['note'] = ('transformer arithmetic parity-unpinned (third-party source absent); attention / GEMMs are library kernels, '
-                       'the pose head is the HIP absolute_loc kernel; stochastic depth (0.2) on')
+        out['note'] = ('transformer arithmetic parity-unpinned (third-party source absent); attention = K14 (p2c_attn_small), LayerNorm = '
+                       'K15 (p2c_layernorm), spatial weight gradients = K12, GEMMs = library (the four temporal blocks are 2.8 TFLOP '
+                       'per step = 17.8 ms at the fp32 MFMA peak); the pose head is the HIP absolute_loc kernel; stochastic depth '
+                       '(0.2) on')
         out['windows_per_step'] = B * (81 - 9 + 1)
     else:
         # the recurrences (K7b encoder layers, K7c decoder loop) priced against the fp32 MFMA peak: 2*T*B*H*4H flop per

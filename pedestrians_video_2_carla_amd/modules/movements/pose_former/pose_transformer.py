@@ -47,7 +47,7 @@ def _linear(layer: nn.Linear, x):
 def _norm(layer: nn.LayerNorm, x):
     """``layer(x)``; fp32 on the GPU through K15 (``ops.layer_norm``, csrc/p2c_norm.hip): G lanes per row instead of a workgroup
     pass per row -- 18 LayerNorms per step over 546 624 x 32 or 21 024 x 832 rows."""
-    if (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and layer.elementwise_affine
+    if (x.is_cuda and x.dtype == torch.float32 and layer.elementwise_affine      # (autocast keeps layer_norm in fp32 as well)
             and layer.bias is not None and len(layer.normalized_shape) == 1):
         from pedestrians_video_2_carla_amd import ops
         if ops.layer_norm_supported(x, layer.normalized_shape[0]):
@@ -82,11 +82,11 @@ class _Attention(nn.Module):
     def forward(self, x):
         B, N, C = x.shape
         qkv = _linear(self.qkv, x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
-        if (x.is_cuda and qkv.dtype == torch.float32 and not torch.is_autocast_enabled()
-                and (self.attn_drop == 0.0 or not self.training)):
+        if x.is_cuda and (self.attn_drop == 0.0 or not self.training):
             from pedestrians_video_2_carla_amd import ops
             if ops.small_attention_supported(N, self.num_heads, C // self.num_heads):      # K14: one launch each way
-                return self.proj_drop(_linear(self.proj, ops.small_attention(qkv, self.scale)))
+                # (fp32 arithmetic also under bf16 autocast: the scores of 4-wide heads gain nothing from bf16 MFMA)
+                return self.proj_drop(_linear(self.proj, ops.small_attention(qkv.float(), self.scale)))
         q, k, v = qkv.permute(2, 0, 3, 1, 4)
         out = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop if self.training else 0.0, scale=self.scale)
         return self.proj_drop(_linear(self.proj, out.transpose(1, 2).reshape(B, N, C)))
