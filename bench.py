@@ -531,22 +531,29 @@ def extra_config(device, name, steps=100, warmup=10):
         out['note'] = ('dtype f32 = the default, exact fp32 MFMA (bit-for-bit an fmaf chain). precision_arms: opt-in bf16 / split-bf16 '
                        'operands (LinearAE(mlp_precision=...) or P2C_MLP_PRECISION), fp32 accumulate; the pose head stays fp32')
     elif name == 'cfg5':
-        try:                                  # the same step with the transformer's GEMMs / attention under bf16 autocast
-            seed_everything(22742)
-            m16 = PoseFormer(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, clip_length=81, compute_dtype=torch.bfloat16)
-            f16 = LitPoseLiftingFlow(movements_model=m16, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
-            t16 = Trainer(device=device, use_graph=True).setup(f16, dm)
-            for i in range(3):
-                t16.train_step(f16, batch, i)
-            torch.cuda.synchronize(device)
-            t0 = time.perf_counter()
-            for i in range(steps):
-                l16 = t16.train_step(f16, batch, i)
-            torch.cuda.synchronize(device)
-            ms16 = (time.perf_counter() - t0) / steps * 1e3
-            out['bf16_autocast'] = {'ms_per_step': round(ms16, 3), 'clips_per_s': round(B / ms16 * 1e3, 1), 'final_loss': float(l16)}
-        except Exception as e:                                      # noqa: BLE001
-            out['bf16_autocast'] = {'error': repr(e)[:200]}
+        # further arms of the same step: bf16 autocast on the GEMMs (K14 / K15 stay fp32), and the per-frame half of the
+        # transformer run once per frame instead of once per (window, frame) -- in training that shares the stochastic-depth
+        # drops of a frame between its windows (opt-in, PoseFormer(share_spatial=True)); fp32 per-window stays the headline
+        def arm(**kw):
+            try:
+                seed_everything(22742)
+                m = PoseFormer(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, clip_length=81, **kw)
+                f = LitPoseLiftingFlow(movements_model=m, loss_modes=['loc_2d_3d'], transform='hips_neck_bbox')
+                t = Trainer(device=device, use_graph=True).setup(f, dm)
+                for i in range(3):
+                    t.train_step(f, batch, i)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    la = t.train_step(f, batch, i)
+                torch.cuda.synchronize(device)
+                ms = (time.perf_counter() - t0) / steps * 1e3
+                return {'ms_per_step': round(ms, 3), 'clips_per_s': round(B / ms * 1e3, 1), 'final_loss': float(la)}
+            except Exception as e:                                      # noqa: BLE001
+                return {'error': repr(e)[:200]}
+        out['bf16_autocast'] = arm(compute_dtype=torch.bfloat16)
+        out['shared_spatial'] = arm(share_spatial=True)
+        out['shared_spatial_bf16'] = arm(share_spatial=True, compute_dtype=torch.bfloat16)
         out['note'] = ('transformer arithmetic parity-unpinned (third-party source absent); attention = K14 (p2c_attn_small), LayerNorm = '
                        'K15 (p2c_layernorm), spatial weight gradients = K12, GEMMs = library (the four temporal blocks are 2.8 TFLOP '
                        'per step = 17.8 ms at the fp32 MFMA peak); the pose head is the HIP absolute_loc kernel; stochastic depth '

@@ -28,8 +28,13 @@ class PoseFormer(MovementsModel):
     def __init__(self, clip_length: int = 30, receptive_frames: int = 9, single_joint_embeddings_size=32, depth=4,
                  num_heads=8, mlp_ratio=2, qkv_bias=True, qk_scale=None, drop_rate=0, attn_drop_rate=0,
                  drop_path_rate=0.2, input_features=2, output_features=3, inner_model: torch.nn.Module = None,
-                 compute_dtype: torch.dtype = torch.float32, **kwargs):
+                 compute_dtype: torch.dtype = torch.float32, share_spatial=None, **kwargs):
         super().__init__(**kwargs)
+        # share_spatial: run the per-frame (spatial) half of the build's PoseTransformer once per FRAME instead of once per
+        # (window, frame) -- every frame sits in up to `receptive_frames` windows. None (default): only when that is exactly
+        # the same function (eval mode, or no dropout / stochastic depth in the spatial half); True: always (in training the
+        # stochastic-depth drops of a frame are then shared by its windows); False: never.
+        self.share_spatial = share_spatial
         self.__n_out = len(self.output_nodes)
         self.__out_features = output_features
         self.__clip_length = clip_length
@@ -66,9 +71,14 @@ class PoseFormer(MovementsModel):
     def forward(self, x, *args, **kwargs):
         B, T = x.shape[:2]
         n_windows = self.__clip_length - self.__receptive + 1
-        # all windows in one batched call: (B, W, R, J, C) -> (B*W, R, J, C)
-        windows = x.unfold(1, self.__receptive, 1)[:, :n_windows].permute(0, 1, 4, 2, 3)
-        centre = self.pose_former(windows.reshape(B * n_windows, self.__receptive, *x.shape[2:]))
+        inner = self.pose_former
+        if (hasattr(inner, 'forward_clip') and self.share_spatial is not False
+                and (self.share_spatial is True or inner.spatial_is_deterministic())):
+            centre = inner.forward_clip(x[:, :n_windows + self.__receptive - 1], n_windows)
+        else:
+            # all windows in one batched call: (B, W, R, J, C) -> (B*W, R, J, C)
+            windows = x.unfold(1, self.__receptive, 1)[:, :n_windows].permute(0, 1, 4, 2, 3)
+            centre = inner(windows.reshape(B * n_windows, self.__receptive, *x.shape[2:]))
         centre = centre.reshape(B, n_windows, self.__n_out, self.__out_features)
         # frame f receives the prediction of the LAST window i with i+shift <= f < i+shift+receptive (overwrite order)
         frames = torch.arange(T, device=x.device)

@@ -144,13 +144,47 @@ class PoseTransformer(nn.Module):
                 return self._forward(x).float()
         return self._forward(x)
 
-    def _forward(self, x):
-        B, Fr, J, C = x.shape
-        t = _linear(self.Spatial_patch_to_embedding, x.reshape(B * Fr, J, C)) + self.Spatial_pos_embed
+    def spatial_is_deterministic(self) -> bool:
+        """No random op acts on the per-frame (spatial) half: it then depends on the frame alone, not on the window."""
+        if not self.training:
+            return True
+        return self.pos_drop.p == 0 and all(b.drop_path.p == 0 and b.attn.attn_drop == 0 and b.attn.proj_drop.p == 0
+                                            and b.mlp.drop.p == 0 for b in self.Spatial_blocks)
+
+    def forward_clip(self, x, n_windows: int):
+        """All sliding windows of a clip batch at once, the per-frame half run once per FRAME: x (B, T, J, C) ->
+        (B * n_windows, 1, J, 3), window w of clip b = frames w .. w + num_frame - 1. The spatial blocks see one frame at a
+        time (joints are the tokens, no frame index enters), so a frame's features are the same in each of the up to
+        ``num_frame`` windows that contain it: T frames are encoded instead of n_windows * num_frame (81 vs 657 per clip at
+        cfg5). Equal to ``forward`` on the unfolded windows whenever the spatial half is deterministic (eval mode, or no
+        dropout / stochastic depth); in training with stochastic depth the random drops would be shared by the windows of a
+        frame instead of drawn per (window, frame) -- callers opt in to that (``PoseFormer(share_spatial=True)``)."""
+        if self.compute_dtype != torch.float32 and x.is_cuda:
+            with torch.autocast('cuda', dtype=self.compute_dtype):
+                return self._forward_clip(x, n_windows).float()
+        return self._forward_clip(x, n_windows)
+
+    def _spatial(self, frames):
+        t = _linear(self.Spatial_patch_to_embedding, frames) + self.Spatial_pos_embed
         t = self.pos_drop(t)
         for blk in self.Spatial_blocks:
             t = blk(t)
-        t = _norm(self.Spatial_norm, t).reshape(B, Fr, -1) + self.Temporal_pos_embed
+        return _norm(self.Spatial_norm, t)
+
+    def _forward_clip(self, x, n_windows: int):
+        B, T, J, C = x.shape
+        feats = self._spatial(x.reshape(B * T, J, C)).reshape(B, T, -1)                     # (B, T, J*E), once per frame
+        t = feats.unfold(1, self.num_frame, 1)[:, :n_windows].permute(0, 1, 3, 2)            # (B, W, F, J*E) view
+        t = t.reshape(B * n_windows, self.num_frame, -1) + self.Temporal_pos_embed
+        return self._temporal(t, J)
+
+    def _forward(self, x):
+        B, Fr, J, C = x.shape
+        t = self._spatial(x.reshape(B * Fr, J, C)).reshape(B, Fr, -1) + self.Temporal_pos_embed
+        return self._temporal(t, J)
+
+    def _temporal(self, t, J):
+        B = t.shape[0]
         t = self.pos_drop(t)
         for blk in self.blocks:
             t = blk(t)
