@@ -289,7 +289,9 @@ P2C_API int p2c_fold_bwd(const float *w_ih, const float *W, const float *b, int6
  * all tensors fp32 row-major, 16-byte aligned. Forward fills out (T,B,H), optional hT/cT (B,H) and the saved activations
  * acts (T,B,4H) / cs (T,B,H). Backward takes g_out / g_hT / g_cT (each optional), acts, cs, c0, w_hh and writes
  * g_gx (T,B,4H) = d gates (from which the caller forms dW_hh = sum_t g_gx[t]^T h[t-1], dW_ih, db with library GEMMs)
- * and optional g_h0 / g_c0. One launch each. */
+ * and optional g_h0 / g_c0. One launch each. B <= 2^20 (per-step rows are addressed through 32-bit buffer offsets); up to
+ * B = 4096 the launch tiles 4 sequences per workgroup (v_mfma_f32_4x4x1_16B), above that 16 (v_mfma_f32_16x16x4);
+ * P2C_REC_TILE=wide|narrow in the environment forces one. */
 typedef struct p2c_lstm_desc {
   int32_t T, B, H;
   const float *gx;              /* (T,B,4H) */

@@ -1352,8 +1352,8 @@ def decoder_stack(hidden: Tensor, cell: Tensor, rnn, fc, T: int, drop: Optional[
 
 def encoder_stack_supported(rnn, x: Tensor, flip: bool = False) -> bool:
     return (rnn.num_layers == 2 and rnn.bias and not rnn.bidirectional and rnn.proj_size == 0 and lstm_supported(rnn.hidden_size)
-            and not flip and x.is_cuda and x.dtype == torch.float32
-            and x.shape[0] * x.shape[1] * 4 * rnn.hidden_size * 4 < 2 ** 31)
+            and not flip and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad      # (x is data: no d x is formed)
+            and x.shape[0] <= 2 ** 20 and x.shape[0] * x.shape[1] * 4 * rnn.hidden_size * 4 < 2 ** 31)
 
 
 class EncoderStackFunction(torch.autograd.Function):
