@@ -456,6 +456,13 @@ typedef struct p2c_atb_problem {
 P2C_API int64_t p2c_atb_group_workspace_floats(const p2c_atb_problem *problems, int32_t n);
 P2C_API int p2c_atb_group(const p2c_atb_problem *problems, int32_t n, float *workspace, void *stream);
 
+/* ---- grouped copy (batch staging of a captured step) ------------------------------------------------------------------------
+ * dst[i][0:bytes[i]] = src[i][0:bytes[i]] for up to 24 device buffers in ONE launch: a HIP-graph train step reads fixed
+ * addresses, so the tensors of every new batch the reference's trainer would hand to `training_step`
+ * (modules/flow/base.py:231-246 `_step(batch, ...)`) are copied into the static buffers first. src / dst / bytes are HOST
+ * arrays of n entries (device pointers inside). */
+P2C_API int p2c_copy_group(const void *const *src, void *const *dst, const int64_t *bytes, int32_t n, void *stream);
+
 /* ---- multi-head self-attention over short token sequences (K14) --------------------------------------------------------------
  * The attention of the build's PoseTransformer (reference modules/movements/pose_former/pose_former.py:33-76 binds the
  * third-party PoseTransformer: 26 joint tokens x 8 heads of 4 channels in the spatial blocks, 9 frame tokens x 8 heads of

@@ -1568,3 +1568,40 @@ class LayerNormFunction(torch.autograd.Function):
 
 def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
     return LayerNormFunction.apply(x, weight, bias, eps)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# grouped copy: a new batch into the static buffers of a captured step (one launch)
+# ----------------------------------------------------------------------------------------------------------------------
+class GroupCopy:
+    """``dst[i].copy_(src[i])`` for a FIXED list of contiguous destination tensors in one launch (p2c_copy_group). The
+    destination table is built once; a call costs one pointer per source and one ctypes call. Sources must be contiguous
+    device tensors of the destinations' shapes and dtypes (the caller checks shapes; non-contiguous sources are made so)."""
+    MAX = 24
+
+    def __init__(self, dst: Sequence[Tensor]):
+        self.dst = list(dst)
+        if not self.dst or any((not t.is_cuda) or (not t.is_contiguous()) for t in self.dst):
+            raise RuntimeError('GroupCopy: destinations must be contiguous device tensors')
+        self.device = self.dst[0].device
+        self.chunks = [range(i, min(i + self.MAX, len(self.dst))) for i in range(0, len(self.dst), self.MAX)]
+        self._tables = []
+        for ch in self.chunks:
+            n = len(ch)
+            d = (ctypes.c_void_p * n)(*[self.dst[i].data_ptr() for i in ch])
+            b = (ctypes.c_int64 * n)(*[self.dst[i].numel() * self.dst[i].element_size() for i in ch])
+            self._tables.append((d, b, (ctypes.c_void_p * n)()))
+
+    def __call__(self, src: Sequence[Tensor]):
+        lib = _lib.lib()
+        stream = _stream()
+        keep = []
+        with torch.cuda.device(self.device):
+            for ch, (d, b, s) in zip(self.chunks, self._tables):
+                for k, i in enumerate(ch):
+                    t = src[i]
+                    if not t.is_contiguous():
+                        t = t.contiguous()
+                        keep.append(t)
+                    s[k] = t.data_ptr()
+                _lib.check(lib.p2c_copy_group(s, d, b, len(ch), stream), 'p2c_copy_group')

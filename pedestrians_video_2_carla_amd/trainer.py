@@ -6,7 +6,7 @@ Two execution modes:
   * eager: every launch issued from Python;
   * ``use_graph=True``: the step (model forward, HIP pose head forward/backward, optimizer) is captured once into a
     HIP graph on STATIC batch buffers owned by the trainer and replayed. Every new batch is *staged* first -- copied
-    into the static buffers (one multi-tensor copy) and handed to ``flow.on_train_batch_start`` (per-batch constants:
+    into the static buffers (ONE launch for all tensors, p2c_copy_group) and handed to ``flow.on_train_batch_start`` (per-batch constants:
     skeleton-type index, target-pair counts) -- outside the graph; passing the same batch object again (a resident
     batch, as bench.py does) stages nothing. With more than one rank the gradient all-reduce is captured into the
     step graph when every rank can do so, otherwise it stays outside (capture A: forward + backward; eager RCCL
@@ -82,6 +82,7 @@ class Trainer:
         self._static_loss = None
         self._static_batch = None
         self._staged_src = None
+        self._group_copy = None
         self._unit = None
         self._packed = []
         self._opt_in_backward = False
@@ -244,7 +245,13 @@ class Trainer:
                 raise RuntimeError('graph mode needs batches of one fixed structure: got '
                                    f'{[(k, tuple(v.shape)) for k, v in self._batch_tensors(batch)]} after '
                                    f'{[(k, tuple(v.shape)) for k, v in zip(self._static_names, self._static_dst)]}')
-            torch._foreach_copy_(self._static_dst, src)
+            if self._group_copy is None and src[0].is_cuda and all(d.is_contiguous() for d in self._static_dst):
+                from pedestrians_video_2_carla_amd import ops
+                self._group_copy = ops.GroupCopy(self._static_dst)           # one launch for all tensors of the batch
+            if self._group_copy is not None and all(t.is_cuda and t.device == d.device for t, d in zip(src, self._static_dst)):
+                self._group_copy(src)
+            else:
+                torch._foreach_copy_(self._static_dst, src)
             for k, v in meta.items():                     # lists of strings etc. travel by reference
                 if not isinstance(v, torch.Tensor):
                     self._static_batch[2][k] = v
