@@ -10,7 +10,9 @@ A "step" = training_step (LinearAE forward, HIP pose head forward) + backward (H
 before the timed region (its per-batch constants -- skeleton-type index, target-pair counts: on_train_batch_start -- are
 derived when the batch is staged). Workload at N=1: BASELINE.json's metric configuration (B=256 clips per GPU, T=16, J=26,
 pose_changes output, loss loc_2d_3d); weak scaling: every rank gets its own B clips. On one GPU at this batch the step is
-two launches (csrc/p2c_train.hip).
+two launches (csrc/p2c_train.hip); the trainer captures it, verifies that the captured graph holds exactly the two kernels
+of its one recorded C-ABI call, and then replays the step by making that call (config.direct_replay: a graph launch costs
+~5 us of start-up per replay).
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus
   repeat_ms_per_step  p50 / min / max of five more timed blocks of K steps (one hiccup cannot move the headline unseen)
@@ -646,6 +648,7 @@ def main():
                    'hip_graph': not args.no_graph, 'lean_train_outputs': not args.full_outputs,
                    'deferred_loss_finalize': os.environ.get('P2C_DEFER_FINALIZE', '2') != '0',
                    'two_launch_step': getattr(flow, '_pair_counts', None) is not None,
+                   'direct_replay': getattr(trainer, '_direct', None) is not None,
                    'grad_allreduce_bytes': trainer.flat.nbytes(), 'final_loss': final_loss},
     }
     if repeats:

@@ -463,6 +463,10 @@ P2C_API int p2c_atb_group(const p2c_atb_problem *problems, int32_t n, float *wor
  * arrays of n entries (device pointers inside). */
 P2C_API int p2c_copy_group(const void *const *src, void *const *dst, const int64_t *bytes, int32_t n, void *stream);
 
+/* Inspection: number of nodes / kernel nodes of a hipGraph_t (the trainer replays a captured step by calling its recorded
+ * entry point directly when the graph holds nothing but that entry point's launches). */
+P2C_API int p2c_graph_node_counts(void *graph, int32_t *n_total, int32_t *n_kernel);
+
 /* ---- multi-head self-attention over short token sequences (K14) --------------------------------------------------------------
  * The attention of the build's PoseTransformer (reference modules/movements/pose_former/pose_former.py:33-76 binds the
  * third-party PoseTransformer: 26 joint tokens x 8 heads of 4 channels in the spatial blocks, 9 frame tokens x 8 heads of

@@ -140,6 +140,7 @@ SYMBOLS = {
     'p2c_fold_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp]),
     'p2c_atb_workspace_floats': (_i64, [_i64, _i32, _i32, _i32]),
     'p2c_atb': (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
+    'p2c_graph_node_counts': (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     'p2c_copy_group': (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     'p2c_layernorm_supported': (ctypes.c_int, [_i32]),
     'p2c_layernorm_workspace_floats': (_i64, [_i64, _i32]),

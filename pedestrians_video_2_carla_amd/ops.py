@@ -706,6 +706,10 @@ def count_target_pairs(spec: PoseHeadSpec, gt2d: Tensor, out: Optional[Tensor] =
         return PairCounter(spec, gt2d, out)(gt2d)
 
 
+TRAIN_STEP_RECORDER: Optional[list] = None      # set by the trainer around a capture: every p2c_train_step call is appended
+                                                # (descriptor, gradient pointers, everything they point to)
+
+
 class FusedTrainStepFunction(torch.autograd.Function):
     """(losses (3,), loc_2d, loc_3d, loc_2d_3d) = step(frames; LinearAE parameters): the forward launches NOTHING, the
     backward runs p2c_train_step (LinearAE forward + pose head forward / backward + dgrad per clip, then weight gradient
@@ -771,6 +775,9 @@ class FusedTrainStepFunction(torch.autograd.Function):
             _lib.check(lib.p2c_train_step(ctypes.byref(desc), gl, _stream()), 'p2c_train_step')
         if ctx.fused_opt is not None:
             ctx.fused_opt.fused_steps_applied += 1
+        if TRAIN_STEP_RECORDER is not None:
+            TRAIN_STEP_RECORDER.append({'desc': desc, 'gl': gl, 'device': x.device, 'fused_opt': ctx.fused_opt,
+                                        'keep': (keep, ctx.bufs, g_losses, scalars, ctx.saved_tensors, gws, gbs, ctx.image)})
         head_none = (None,) * 13
         if ctx.sinks is not None:
             return head_none + (None,) * (2 * n)
