@@ -21,6 +21,16 @@ namespace p2c_attn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef P2C_ATTN_TRACE   // developer build only (tools/attntrace.py): shader-clock stamps of workgroup 0's first sequence
+static __device__ unsigned long long g_attn_trace[16];
+#define AT(i)                                                                              \
+  do {                                                                                     \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && s == (int)blockIdx.x) g_attn_trace[i] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define AT(i)
+#endif
+
 struct Args {
   const float *qkv;   // (S, N, 3, Hh, D)
   const float *g_out; // (S, N, Hh*D)        [bwd]
@@ -60,22 +70,69 @@ __device__ __forceinline__ void copy_rows(float *dst, int pitch, const float *sr
   }
 }
 
-// S[h][i][j] = <a_i, b_j>_h for all heads: a rows at `ar` (pitch ap, head h at column h D), b rows at `br` (pitch bp)
+// S[h][i][j] = <a_i, b_j>_h for all heads: a rows at `ar` (pitch ap, head h at column h D), b rows at `br` (pitch bp).
+// The loop bodies are written "all loads, then all FMAs": with one load-use pair per iteration a wave pays one LDS round
+// trip (~100+ cycles) per pair, and a sequence image of 90-120 KB leaves room for only 4 waves on the CU to hide it.
 __device__ __forceinline__ void head_dots(float *S, const float *ar, int ap, const float *br, int bp, float scale, int N, int Hh,
                                           int D, const Div &dN) {
   const int NN = N * N;
+  if (D == 4 || D == 8) {     // narrow heads: a thread owns row (h, i) -- its a_i stays in registers and the b rows are walked
+    for (int row = threadIdx.x; row < Hh * N; row += blockDim.x) {      // with one add per step: ~8 instructions per score
+      const int h = dN.quot(row), i = row - h * N;
+      const float *a = ar + i * ap + h * D, *b = br + h * D;
+      const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a);
+      const f32x4 a1 = (D == 8) ? *reinterpret_cast<const f32x4 *>(a + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      float *out = S + row * N;
+      int j = 0;
+      for (; j + 3 < N; j += 4) {
+        f32x4 bv[4], bw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          bv[u] = *reinterpret_cast<const f32x4 *>(b + (j + u) * bp);
+          if (D == 8) bw[u] = *reinterpret_cast<const f32x4 *>(b + (j + u) * bp + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float s0 = a0[0] * bv[u][0];
+          s0 = fmaf(a0[1], bv[u][1], s0), s0 = fmaf(a0[2], bv[u][2], s0), s0 = fmaf(a0[3], bv[u][3], s0);
+          if (D == 8) s0 = fmaf(a1[0], bw[u][0], s0), s0 = fmaf(a1[1], bw[u][1], s0), s0 = fmaf(a1[2], bw[u][2], s0), s0 = fmaf(a1[3], bw[u][3], s0);
+          out[j + u] = s0 * scale;
+        }
+      }
+      for (; j < N; ++j) {
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(b + j * bp);
+        float s0 = a0[0] * bv[0];
+        s0 = fmaf(a0[1], bv[1], s0), s0 = fmaf(a0[2], bv[2], s0), s0 = fmaf(a0[3], bv[3], s0);
+        if (D == 8) {
+          const f32x4 bw = *reinterpret_cast<const f32x4 *>(b + j * bp + 4);
+          s0 = fmaf(a1[0], bw[0], s0), s0 = fmaf(a1[1], bw[1], s0), s0 = fmaf(a1[2], bw[2], s0), s0 = fmaf(a1[3], bw[3], s0);
+        }
+        out[j] = s0 * scale;
+      }
+    }
+    return;
+  }
   for (int h = 0; h < Hh; ++h)
     for (int r = threadIdx.x; r < NN; r += blockDim.x) {
       const int i = dN.quot(r), j = r - i * N;
       const float *a = ar + i * ap + h * D, *b = br + j * bp + h * D;
-      float s0 = 0.f, s1 = 0.f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
       int d = 0;
+      for (; d + 15 < D; d += 16) {               // 8 x 16-byte loads in flight, then 16 FMAs on four chains
+        f32x4 av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) av[u] = *reinterpret_cast<const f32x4 *>(a + d + 4 * u), bv[u] = *reinterpret_cast<const f32x4 *>(b + d + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          s0 = fmaf(av[u][0], bv[u][0], s0), s1 = fmaf(av[u][1], bv[u][1], s1);
+          s2 = fmaf(av[u][2], bv[u][2], s2), s3 = fmaf(av[u][3], bv[u][3], s3);
+        }
+      }
       for (; d + 3 < D; d += 4) {
         const f32x4 av = *reinterpret_cast<const f32x4 *>(a + d), bv = *reinterpret_cast<const f32x4 *>(b + d);
-        s0 = fmaf(av[0], bv[0], s0), s1 = fmaf(av[1], bv[1], s1), s0 = fmaf(av[2], bv[2], s0), s1 = fmaf(av[3], bv[3], s1);
+        s0 = fmaf(av[0], bv[0], s0), s1 = fmaf(av[1], bv[1], s1), s2 = fmaf(av[2], bv[2], s2), s3 = fmaf(av[3], bv[3], s3);
       }
-      for (; d < D; ++d) s0 = fmaf(a[d], b[d], s0);
-      S[h * NN + r] = (s0 + s1) * scale;
+      S[h * NN + r] = ((s0 + s1) + (s2 + s3)) * scale;
     }
 }
 
@@ -88,7 +145,10 @@ __device__ __forceinline__ void softmax_rows_nb(float *P, int rows, int N) {
     float *p = P + row * N;
     float v[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) v[j] = (j < N) ? p[j] : -3.0e38f;
+    for (int j = 0; j < NB; ++j) {                // (clamped index, not a guarded load: no branch between the loads)
+      const float x = p[j < N ? j : N - 1];
+      v[j] = (j < N) ? x : -3.0e38f;
+    }
     float m = v[0];
 #pragma unroll
     for (int j = 1; j < NB; ++j) m = fmaxf(m, v[j]);
@@ -114,7 +174,11 @@ __device__ __forceinline__ void ds_rows_nb(float *dS, const float *P, int rows, 
     const float *p = P + row * N;
     float dv[NB], pv[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) dv[j] = (j < N) ? ds[j] : 0.f, pv[j] = (j < N) ? p[j] : 0.f;
+    for (int j = 0; j < NB; ++j) {
+      const int jc = j < N ? j : N - 1;
+      const float a_ = ds[jc], b_ = p[jc];
+      dv[j] = (j < N) ? a_ : 0.f, pv[j] = (j < N) ? b_ : 0.f;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int j = 0; j < NB; ++j) rs = fmaf(dv[j], pv[j], rs);
@@ -122,6 +186,38 @@ __device__ __forceinline__ void ds_rows_nb(float *dS, const float *P, int rows, 
     for (int j = 0; j < NB; ++j)
       if (j < N) ds[j] = pv[j] * (dv[j] - rs) * scale;
   }
+}
+// both row passes of the backward in one: the thread that owns row (h, i) reads scores and dP once
+template <int NB>
+__device__ __forceinline__ void softmax_ds_rows_nb(float *P, float *dS, int rows, int N, float scale) {
+  for (int row = threadIdx.x; row < rows; row += blockDim.x) {
+    float *p = P + row * N, *ds = dS + row * N;
+    float v[NB], dv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int jc = j < N ? j : N - 1;
+      const float x = p[jc], y = ds[jc];
+      v[j] = (j < N) ? x : -3.0e38f, dv[j] = (j < N) ? y : 0.f;
+    }
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < NB; ++j) m = fmaxf(m, v[j]);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = __expf(v[j] - m), sum += v[j];
+    const float inv = 1.f / sum;
+    float rs = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] *= inv, rs = fmaf(dv[j], v[j], rs);
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j < N) p[j] = v[j], ds[j] = v[j] * (dv[j] - rs) * scale;
+  }
+}
+__device__ __forceinline__ void softmax_ds_rows(float *P, float *dS, int rows, int N, float scale) {
+  if (N <= 16) softmax_ds_rows_nb<16>(P, dS, rows, N, scale);
+  else if (N <= 32) softmax_ds_rows_nb<32>(P, dS, rows, N, scale);
+  else softmax_ds_rows_nb<64>(P, dS, rows, N, scale);
 }
 __device__ __forceinline__ void ds_rows(float *dS, const float *P, int rows, int N, float scale) {
   if (N <= 16) ds_rows_nb<16>(dS, P, rows, N, scale);
@@ -136,17 +232,61 @@ __device__ __forceinline__ void ds_rows(float *dS, const float *P, int rows, int
 template <int NB>
 __device__ __forceinline__ void channel_contract(const float *m, int sn, int sk, const float *x, int xp, float *y, int yp, int N) {
   float xv[NB];
+  int ko[NB];
 #pragma unroll
-  for (int k = 0; k < NB; ++k) xv[k] = (k < N) ? x[k * xp] : 0.f;
+  for (int k = 0; k < NB; ++k) {                  // clamped indices, zero weights beyond N: no branch between the loads
+    const int kc = k < N ? k : N - 1;
+    const float v = x[kc * xp];
+    xv[k] = (k < N) ? v : 0.f;
+    ko[k] = kc * sk;
+  }
   for (int n = 0; n < N; ++n) {
+    float mv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) mv[k] = m[n * sn + ko[k]];
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-    for (int k = 0; k < NB; k += 2) {
-      if (k < N) a0 = fmaf(m[n * sn + k * sk], xv[k], a0);
-      if (k + 1 < N) a1 = fmaf(m[n * sn + (k + 1) * sk], xv[k + 1], a1);
-    }
+    for (int k = 0; k < NB; k += 2) a0 = fmaf(mv[k], xv[k], a0), a1 = fmaf(mv[k + 1], xv[k + 1], a1);
     y[n * yp] = a0 + a1;
   }
+}
+
+// Narrow heads (D = 4 or 8): a thread owns all D channels of one (head, token) output: y[0..D) = sum_k m[k * sk] * x_k[0..D)
+// with x_k one or two 16-byte LDS reads (wave-uniform per head: broadcast) and m a scalar read -- 6 instructions per four
+// products where the one-output-per-thread loop needs 12, and one index split per D outputs.
+template <int D>
+__device__ __forceinline__ void vec_contract(const float *m, int sk, const float *x, int xp, float *y, int N) {
+  f32x4 acc[D / 4];
+#pragma unroll
+  for (int v = 0; v < D / 4; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 3 < N; k += 4) {
+    float mv[4];
+    f32x4 xv[4][D / 4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      mv[u] = m[(k + u) * sk];
+#pragma unroll
+      for (int v = 0; v < D / 4; ++v) xv[u][v] = *reinterpret_cast<const f32x4 *>(x + (k + u) * xp + 4 * v);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < D / 4; ++v)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[v][c] = fmaf(mv[u], xv[u][v][c], acc[v][c]);
+  }
+  for (; k < N; ++k) {
+    const float mv = m[k * sk];
+#pragma unroll
+    for (int v = 0; v < D / 4; ++v) {
+      const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + k * xp + 4 * v);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[v][c] = fmaf(mv, xv[c], acc[v][c]);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < D / 4; ++v) *reinterpret_cast<f32x4 *>(y + 4 * v) = acc[v];
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const Args a) {
@@ -175,17 +315,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const Args a) {
     // out[i][e] = sum_j P[h(e)][i][j] v[j][e], one output per thread and round (lanes walk over e: conflict-free v reads,
     // broadcast P reads)
     float *o = a.out + (size_t)s * N * E;
-    if (E >= (int)blockDim.x && N <= 16) {
+    if (D == 4 || D == 8) {                        // thread (h, i): the D channels of head h of query i
+      for (int row = threadIdx.x; row < Hh * N; row += blockDim.x) {
+        const int h = dN.quot(row), i = row - h * N;
+        if (D == 4) vec_contract<4>(P + row * N, 1, rows + 2 * E + h * D, RP, o + i * E + h * D, N);
+        else vec_contract<8>(P + row * N, 1, rows + 2 * E + h * D, RP, o + i * E + h * D, N);
+      }
+    } else if (E >= (int)blockDim.x && N <= 16) {
       for (int e = threadIdx.x; e < E; e += blockDim.x)
-        channel_contract<16>(P + dD.quot(e) * NN, N, 1, rows + 2 * E + e, RP, o + e, E, N);
+        if (N <= 12) channel_contract<12>(P + dD.quot(e) * NN, N, 1, rows + 2 * E + e, RP, o + e, E, N);
+        else channel_contract<16>(P + dD.quot(e) * NN, N, 1, rows + 2 * E + e, RP, o + e, E, N);
     } else
     for (int idx = threadIdx.x; idx < N * E; idx += blockDim.x) {
       const int i = dE.quot(idx), e = idx - i * E, h = dD.quot(e);
       const float *v = rows + 2 * E + e, *p = P + h * NN + i * N;
       float a0 = 0.f, a1 = 0.f;
       int j = 0;
-      for (; j + 1 < N; j += 2) a0 = fmaf(p[j], v[j * RP], a0), a1 = fmaf(p[j + 1], v[(j + 1) * RP], a1);
-      if (j < N) a0 = fmaf(p[j], v[j * RP], a0);
+      for (; j + 3 < N; j += 4) {
+        const float p0 = p[j], p1 = p[j + 1], p2 = p[j + 2], p3 = p[j + 3];
+        const float v0 = v[j * RP], v1 = v[(j + 1) * RP], v2 = v[(j + 2) * RP], v3 = v[(j + 3) * RP];
+        a0 = fmaf(p0, v0, a0), a1 = fmaf(p1, v1, a1), a0 = fmaf(p2, v2, a0), a1 = fmaf(p3, v3, a1);
+      }
+      for (; j < N; ++j) a0 = fmaf(p[j], v[j * RP], a0);
       o[idx] = a0 + a1;
     }
     __syncthreads();                               // the image is rewritten by the next sequence
@@ -199,9 +350,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const Args a) {
   float *rows = lds, *dO = rows + N * RP, *P = dO + N * GP, *dS = P + Hh * NN;
   const Div dN(N), dRow(3 * E >> 2), dG(E >> 2), dD(D), d3E(3 * E);
   for (int s = blockIdx.x; s < a.S; s += gridDim.x) {
+    AT(0);
     copy_rows(rows, RP, a.qkv + (size_t)s * N * 3 * E, N, 3 * E, dRow);
     copy_rows(dO, GP, a.g_out + (size_t)s * N * E, N, E, dG);
     __syncthreads();
+    AT(1);
     if (vec) {
       head_dots(P, rows, RP, rows + E, RP, a.scale, N, Hh, D, dN);            // scores
       head_dots(dS, dO, GP, rows + 2 * E, RP, 1.f, N, Hh, D, dN);              // dP[h][i][j] = <dO_i, v_j>_h
@@ -218,19 +371,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const Args a) {
         }
     }
     __syncthreads();
-    softmax_rows(P, Hh * N, N);
+    AT(2);
+    softmax_ds_rows(P, dS, Hh * N, N, a.scale);    // P = softmax(scores); dS = P * (dP - sum_j dP P), times the score scale
     __syncthreads();
-    ds_rows(dS, P, Hh * N, N, a.scale);            // dS = P * (dP - sum_j dP P), times the score scale
-    __syncthreads();
+    AT(3);
     // one gradient element per thread and round (lanes walk over the 3E channels c of token n):
     //   dQ[n][e] = sum_j dS[n][j] k[j][e];  dK[n][e] = sum_i dS[i][n] q[i][e];  dV[n][e] = sum_i P[i][n] dO[i][e]
     float *g = a.g_qkv + (size_t)s * N * 3 * E;
-    if (E >= (int)blockDim.x && N <= 16) {
+    if (D == 4 || D == 8) {                        // thread (q | k | v, h, n): the D channels of that head and token
+      const int per = Hh * N;
+      for (int r = threadIdx.x; r < 3 * per; r += blockDim.x) {
+        const int which = (r >= 2 * per) ? 2 : (r >= per ? 1 : 0), row = r - which * per, h = dN.quot(row), n = row - h * N;
+        const float *m = (which == 2 ? P : dS) + h * NN + (which == 0 ? n * N : n);
+        const float *x = (which == 0 ? rows + E : (which == 1 ? rows : dO)) + h * D;
+        float *y = g + n * 3 * E + which * E + h * D;
+        if (D == 4) vec_contract<4>(m, which == 0 ? 1 : N, x, which == 2 ? GP : RP, y, N);
+        else vec_contract<8>(m, which == 0 ? 1 : N, x, which == 2 ? GP : RP, y, N);
+      }
+    } else if (E >= (int)blockDim.x && N <= 16) {
       for (int c = threadIdx.x; c < 3 * E; c += blockDim.x) {
         const int which = (c >= 2 * E) ? 2 : (c >= E ? 1 : 0), e = c - which * E, h = dD.quot(e);
         const float *m = (which == 2 ? P : dS) + h * NN;
         const float *x = (which == 0) ? rows + E + e : (which == 1 ? rows + e : dO + e);
-        channel_contract<16>(m, which == 0 ? N : 1, which == 0 ? 1 : N, x, which == 2 ? GP : RP, g + c, 3 * E, N);
+        if (N <= 12) channel_contract<12>(m, which == 0 ? N : 1, which == 0 ? 1 : N, x, which == 2 ? GP : RP, g + c, 3 * E, N);
+        else channel_contract<16>(m, which == 0 ? N : 1, which == 0 ? 1 : N, x, which == 2 ? GP : RP, g + c, 3 * E, N);
       }
     } else
     for (int idx = threadIdx.x; idx < N * 3 * E; idx += blockDim.x) {
@@ -241,11 +405,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const Args a) {
       const int xp = (which == 2) ? GP : RP, sk = (which == 0) ? 1 : N;
       float a0 = 0.f, a1 = 0.f;
       int k = 0;
-      for (; k + 1 < N; k += 2) a0 = fmaf(m[k * sk], x[k * xp], a0), a1 = fmaf(m[(k + 1) * sk], x[(k + 1) * xp], a1);
-      if (k < N) a0 = fmaf(m[k * sk], x[k * xp], a0);
+      for (; k + 3 < N; k += 4) {
+        const float m0 = m[k * sk], m1 = m[(k + 1) * sk], m2 = m[(k + 2) * sk], m3 = m[(k + 3) * sk];
+        const float x0 = x[k * xp], x1 = x[(k + 1) * xp], x2 = x[(k + 2) * xp], x3 = x[(k + 3) * xp];
+        a0 = fmaf(m0, x0, a0), a1 = fmaf(m1, x1, a1), a0 = fmaf(m2, x2, a0), a1 = fmaf(m3, x3, a1);
+      }
+      for (; k < N; ++k) a0 = fmaf(m[k * sk], x[k * xp], a0);
       g[idx] = a0 + a1;
     }
     __syncthreads();
+    AT(4);
   }
 }
 
@@ -312,3 +481,9 @@ extern "C" int p2c_attn_small_bwd(const float *qkv, const float *g_out, float *g
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+
+#ifdef P2C_ATTN_TRACE
+extern "C" __attribute__((visibility("default"))) int p2c_debug_attn_trace(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_attn::g_attn_trace), sizeof(unsigned long long) * 16);
+}
+#endif
