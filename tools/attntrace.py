@@ -19,3 +19,5 @@ names = ['copy-in', 'scores + dP', 'softmax + dS', 'gradients out']
 for i, n in enumerate(names):
     print(f'{n:16s} {t[i + 1] - t[i]:8d} cycles')
 print('sequence total  ', t[4] - t[0])
+if t[5]:
+    print('  dQ', t[5] - t[3], 'dK', t[6] - t[5], 'dV', t[7] - t[6], 'drain + barrier', t[4] - t[7])
