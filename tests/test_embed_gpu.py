@@ -86,3 +86,81 @@ def test_errors():
         ops.joint_embeddings(torch.zeros(2, 4, 26, 2), ws, bs)
     with pytest.raises(RuntimeError):
         ops.joint_embeddings(torch.zeros(2, 4, 25, 2, device=d), ws, bs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('G,J,E,C,acc', [(256, 26, 64, 2, False), (7, 5, 20, 3, True), (33, 3, 130, 4, False), (1, 1, 4, 1, True)])
+def test_fold_kernels_match_fp64(G, J, E, C, acc):
+    """K7a' (p2c_fold_fwd / p2c_fold_bwd) on cfg3's shape and on odd ones (gate rows not a multiple of the 16 row groups, more
+    than 64 channels per joint, C = 1..4), strided parameter blocks, against the composition written out in fp64: w_eff, b_eff,
+    and from given output gradients d W_ih (written or accumulated), d W_j / d b_j (accumulated) and the two bias gradients."""
+    import ctypes
+    import torch
+    from pedestrians_video_2_carla_amd import _lib, ops
+    d = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(G * 7 + J)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    w_ih, W, b, b_ih, b_hh = rnd(G, J * E), rnd(J, E, C), rnd(J, E), rnd(G), rnd(G)
+    g_eff, g_b = rnd(G, J * C), rnd(G)
+    w3 = w_ih.view(G, J, E)
+    w_eff_ref = torch.einsum('gje,jec->gjc', w3, W).reshape(G, J * C)
+    b_eff_ref = torch.einsum('gje,je->g', w3, b) + b_ih + b_hh
+    g3 = g_eff.view(G, J, C)
+    g_w_ref = (torch.einsum('gjc,jec->gje', g3, W) + g_b.view(G, 1, 1) * b.unsqueeze(0)).reshape(G, J * E)
+    gW_ref, gb_ref = torch.einsum('gjc,gje->jec', g3, w3), torch.einsum('g,gje->je', g_b, w3)
+
+    f = lambda t: t.float().to(d).contiguous()
+    pad = 3                                                     # parameter blocks with a stride, like views of a flat buffer
+    Wb, bb = torch.zeros(J, E * C + pad, device=d), torch.zeros(J, E + pad, device=d)
+    Wb[:, :E * C], bb[:, :E] = f(W).view(J, -1), f(b)
+    gWb, gbb = torch.ones_like(Wb), torch.ones_like(bb)
+    w_ih_d, b_ih_d, b_hh_d = f(w_ih), f(b_ih), f(b_hh)
+    w_eff, b_eff = torch.empty(G, J * C, device=d), torch.empty(G, device=d)
+    lib, st = _lib.lib(), ops._stream()
+    _lib.check(lib.p2c_fold_fwd(w_ih_d.data_ptr(), Wb.data_ptr(), bb.data_ptr(), Wb.stride(0), bb.stride(0), b_ih_d.data_ptr(),
+                                b_hh_d.data_ptr(), w_eff.data_ptr(), b_eff.data_ptr(), G, J, E, C, st), 'p2c_fold_fwd')
+    g_w = torch.ones(G, J * E, device=d) if acc else torch.empty(G, J * E, device=d)
+    g_bi, g_bh = torch.ones(G, device=d), torch.ones(G, device=d)
+    g_eff_d, g_b_d = f(g_eff), f(g_b)                            # (kept alive: the library sees raw pointers)
+    _lib.check(lib.p2c_fold_bwd(w_ih_d.data_ptr(), Wb.data_ptr(), bb.data_ptr(), Wb.stride(0), bb.stride(0), g_eff_d.data_ptr(),
+                                g_b_d.data_ptr(), g_w.data_ptr(), int(acc), gWb.data_ptr(), gbb.data_ptr(), g_bi.data_ptr(),
+                                g_bh.data_ptr(), G, J, E, C, st), 'p2c_fold_bwd')
+
+    def close(a, ref, what, rtol=2e-5):
+        a, ref = a.double().cpu(), ref
+        err, sc = (a - ref).abs().max().item(), max(ref.abs().max().item(), 1e-6)
+        assert err <= rtol * sc * max(1.0, G ** 0.5), f'{what}: {err:.3e} vs scale {sc:.3e}'
+    close(w_eff, w_eff_ref, 'w_eff'), close(b_eff, b_eff_ref, 'b_eff')
+    close(g_w, g_w_ref + (1 if acc else 0), 'd w_ih')
+    close(gWb[:, :E * C].reshape(J, E, C), gW_ref + 1, 'd W_j'), close(gbb[:, :E], gb_ref + 1, 'd b_j')
+    assert (gWb[:, E * C:] == 1).all() and (gbb[:, E:] == 1).all()          # the padding between the blocks is untouched
+    close(g_bi, g_b + 1, 'd b_ih'), close(g_bh, g_b + 1, 'd b_hh')
+
+
+@pytest.mark.gpu
+def test_group_copy_matches_per_tensor_copies():
+    """p2c_copy_group through ops.GroupCopy: 30 tensors (two launches of <= 24), sizes from 0 to 3 MB, odd byte counts and
+    int32 / uint8 payloads, a non-contiguous source -- every destination equals its source, nothing else is touched."""
+    import torch
+    from pedestrians_video_2_carla_amd import ops
+    d = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(1)
+    shapes = [(0,), (1,), (3,), (5, 7), (256, 16, 26, 2), (256, 16, 26, 3, 3), (1025,), (17, 3)] * 3 + [(33,), (2, 2), (9,), (4, 4, 4), (1,), (7,)]
+    dst, src = [], []
+    for i, shp in enumerate(shapes):
+        if i % 7 == 3:
+            s = torch.randint(0, 100, shp, generator=g, dtype=torch.int32).to(d)
+        elif i % 7 == 5:
+            s = torch.randint(0, 255, shp, generator=g, dtype=torch.uint8).to(d)
+        else:
+            s = torch.randn(*shp, generator=g).to(d)
+        src.append(s)
+        dst.append(torch.full_like(s, 7))
+    src[4] = src[4].transpose(1, 2).contiguous().transpose(1, 2)          # same values, non-contiguous view
+    guard = torch.full((1024,), 3.0, device=d)
+    copy = ops.GroupCopy(dst)
+    copy(src)
+    torch.cuda.synchronize()
+    for a, b in zip(dst, src):
+        assert torch.equal(a, b)
+    assert (guard == 3).all()
