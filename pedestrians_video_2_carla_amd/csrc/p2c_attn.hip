@@ -253,32 +253,6 @@ __device__ __forceinline__ void softmax_rows_nb(float *P, int rows, int N) {
       if (j < N) p[j] = v[j] * inv;
   }
 }
-__device__ __forceinline__ void softmax_rows(float *P, int rows, int N) {
-  if (N <= 16) softmax_rows_nb<16>(P, rows, N);
-  else if (N <= 32) softmax_rows_nb<32>(P, rows, N);
-  else softmax_rows_nb<64>(P, rows, N);
-}
-// dS = P * (dP - sum_j dP P) * scale, row by row, same register scheme
-template <int NB>
-__device__ __forceinline__ void ds_rows_nb(float *dS, const float *P, int rows, int N, float scale) {
-  for (int row = threadIdx.x; row < rows; row += blockDim.x) {
-    float *ds = dS + row * N;
-    const float *p = P + row * N;
-    float dv[NB], pv[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int jc = j < N ? j : N - 1;
-      const float mk = (j < N) ? 1.f : 0.f;
-      dv[j] = ds[jc] * mk, pv[j] = p[jc] * mk;
-    }
-    float rs = 0.f;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) rs = fmaf(dv[j], pv[j], rs);
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-      if (j < N) ds[j] = pv[j] * (dv[j] - rs) * scale;
-  }
-}
 // both row passes of the backward in one: the thread that owns row (h, i) reads scores and dP once
 template <int NB>
 __device__ __forceinline__ void softmax_ds_rows_nb(float *P, float *dS, int rows, int N, float scale) {
@@ -306,17 +280,6 @@ __device__ __forceinline__ void softmax_ds_rows_nb(float *P, float *dS, int rows
       if (j < N) p[j] = v[j], ds[j] = v[j] * (dv[j] - rs) * scale;
   }
 }
-__device__ __forceinline__ void softmax_ds_rows(float *P, float *dS, int rows, int N, float scale) {
-  if (N <= 16) softmax_ds_rows_nb<16>(P, dS, rows, N, scale);
-  else if (N <= 32) softmax_ds_rows_nb<32>(P, dS, rows, N, scale);
-  else softmax_ds_rows_nb<64>(P, dS, rows, N, scale);
-}
-__device__ __forceinline__ void ds_rows(float *dS, const float *P, int rows, int N, float scale) {
-  if (N <= 16) ds_rows_nb<16>(dS, P, rows, N, scale);
-  else if (N <= 32) ds_rows_nb<32>(dS, P, rows, N, scale);
-  else ds_rows_nb<64>(dS, P, rows, N, scale);
-}
-
 // Narrow heads (D = 4 or 8): a thread owns all D channels of one (head, token) output: y[0..D) = sum_k m[k * sk] * x_k[0..D)
 // with x_k one or two 16-byte LDS reads (wave-uniform per head: broadcast) and m a scalar read -- 6 instructions per four
 // products where the one-output-per-thread loop needs 12, and one index split per D outputs.

@@ -86,10 +86,11 @@ def test_cfg5_train_steps_through_the_flow_with_lr_schedule():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('S,N,heads,hd', [(37, 26, 8, 4), (11, 9, 8, 104), (5, 1, 2, 6), (3, 17, 3, 12)])
+@pytest.mark.parametrize('S,N,heads,hd', [(37, 26, 8, 4), (11, 9, 8, 104), (5, 1, 2, 6), (3, 17, 3, 12), (6, 16, 2, 16), (4, 12, 4, 8),
+                                          (2, 33, 2, 12), (3, 40, 1, 4), (300, 5, 3, 20)])
 def test_small_attention_matches_fp64(S, N, heads, hd):
     """K14 (p2c_attn_small_fwd/_bwd) on PoseTransformer's two shapes (26 joint tokens x 8 heads x 4, 9 frame tokens x 8 x 104) and
-    two odd ones against softmax(scale q k^T) v written out in fp64: output and the gradient of qkv, 1e-5 relative."""
+    on every kernel family and row width (narrow 4 / 8, matrix-core wide, generic vector and scalar; N <= 16 / 32 / 64) against softmax(scale q k^T) v written out in fp64: output and the gradient of qkv, 1e-5 relative."""
     import torch
     from pedestrians_video_2_carla_amd import ops
     d = torch.device('cuda:0')
