@@ -60,12 +60,14 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
   auto step = [&](const FrameIn<K::NY> &cur, int t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
     M3 c;
+    float yin[K::NY];
+    rotation_input<K::NY>(cur, ptrs, yin);
     if (K::SIXD) {
       SixD s;
-      c = rot6d_fwd(cur.y, s);
+      c = rot6d_fwd(yin, s);
     } else {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) c.m[i] = cur.y[i];
+      for (int i = 0; i < 9; ++i) c.m[i] = yin[i];
     }
     R = K::SCAN ? mul(c, R) : c;  // p3d_pose.py:98-114
     if (MAT && L.active) {
@@ -84,12 +86,14 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
     if (MAT && W.on) world_store(d, L, t, W);
     frame_head<MAT ? MODE_FWD_MATERIALIZE : MODE_FWD>(d, L, t, x, W, acc, 0.f, 0.f, nullptr, nullptr, cur.g2, cur.g3);
   };
+  // (the prefetch is unconditional: past the last frame a buffer load reads the next clip's rows or, out of range, zeros --
+  // never used; a guard around it is a join at which the wait for THIS frame's loads would also cover the prefetch)
   load_frame<K::NY, 1>(L, ptrs, fa);
   for (int t = 0; t < T; t += 2) {
-    if (t + 1 < T) load_frame<K::NY, 1>(L, ptrs, fb);
+    load_frame<K::NY, 1>(L, ptrs, fb);
     step(fa, t);
     if (t + 1 < T) {
-      if (t + 2 < T) load_frame<K::NY, 1>(L, ptrs, fa);
+      load_frame<K::NY, 1>(L, ptrs, fa);
       step(fb, t + 1);
     }
   }
@@ -148,14 +152,16 @@ __global__ __launch_bounds__(256) void pose_head_rot_bwd(const p2c_pose_head_des
   load_frame<K::NY, -1>(L, ptrs, cur);
   for (int t = T - 1; t >= 0; --t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
-    if (t > 0) load_frame<K::NY, -1>(L, ptrs, nxt);
+    load_frame<K::NY, -1>(L, ptrs, nxt);       // (unconditional: before frame 0 the offsets wrap out of range -> zeros, unused)
     M3 c;
     SixD s;
+    float yin[K::NY];
+    rotation_input<K::NY>(cur, ptrs, yin);
     if (K::SIXD) {
-      c = rot6d_fwd(cur.y, s);
+      c = rot6d_fwd(yin, s);
     } else {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) c.m[i] = cur.y[i];
+      for (int i = 0; i < 9; ++i) c.m[i] = yin[i];
     }
     if (!K::SCAN) R = c;
     // ---- forward of this frame ----
@@ -278,9 +284,11 @@ __global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(
   load_frame<6, -1>(L, ptrs, cur);
   float *gy = L.active ? grad_y + (((size_t)L.clip * T + (T - 1)) * J + L.j) * 6 : nullptr;
   for (int t = T - 1; t >= 0; --t) {
-    if (t > 0) load_frame<6, -1>(L, ptrs, nxt);
+    load_frame<6, -1>(L, ptrs, nxt);           // (unconditional: before frame 0 the offsets wrap out of range -> zeros, unused)
     SixD s;
-    M3 c = rot6d_fwd(cur.y, s);
+    float yin[6];
+    rotation_input<6>(cur, ptrs, yin);
+    M3 c = rot6d_fwd(yin, s);
     if (!K::SCAN) R = c;
     M3 A = R;
     V3 x = l;
@@ -382,12 +390,14 @@ __global__ __launch_bounds__(1024) void pose_head_rot_fwd_tp(const p2c_pose_head
   FramePtrs ptrs = frame_ptrs<K::NY>(d, L, t);
   load_frame<K::NY, 1>(L, ptrs, cur);
   M3 c;
+  float yin[K::NY];
+  rotation_input<K::NY>(cur, ptrs, yin);
   if (K::SIXD) {
     SixD s;
-    c = rot6d_fwd(cur.y, s);
+    c = rot6d_fwd(yin, s);
   } else {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) c.m[i] = cur.y[i];
+    for (int i = 0; i < 9; ++i) c.m[i] = yin[i];
   }
   M3 R = c;
   if (K::SCAN) R = mul(scan_time(c, t, L.j, T, tp_lds, plane), Rref);
@@ -475,7 +485,9 @@ __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_p
     loss_coefs(d, grad_losses, coef2, coef3);
   }
   SixD s;
-  const M3 c = rot6d_fwd(cur.y, s);
+  float yin6[6];
+  rotation_input<6>(cur, ptrs, yin6);
+  const M3 c = rot6d_fwd(yin6, s);
   M3 R = c;
   if (K::SCAN) R = mul(scan_time(c, t, L.j, T, tp_lds, plane), Rref);
   M3 A = R;
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc
   load_frame<3, 1>(L, ptrs, cur);
   for (int t = 0; t < T; ++t) {
     const size_t jf = ((size_t)L.clip * T + t) * J + L.j;
-    if (t + 1 < T) load_frame<3, 1>(L, ptrs, nxt);
+    load_frame<3, 1>(L, ptrs, nxt);            // (unconditional prefetch: past the last frame the values are never used)
     V3 yin = v3(cur.y[0], cur.y[1], cur.y[2]);
     const bool up = L.base != 0;
     V3 h = v3(group_bcast(yin.x, HIPS, up), group_bcast(yin.y, HIPS, up), group_bcast(yin.z, HIPS, up));

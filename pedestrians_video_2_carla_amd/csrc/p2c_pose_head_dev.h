@@ -584,42 +584,78 @@ struct FrameIn {
   float g2[2];
   float g3[3];
 };
-// per-lane read cursors: computed once, then advanced by one frame (a constant stride) per iteration
+// Per-lane read cursors, computed once and advanced by one frame (a constant stride) per iteration. The frame inputs go
+// through BUFFER loads whose range check stands in for `if (active)` / `if (has2)` / `if (has3)`: a lane without the input
+// addresses past num_records and reads zeros. Guarded loads put exec-masked branches into the frame loop, and at their joins
+// the compiler's waitcnt pass falls back to vmcnt(0) -- the loads of frame t + 1, issued one line earlier as a software
+// prefetch, were waited for before frame t was computed (measured: see DESIGN section 5, large-batch pose head). The descriptors
+// are per wave (base = the wave's first clip, records = the one or two clips the wave owns): offsets stay small for any B.
+typedef unsigned int fb_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int fb_u32x3 __attribute__((ext_vector_type(3)));
+typedef unsigned int fb_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int FRAME_OOB = 0x7fffff00;
 struct FramePtrs {
-  const float *y, *g2, *g3;
-  int sy, s2, s3;  // floats per frame
+  __amdgpu_buffer_rsrc_t y, g2, g3;
+  int oy, o2, o3;      // byte offset of this lane's current frame (FRAME_OOB for a lane without that input)
+  int sy, s2, s3;      // bytes per frame (0 for such a lane)
+  float idle;          // 1 for lanes that hold the identity rotation
 };
 template <int NY>
 __device__ __forceinline__ FramePtrs frame_ptrs(const p2c_pose_head_desc &d, const LaneCtx &L, int t) {
   FramePtrs p;
-  const size_t frame = (size_t)L.clip * d.T + t;
-  p.sy = J * NY, p.s2 = d.gt2d_joints * d.gt2d_channels, p.s3 = d.gt3d_joints * 3;
-  p.y = L.active ? d.y + (frame * J + L.j) * NY : nullptr;
-  p.g2 = L.has2 ? d.gt2d + (frame * d.gt2d_joints + L.gm2) * d.gt2d_channels : nullptr;
-  p.g3 = L.has3 ? d.gt3d + (frame * d.gt3d_joints + L.gm3) * 3 : nullptr;
+  const int clip0 = __builtin_amdgcn_readfirstlane(L.clip);          // lane 0's clip = the wave's first
+  const int avail = clip0 < d.B ? (d.B - clip0 < 2 ? d.B - clip0 : 2) : 0;
+  const int fy = J * NY * 4, f2 = d.gt2d_joints * d.gt2d_channels * 4, f3 = d.gt3d_joints * 3 * 4;   // bytes per frame
+  const int cy = d.T * fy, c2 = d.T * f2, c3 = d.T * f3;                                                // bytes per clip
+  auto rsrc = [&](const float *base, int clip_bytes) {
+    const uintptr_t q = reinterpret_cast<uintptr_t>(base) + (size_t)clip0 * clip_bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(q), 0, base ? avail * clip_bytes : 0, 0x00020000);
+  };
+  p.y = rsrc(d.y, cy), p.g2 = rsrc(d.gt2d, c2), p.g3 = rsrc(d.gt3d, c3);
+  const int lc = L.clip - clip0;
+  p.oy = L.active ? lc * cy + (t * J + L.j) * NY * 4 : FRAME_OOB, p.sy = L.active ? fy : 0;
+  p.o2 = L.has2 ? lc * c2 + (t * d.gt2d_joints + L.gm2) * d.gt2d_channels * 4 : FRAME_OOB, p.s2 = L.has2 ? f2 : 0;
+  p.o3 = L.has3 ? lc * c3 + (t * d.gt3d_joints + L.gm3) * 12 : FRAME_OOB, p.s3 = L.has3 ? f3 : 0;
+  p.idle = L.active ? 0.f : 1.f;
   return p;
 }
+// Idle lanes (joint slots 26..31, clips beyond the batch) read zeros; where a frame's y is CONSUMED they become the identity
+// rotation (added at the use, not at the load: an add right behind the load would wait for the prefetch it has just issued).
+template <int NY>
+__device__ __forceinline__ void rotation_input(const FrameIn<NY> &f, const FramePtrs &p, float (&y)[NY]) {
+#pragma unroll
+  for (int i = 0; i < NY; ++i) y[i] = f.y[i];
+  if (NY == 6) y[0] += p.idle, y[4] += p.idle;
+  if (NY == 9) y[0] += p.idle, y[4] += p.idle, y[8] += p.idle;
+}
+typedef float fb_f32x2 __attribute__((ext_vector_type(2)));
+typedef float fb_f32x3 __attribute__((ext_vector_type(3)));
+typedef float fb_f32x4 __attribute__((ext_vector_type(4)));
+// (the loaded vectors are re-typed as WHOLE vectors: element-wise bit casts of the integer vector make this compiler keep only
+// the first dword of the load)
 template <int NY, int DIR>
 __device__ __forceinline__ void load_frame(const LaneCtx &L, FramePtrs &p, FrameIn<NY> &f) {
-  if (L.active) {
-    load_y<NY>(p.y, 0, f.y);
-    p.y += DIR * p.sy;
-  } else {  // identity rotation / zero location for idle lanes
-#pragma unroll
-    for (int i = 0; i < NY; ++i) f.y[i] = 0.f;
-    if (NY == 6) f.y[0] = 1.f, f.y[4] = 1.f;
-    if (NY == 9) f.y[0] = 1.f, f.y[4] = 1.f, f.y[8] = 1.f;
+  (void)L;
+  if constexpr (NY == 6) {
+    const fb_f32x4 a = __builtin_bit_cast(fb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(p.y, p.oy, 0, 0));
+    const fb_f32x2 b = __builtin_bit_cast(fb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(p.y, p.oy + 16, 0, 0));
+    f.y[0] = a[0], f.y[1] = a[1], f.y[2] = a[2], f.y[3] = a[3], f.y[4] = b[0], f.y[5] = b[1];
+  } else if constexpr (NY == 9) {
+    const fb_f32x4 a = __builtin_bit_cast(fb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(p.y, p.oy, 0, 0));
+    const fb_f32x4 b = __builtin_bit_cast(fb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(p.y, p.oy + 16, 0, 0));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(p.y, p.oy + 32, 0, 0));
+    f.y[0] = a[0], f.y[1] = a[1], f.y[2] = a[2], f.y[3] = a[3];
+    f.y[4] = b[0], f.y[5] = b[1], f.y[6] = b[2], f.y[7] = b[3], f.y[8] = c;
+  } else {
+    static_assert(NY == 3, "frame inputs are 6-D rotations, 3x3 matrices or 3-D locations");
+    const fb_f32x3 a = __builtin_bit_cast(fb_f32x3, __builtin_amdgcn_raw_buffer_load_b96(p.y, p.oy, 0, 0));
+    f.y[0] = a[0], f.y[1] = a[1], f.y[2] = a[2];
   }
-  f.g2[0] = f.g2[1] = 0.f;
-  f.g3[0] = f.g3[1] = f.g3[2] = 0.f;
-  if (L.has2) {
-    f.g2[0] = p.g2[0], f.g2[1] = p.g2[1];
-    p.g2 += DIR * p.s2;
-  }
-  if (L.has3) {
-    f.g3[0] = p.g3[0], f.g3[1] = p.g3[1], f.g3[2] = p.g3[2];
-    p.g3 += DIR * p.s3;
-  }
+  const fb_f32x2 g2 = __builtin_bit_cast(fb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(p.g2, p.o2, 0, 0));
+  const fb_f32x3 g3 = __builtin_bit_cast(fb_f32x3, __builtin_amdgcn_raw_buffer_load_b96(p.g3, p.o3, 0, 0));
+  f.g2[0] = g2[0], f.g2[1] = g2[1];
+  f.g3[0] = g3[0], f.g3[1] = g3[1], f.g3[2] = g3[2];
+  p.oy += DIR * p.sy, p.o2 += DIR * p.s2, p.o3 += DIR * p.s3;
 }
 
 __device__ __forceinline__ void store_m3(float *base, size_t idx, const M3 &a) {
