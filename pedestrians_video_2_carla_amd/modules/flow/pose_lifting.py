@@ -158,7 +158,7 @@ class LitPoseLiftingFlow(LitBaseFlow):
     def _fused_train_plan(self, frames, targets):
         """(PoseHeadSpec, gt2d, gt3d) when this batch can take ``ops.fused_train_step`` -- LinearAE with the 6-D rotation
         output on CARLA nodes, built-in transform, fusable losses, lean outputs, one clip per 16-sample tile, a small
-        batch (``P2C_FUSED_TRAIN_MAX_B``, default 1024: measured crossover with the separate kernels at about 2048 clips) -- else None.
+        batch (``P2C_FUSED_TRAIN_MAX_B``, default 2048: the measured crossover with the separate kernels -- 1536: 107 vs 120 us, 2048: 139 vs 141, 3072: 202 vs 189) -- else None.
         ``P2C_FUSED_TRAIN=0`` turns the path off. Everything but the two target tensors is a function of the configuration
         and the batch shape: it is worked out once per (shape, configuration) and cached."""
         import os
@@ -167,7 +167,7 @@ class LitPoseLiftingFlow(LitBaseFlow):
             return None
         transform_callable = self.datamodule.transform_callable
         key = (tuple(frames.shape), frames.device, frames.dtype, tuple(targets.keys()), os.environ.get('P2C_FUSED_TRAIN', '1'),
-               os.environ.get('P2C_FUSED_TRAIN_MAX_B', '1024'), self.lean_train_outputs, type(model), model.eval_slice.start,
+               os.environ.get('P2C_FUSED_TRAIN_MAX_B', '2048'), self.lean_train_outputs, type(model), model.eval_slice.start,
                model.eval_slice.stop, getattr(model, 'rotation_output_format', None), id(transform_callable),
                id(self.trajectory_model), bool(self.mask_missing_joints), model.fused_mlp, model.training, model.mlp_precision,
                tuple(targets[k].shape for k in ('projection_2d_transformed', 'projection_2d', 'absolute_pose_loc') if k in targets))
@@ -191,7 +191,7 @@ class LitPoseLiftingFlow(LitBaseFlow):
         if not (frames.is_cuda and frames.dtype == torch.float32 and frames.ndim == 4):
             return None
         B, T = frames.shape[0], frames.shape[1]
-        if B > int(os.environ.get('P2C_FUSED_TRAIN_MAX_B', '1024')) or model.input_nodes is not CARLA_SKELETON:
+        if B > int(os.environ.get('P2C_FUSED_TRAIN_MAX_B', '2048')) or model.input_nodes is not CARLA_SKELETON:
             return None
         if model.output_type not in (MovementsModelOutputType.pose_changes, MovementsModelOutputType.relative_rot) \
                 or getattr(model, 'rotation_output_format', None) != 'rotation_6d':
