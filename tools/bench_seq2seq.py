@@ -2,7 +2,6 @@
 import os, sys, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from oracle import pose_head as O   # synthetic batch recipe only (tool, not product)
 from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
 from pedestrians_video_2_carla_amd.data.carla.carla_recorded_synthetic import SyntheticCarlaRecordedDataModule
 from pedestrians_video_2_carla_amd.modules.flow.autoencoder import LitAutoencoderFlow
