@@ -153,16 +153,23 @@ def test_graph_mode_trains_on_new_batches_like_eager(monkeypatch, fused):
 def test_captured_step_replayed_as_its_recorded_call(monkeypatch, direct):
     """Single GPU, two-launch step with the optimizer inside: the capture records the one p2c_train_step call, the captured graph
     is checked to hold exactly its two kernel nodes, and the step is then replayed by making that call directly (no graph
-    start-up). Same losses, bit for bit, as eager and as the graph replay (P2C_DIRECT_REPLAY=0); a model the fused step does not
-    cover keeps the graph."""
+    start-up). Same losses, bit for bit, as eager and as the graph replay (P2C_DIRECT_REPLAY=0), across a learning-rate change;
+    a model the fused step does not cover keeps the graph."""
     monkeypatch.setenv('P2C_DIRECT_REPLAY', direct)
     flow, dm = make(B=64, missing=0.1)
     eager_flow, _ = make(B=64, missing=0.1)
     eager = _trainer(eager_flow, dm)
     trainer = _trainer(flow, dm, use_graph=True)
     batches = list(dm.train_batches(dev(), 12))
-    got = torch.stack([trainer.train_step(flow, b, i).clone() for i, b in enumerate(batches)]).cpu()
-    want = torch.stack([eager.train_step(eager_flow, b, i).clone() for i, b in enumerate(batches)]).cpu()
+    def run(tr, fl):
+        out = []
+        for i, b in enumerate(batches):
+            if i == 6:                                                    # an LR-scheduler step between replays reaches the launch
+                for grp in tr.optimizers[0].param_groups:
+                    grp['lr'] *= 0.1
+            out.append(tr.train_step(fl, b, i).clone())
+        return torch.stack(out).cpu()
+    got, want = run(trainer, flow), run(eager, eager_flow)
     assert _took_fused_path(flow)
     assert (trainer._direct is not None) == (direct == '1')
     assert torch.equal(got, want), (got - want).abs().max()
