@@ -202,10 +202,12 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         # (the decoder state is the encoder's for every frame: its recurrent terms k_l = b_ih_l + b_hh_l + W_hh_l hidden_l are
         # per-clip constants, formed inside the launch)
         drop = None
-        if rnn.dropout > 0 and rnn.training:      # nn.LSTM's inter-layer dropout, one mask tensor for all frames
-            keep = 1.0 - rnn.dropout
-            drop = torch.empty(clip_length, hidden.shape[1], rnn.hidden_size, device=hidden.device,
-                               dtype=hidden.dtype).bernoulli_(keep).div_(keep)
+        if rnn.dropout > 0 and rnn.training:      # nn.LSTM's inter-layer dropout, one mask tensor for all frames:
+            shape = (clip_length, hidden.shape[1], rnn.hidden_size)       # dropout(ones) = mask / keep in ONE launch
+            ones = getattr(self, '_drop_ones', None)
+            if ones is None or ones.shape != shape or ones.device != hidden.device or ones.dtype != hidden.dtype:
+                ones = self._drop_ones = torch.ones(shape, device=hidden.device, dtype=hidden.dtype)
+            drop = torch.nn.functional.dropout(ones, rnn.dropout, True)
         return ops.decoder_stack(hidden, cell, rnn, fc, clip_length, drop)            # (B,T,O)
 
     def _format_output(self, original_shape, outputs, batch_first: bool = False):
