@@ -568,7 +568,7 @@ def extra_config(device, name, steps=100, warmup=10):
         out['roofline'] = [mfma_entry(k, B, rt[k], fl) for k, fl in rflops.items()]
         out['note'] = ('the time-loop launches are latency chains (one to three workgroup barriers per time step); at B <= 4096 they '
                        'run 4 sequences per workgroup on v_mfma_f32_4x4x1_16B (128 workgroups at B = 512), above that 16 on '
-                       'v_mfma_f32_16x16x4. The step is 25 launches: fold, 2 projection GEMMs, 2 + 2 encoder recurrences, '
+                       'v_mfma_f32_16x16x4. The step is 24 launches: fold, 2 projection GEMMs, 2 + 2 encoder recurrences, '
                        'dropout, decoder fwd / bwd with the frame-invariant terms inside, 2 grouped weight-gradient pairs, '
                        'loss, AdamW')
     return out
