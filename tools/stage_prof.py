@@ -37,3 +37,14 @@ print('list + checks        ', T(lists))
 for o in trainer.optimizers:
     if hasattr(o, 'sync_hyper'):
         print('sync_hyper           ', T(lambda i: o.sync_hyper()))
+sb = trainer._static_batch
+print('  projection hook    ', T(lambda i: flow.projection.on_batch_start(sb, i)))
+print('  plan lookup        ', T(lambda i: flow._fused_train_plan(sb[0], sb[1])))
+pc = getattr(flow, '_pair_counter', None)
+if pc is not None:
+    gt = flow._fused_train_plan(sb[0], sb[1])[1]
+    print('  pair counter call  ', T(lambda i: pc(gt)))
+d = trainer._direct
+if d is not None:
+    print('direct call only     ', T(lambda i: d['call'](d['desc_ref'], d['gl'], torch.cuda.current_stream().cuda_stream)))
+    print('  current_stream     ', T(lambda i: torch.cuda.current_stream().cuda_stream))
