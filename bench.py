@@ -574,12 +574,62 @@ def extra_config(device, name, steps=100, warmup=10):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks here, as the reference starts its own
+    (modeling.py:275-282 -> Lightning re-runs the script once per GPU under `--gpus=0,1 --accelerator=ddp`, README.md:74-75).
+    N fresh child processes of this script, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; this parent makes no GPU call
+    (torch.cuda.device_count() only reads the device list) and does not replace itself. Rank 0's stdout is passed through
+    (the ONE JSON line); any failing rank stops the others and the exit code is non-zero."""
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f'bench.py --gpus {n}: this host shows {have} GPU(s); refusing to report an n_gpus={n} line from fewer ranks')
+    env0 = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(os.environ.get('MASTER_PORT') or _free_port()),
+                WORLD_SIZE=str(n), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        rc, pending = 0, list(procs)
+        while pending and rc == 0:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0:
+                    rc = code
+            time.sleep(0.05)
+        return rc
+    finally:
+        for pr in procs:                                        # exactly the processes started here
+            if pr.poll() is None:
+                pr.terminate()
+        for pr in procs:
+            try:
+                pr.wait(timeout=30)
+            except subprocess.TimeoutExpired:
+                pr.kill()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     from pedestrians_video_2_carla_amd.trainer import init_distributed
     info = init_distributed()
     world, rank, local_rank = info['world_size'], info['rank'], info['local_rank']
-    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch as many ranks as GPUs (or none: '
+                         f'`python bench.py --gpus N` starts them itself)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP hot path has no CPU fallback')
     device = torch.device('cuda', local_rank)

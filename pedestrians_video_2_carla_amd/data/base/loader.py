@@ -14,7 +14,10 @@ the host side only has to move raw arrays:
 
 Batch order: ``shuffle`` draws one permutation per epoch from a seeded host generator (DataLoader's RandomSampler);
 ``drop_last`` (default True: a captured step has one batch shape) drops the ragged tail the reference would keep.
-Under data-parallel training rank r of W takes every W-th index of the epoch's order (DistributedSampler).
+Under data-parallel training rank r of W takes every W-th index of the epoch's order, and every rank gets the SAME number
+of clips, as with DistributedSampler: the order is truncated to floor(n / W) * W indices under ``drop_last`` and otherwise
+padded with its own head to ceil(n / W) * W -- each step carries a collective, so a rank with one batch fewer would leave
+the others waiting in it.
 """
 from typing import Dict, Iterable, Iterator, Optional, Tuple
 
@@ -51,8 +54,13 @@ class DeviceLoader:
         self._copy_stream = torch.cuda.Stream(device=self.device)
         self._slot_events = [None, None]
 
+    def _per_rank(self) -> int:
+        """Clips per rank and epoch: the same on every rank (torch DistributedSampler's num_samples)."""
+        w = max(int(self.world_size), 1)
+        return self.n // w if self.drop_last else -(-self.n // w)
+
     def __len__(self) -> int:
-        per_rank = len(range(self.rank, self.n, self.world_size))
+        per_rank = self._per_rank()
         return per_rank // self.batch_size if self.drop_last else -(-per_rank // self.batch_size)
 
     def _order(self) -> torch.Tensor:
@@ -61,6 +69,12 @@ class DeviceLoader:
             order = torch.randperm(self.n, generator=g)
         else:
             order = torch.arange(self.n)
+        total = self._per_rank() * max(int(self.world_size), 1)
+        if total > order.numel():                    # pad with the head of the same order (repeated for a tiny subset)
+            reps = -(-total // max(order.numel(), 1))
+            order = order.repeat(reps)[:total] if order.numel() else order
+        else:
+            order = order[:total]
         return order[self.rank::self.world_size]
 
     def _stage(self, idx: torch.Tensor, slot: int):

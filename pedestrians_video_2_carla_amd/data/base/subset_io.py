@@ -21,12 +21,26 @@ except ImportError:        # pragma: no cover - depends on the environment
     h5py = None
 
 
-def _encode_strings(values: Iterable) -> Tuple[np.ndarray, np.ndarray]:
-    """string meta -> (uint16 codes, label table), the reference's attribute form (base_datamodule.py:487-499)."""
+_ATTRIBUTE_LIMIT = 64 * 1024      # base_datamodule.py:494: a label table at or past 64 KB cannot be an HDF5 attribute
+
+
+def _fixed_ascii(strings) -> np.ndarray:
+    """latin-1 byte strings as one fixed-length 'S' array (an empty list gives an empty 'S1' array)."""
+    enc = [str(s).encode('latin-1') for s in strings]
+    return np.array(enc, dtype=f'S{max((len(s) for s in enc), default=1) or 1}')
+
+
+def _encode_strings(values: Iterable):
+    """string meta -> (uint16 codes, label table) while the table stays below 64 KB -- the reference's attribute form
+    (base_datamodule.py:487-499) -- else (fixed-length ASCII values, None): its dataset form (500-506), which is also what
+    more than 65 535 distinct strings (per-clip ids) need, since the codes are uint16."""
     values = [str(v) for v in values]
     unique = sorted(set(values))
-    mapping = {s: i for i, s in enumerate(unique)}
-    return np.array([mapping[s] for s in values], dtype=np.uint16), np.array([s.encode('latin-1') for s in unique])
+    labels = _fixed_ascii(unique)
+    if labels.nbytes < _ATTRIBUTE_LIMIT and len(unique) <= np.iinfo(np.uint16).max + 1:
+        mapping = {s: i for i, s in enumerate(unique)}
+        return np.array([mapping[s] for s in values], dtype=np.uint16), labels
+    return _fixed_ascii(values), None
 
 
 def save_subset(save_dir: str, name: str, projection_2d: np.ndarray, targets: Dict[str, np.ndarray],
@@ -44,8 +58,11 @@ def save_subset(save_dir: str, name: str, projection_2d: np.ndarray, targets: Di
                     f.create_dataset(f'meta/{k}', data=v, chunks=(1, *v.shape[1:]) if v.ndim > 1 else None)
                 else:
                     codes, labels = _encode_strings(v)
-                    f.create_dataset(f'meta/{k}', data=codes)
-                    f[f'meta/{k}'].attrs['labels'] = labels.astype(h5py.string_dtype('ascii', max(len(s) for s in labels)))
+                    if labels is None:             # dataset form: the encoded strings themselves
+                        f.create_dataset(f'meta/{k}', data=codes.astype(h5py.string_dtype('ascii', codes.dtype.itemsize)))
+                    else:
+                        f.create_dataset(f'meta/{k}', data=codes)
+                        f[f'meta/{k}'].attrs['labels'] = labels.astype(h5py.string_dtype('ascii', labels.dtype.itemsize))
         return path
     path = os.path.join(save_dir, f'{name}.npz')
     arrays = {'projection_2d': np.asarray(projection_2d)}
@@ -55,7 +72,10 @@ def save_subset(save_dir: str, name: str, projection_2d: np.ndarray, targets: Di
         if isinstance(v, np.ndarray) and v.dtype.kind not in 'USO':
             arrays[f'meta/{k}'] = v
         else:
-            arrays[f'meta/{k}'], arrays[f'meta/{k}__labels'] = _encode_strings(v)
+            codes, labels = _encode_strings(v)
+            arrays[f'meta/{k}'] = codes
+            if labels is not None:
+                arrays[f'meta/{k}__labels'] = labels
     np.savez(path, **arrays)
     return path
 
@@ -74,6 +94,8 @@ def load_subset(path: str) -> Tuple[np.ndarray, Dict[str, np.ndarray], Dict[str,
                     if f'{k}__labels' in d.files:
                         labels = [s.decode('latin-1') for s in d[f'{k}__labels']]
                         meta[name] = [labels[i] for i in d[k]]
+                    elif d[k].dtype.kind == 'S':
+                        meta[name] = [s.decode('latin-1') for s in d[k]]
                     else:
                         meta[name] = d[k]
         return projection_2d, targets, meta

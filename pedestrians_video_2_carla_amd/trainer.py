@@ -89,6 +89,8 @@ class Trainer:
         self._opt_in_backward = False
         self._fused_seen = 0
         self._grad_sinks = False
+        self._kept_graph = False
+        self._graph_nodes = None
 
     # ------------------------------------------------------------------------------------------------------------
     def setup(self, flow, datamodule):
@@ -216,8 +218,12 @@ class Trainer:
         """meta['skel_type'] as a device tensor (data/carla/reference.py:skeleton_types_from_meta): inside a captured step
         the per-clip (age, gender) strings cannot be looked at again."""
         frames, targets, meta = batch
-        if isinstance(meta.get('skel_type'), torch.Tensor) or not ('age' in meta and 'gender' in meta):
+        st = meta.get('skel_type')
+        if isinstance(st, torch.Tensor) and st.dtype == torch.int32 and st.device == frames.device:
             return batch
+        # ALWAYS an int32 tensor on the frames' device, also for an int64 / host tensor and for the default adult-female
+        # case without age / gender: the static batch then owns it and ProjectionModule.on_batch_start (whose `.to()` calls
+        # are no-ops on it) hands the captured step that same storage for every staged batch
         from pedestrians_video_2_carla_amd.data.carla import reference as ref
         meta = dict(meta)
         meta['skel_type'] = ref.skeleton_types_from_meta(meta, batch_size=len(frames), strict=True, device=frames.device)
@@ -278,7 +284,11 @@ class Trainer:
                     o.sync_hyper()               # LR-scheduler changes reach the captured optimizer launch
             if self._direct is not None:            # the step IS one recorded call: two launches, no graph start-up
                 d = self._direct
-                rc = d['call'](d['desc_ref'], d['gl'], torch.cuda.current_stream().cuda_stream)
+                if torch.cuda.current_device() != d['device_index']:   # the recorded pointers belong to the trainer's GPU
+                    with torch.cuda.device(d['device_index']):
+                        rc = d['call'](d['desc_ref'], d['gl'], torch.cuda.current_stream(d['device_index']).cuda_stream)
+                else:
+                    rc = d['call'](d['desc_ref'], d['gl'], torch.cuda.current_stream().cuda_stream)
                 if rc != 0:
                     raise RuntimeError(f'p2c_train_step failed in direct replay (rc={rc})')
             else:
@@ -299,6 +309,13 @@ class Trainer:
     def _capture(self, flow, batch, batch_idx):
         """Capture on the trainer's static batch (``stage_batch`` fills it; the flow's batch-start hook already ran)."""
         distributed = self.exchange is not None and self.exchange.enabled
+        # the captured launches keep the ADDRESS of the per-batch skeleton-type index: it must be the static batch's own tensor
+        # (stage_batch refills it in place), not a temporary the batch-start hook derived from something else
+        st = batch[2].get('skel_type') if isinstance(batch[2], dict) else None
+        held = getattr(getattr(flow, 'projection', None), '_skel_type', None)
+        if isinstance(st, torch.Tensor) and isinstance(held, torch.Tensor) and held.data_ptr() != st.data_ptr():
+            raise RuntimeError('graph capture: ProjectionModule holds a skeleton-type tensor that is not the static batch\'s '
+                               f'(meta[\'skel_type\'] is {st.dtype} on {st.device}; int32 on the frames\' device is kept as is)')
         # the warm-up iterations below are real optimisation steps: snapshot parameters + optimizer state and restore
         # them IN PLACE afterwards (the graphs hold the addresses), so that replay #1 is training step #1
         snapshot = self._snapshot(flow)
@@ -312,18 +329,21 @@ class Trainer:
                 self._optimizer_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g_fb = torch.cuda.CUDAGraph()
         mode = os.environ.get('P2C_GRAPH_ALLREDUCE', 'auto')
+        g_fb = self._new_graph(keep=distributed)
         if distributed and mode != '0':
             # the RCCL all-reduce is captured too: the whole step is ONE graph replay (one-rank rehearsal: 49 us against
             # 59 us for graph + eager collective + optimizer launch). Guarded: a failed capture / first replay on any rank,
             # or ranks whose parameters differ after that replay, send every rank to the eager-collective path below.
             if self._capture_with_allreduce(flow, batch, batch_idx, g_fb, snapshot, strict=(mode == '1')):
                 return
-            g_fb = torch.cuda.CUDAGraph()
+            g_fb = self._new_graph(keep=True)
         if distributed:
             with torch.cuda.graph(g_fb):
                 self._static_loss = self._forward_backward(flow, batch, batch_idx, batch_start=False)
+            if self._kept_graph:
+                self._graph_nodes = self._count_nodes(g_fb)      # stage A alone: forward + backward
+                g_fb.instantiate()
             if all(hasattr(o, '_descriptor') for o in self.optimizers):
                 g_opt = 'eager'          # FlatAdamW is a single kernel: a direct launch has less latency than a 1-node graph
             else:
@@ -340,7 +360,9 @@ class Trainer:
             try_direct = self._opt_in_backward and os.environ.get('P2C_DIRECT_REPLAY', '1') == '1'
             rec = [] if try_direct else None
             if try_direct:
-                g_fb = torch.cuda.CUDAGraph(keep_graph=True)
+                g_fb = self._new_graph(keep=True)
+                try_direct = self._kept_graph          # an older torch without keep_graph: the plain graph replays the step
+                rec = rec if try_direct else None
             ops.TRAIN_STEP_RECORDER = rec
             try:
                 with torch.cuda.graph(g_fb):
@@ -353,6 +375,30 @@ class Trainer:
                 g_fb.instantiate()
         self._graphs = (g_fb, g_opt)
         self._restore(flow, snapshot)
+
+    def _new_graph(self, keep: bool = False):
+        """A CUDAGraph; ``keep`` asks torch to keep the captured hipGraph_t so its nodes can be counted (instantiate() is then
+        ours to call). A torch without ``keep_graph`` gives the plain graph (``self._kept_graph`` False)."""
+        self._kept_graph = False
+        if keep:
+            try:
+                g = torch.cuda.CUDAGraph(keep_graph=True)
+                self._kept_graph = True
+                return g
+            except TypeError:
+                pass
+        return torch.cuda.CUDAGraph()
+
+    @staticmethod
+    def _count_nodes(graph):
+        import ctypes
+        from pedestrians_video_2_carla_amd import _lib
+        total, kernels = ctypes.c_int32(0), ctypes.c_int32(0)
+        try:
+            rc = _lib.lib().p2c_graph_node_counts(graph.raw_cuda_graph(), ctypes.byref(total), ctypes.byref(kernels))
+        except Exception:                       # noqa: BLE001 -- no handle on this torch
+            return None
+        return (total.value, kernels.value) if rc == 0 else None
 
     @staticmethod
     def _direct_replay_plan(graph, rec):
@@ -369,6 +415,7 @@ class Trainer:
         if rc != 0 or total.value != 2 or kernels.value != 2:
             return None
         plan = rec[0]
+        plan['device_index'] = plan['device'].index if plan['device'].index is not None else torch.cuda.current_device()
         plan['call'] = _lib.lib().p2c_train_step
         plan['desc_ref'] = ctypes.byref(plan['desc'])
         return plan
@@ -379,10 +426,7 @@ class Trainer:
         eager one (collectives of different sizes pair up and the job hangs). Only when every rank captured does the
         verification replay run, followed by a second agreement on bit-identical parameters."""
         ok, err = True, None
-        fail_rank = os.environ.get('P2C_TEST_FAIL_CAPTURE_RANK')        # tests: make one rank's capture fail
         try:
-            if fail_rank is not None and int(fail_rank) == dist.get_rank():
-                raise RuntimeError('capture failure requested by P2C_TEST_FAIL_CAPTURE_RANK')
             with torch.cuda.graph(graph):
                 self._static_loss = self._forward_backward(flow, batch, batch_idx, batch_start=False)
                 self.exchange.all_reduce_gradients()
@@ -394,6 +438,9 @@ class Trainer:
         agreed = ranks_agree(ok, device)        # eager collectives on the (non-capturing) current stream
         if agreed:
             try:
+                self._graph_nodes = self._count_nodes(graph)     # (all nodes, kernel nodes) of the captured step, or None
+                if self._kept_graph:
+                    graph.instantiate()
                 graph.replay()                  # one real step: every rank must come out with the same parameters
                 torch.cuda.synchronize()
             except Exception as e:              # noqa: BLE001

@@ -89,3 +89,49 @@ def test_failed_capture_of_the_collective_falls_back_to_the_eager_path(monkeypat
     finally:
         dist.destroy_process_group()
     assert torch.equal(want, got), (want, got)
+
+
+@pytest.mark.parametrize('captured', ['auto', '0'])
+def test_cfg4_per_gpu_step_with_the_exchange_on(monkeypatch, captured):
+    """BASELINE.json configs[3] per GPU: B = 1024 clips, the two-launch step WITHOUT the optimizer in its second launch
+    (train_clip_kernel -> train_wgrad_kernel<false> -> RCCL all-reduce of the flat gradient -> p2c_adamw_step), captured as one
+    graph ('auto') and as two stages with the eager collective between ('0'), against the single-GPU two-launch step on the
+    same batch. The captured step's graph is counted through the C ABI: the three kernels plus whatever the collective adds
+    (a one-rank in-place all-reduce may add a kernel node or nothing; a memcpy / memset node would be a regression)."""
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    from test_flow_gpu import make
+    from pedestrians_video_2_carla_amd.trainer import Trainer
+    d = torch.device('cuda:0')
+    torch.cuda.set_device(d)
+    steps, B = 8, 1024
+    flow_a, dm = make(B=B, missing=0.1)
+    flow_b, _ = make(B=B, missing=0.1)
+    batch = dm.generate_batch(d)
+    ta = Trainer(device=d, use_graph=True).setup(flow_a, dm)
+    single = torch.stack([ta.train_step(flow_a, batch, i).clone() for i in range(steps)]).cpu()
+    assert ta._direct is not None, 'B = 1024 takes the two-launch step on one GPU'
+
+    monkeypatch.setenv('P2C_FORCE_EXCHANGE', '1')
+    monkeypatch.setenv('P2C_GRAPH_ALLREDUCE', captured)
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', '29535')
+    dist.init_process_group(backend='nccl', rank=0, world_size=1)
+    try:
+        tb = Trainer(device=d, use_graph=True).setup(flow_b, dm)
+        assert tb.exchange.enabled and not tb._opt_in_backward
+        multi = torch.stack([tb.train_step(flow_b, batch, i).clone() for i in range(steps)]).cpu()
+        assert getattr(flow_b, '_pair_counts', None) is not None, 'the exchange step is the two-launch step too'
+        nodes = tb._graph_nodes
+        assert nodes is not None, 'the captured graph could not be counted'
+        total, kernels = nodes
+        if captured == '0':
+            assert tb._graphs[1] is not None and (total, kernels) == (2, 2), nodes      # stage A: clip + wgrad<false>
+        else:
+            assert tb._graphs[1] is None and total == kernels and kernels in (3, 4), nodes
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+    assert torch.allclose(single, multi, rtol=2e-4, atol=0), (single, multi)
+    pa = torch.cat([p.detach().reshape(-1) for p in flow_a.parameters()])
+    pb = torch.cat([p.detach().reshape(-1) for p in flow_b.parameters()])
+    assert float((pa - pb).abs().max()) <= 3e-4

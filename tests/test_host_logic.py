@@ -260,3 +260,43 @@ def test_seq2seq_residual_variants_drop_in(golden, name):
         model = cls(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d).eval()
         _load_sd(model, g, golden('model_seq2seq_embeddings_pose_2d'))
     assert torch.allclose(model(g['frames']), g['out'], atol=1e-5)
+
+
+def test_bench_refuses_to_report_more_gpus_than_ranks(tmp_path):
+    """`python bench.py --gpus N` outside torchrun starts its own N ranks (reference: Lightning starts one process per GPU,
+    modeling.py:275-282); with fewer devices than N it must fail loudly instead of printing an n_gpus line from fewer ranks,
+    and a torchrun-style environment whose WORLD_SIZE disagrees with --gpus is an error too."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('needs a host with fewer than two GPUs')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'n_gpus' not in r.stdout and '--gpus 2' in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])
+    env.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'n_gpus' not in r.stdout and 'WORLD_SIZE=1' in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])
+
+
+def test_static_batch_owns_an_int32_skeleton_type_index():
+    """Graph mode: the captured launches keep the address of meta['skel_type'], so staging must hand the flow ONE int32 tensor
+    on the frames' device whatever the batch carried -- an int64 tensor, age / gender strings, or nothing (adult female,
+    data/carla/reference.py) -- and an int32 tensor already there is kept as is."""
+    from pedestrians_video_2_carla_amd.trainer import Trainer
+    tr = Trainer()
+    frames = torch.zeros(3, 4, 26, 2)
+    for meta, want in (({'skel_type': torch.tensor([0, 1, 2])}, [0, 1, 2]),
+                       ({'age': ['adult', 'child', 'adult'], 'gender': ['male', 'female', 'female']}, None),
+                       ({}, [0, 0, 0])):
+        _, _, m = tr._with_skel_type((frames, {}, meta))
+        st = m['skel_type']
+        assert st.dtype == torch.int32 and st.device == frames.device and st.shape == (3,)
+        if want is not None:
+            assert st.tolist() == want
+    keep = torch.tensor([3, 1, 0], dtype=torch.int32)
+    batch = (frames, {}, {'skel_type': keep})
+    assert tr._with_skel_type(batch) is batch

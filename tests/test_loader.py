@@ -34,6 +34,49 @@ def test_subset_container_round_trip(tmp_path):
     assert qm['age'] == meta['age'] and qm['video_id'] == meta['video_id'] and np.array_equal(qm['start_frame'], meta['start_frame'])
 
 
+def test_subset_container_string_meta_past_the_attribute_form(tmp_path):
+    """base_datamodule.py:494-506: a label table of 64 KB or more (or more distinct strings than uint16 codes) is stored as
+    the encoded strings themselves; an empty subset round-trips too."""
+    from pedestrians_video_2_carla_amd.data.base.subset_io import load_subset, save_subset
+    n = 70000                                                   # > 65 535 distinct per-clip ids
+    p2d = np.zeros((n, 1, 1, 2), np.float32)
+    meta = {'clip_id': [f'video-{i:06d}' for i in range(n)], 'age': ['adult'] * n}
+    path = save_subset(str(tmp_path), 'big', p2d, {}, meta, prefer_hdf5=False)
+    with np.load(path) as d:
+        assert d['meta/clip_id'].dtype.kind == 'S' and 'meta/clip_id__labels' not in d.files
+        assert d['meta/age'].dtype == np.uint16
+    _, _, qm = load_subset(path)
+    assert qm['clip_id'] == meta['clip_id'] and qm['age'] == meta['age']
+    path = save_subset(str(tmp_path), 'empty', np.zeros((0, 4, 26, 2), np.float32), {}, {'age': [], 'gender': []},
+                       prefer_hdf5=False)
+    q2d, _, qm = load_subset(path)
+    assert q2d.shape == (0, 4, 26, 2) and qm['age'] == []
+
+
+@pytest.mark.parametrize('n,B,W,drop_last', [(1023, 512, 2, True), (1023, 512, 2, False), (37, 4, 3, True), (37, 4, 3, False),
+                                             (5, 4, 8, False), (64, 8, 4, True)])
+def test_device_loader_gives_every_rank_the_same_number_of_batches(n, B, W, drop_last):
+    """DistributedSampler semantics (the reference trains under Lightning DDP, README.md:74-75): equal clip counts per rank,
+    by truncation under drop_last and by padding with the head of the order otherwise."""
+    from pedestrians_video_2_carla_amd.data.base.loader import DeviceLoader
+    orders, lens = [], []
+    for rank in range(W):
+        ld = DeviceLoader.__new__(DeviceLoader)                 # the sharding arithmetic only: no device, no pinned memory
+        ld.n, ld.batch_size, ld.rank, ld.world_size, ld.drop_last, ld.shuffle, ld.seed, ld.epoch = n, B, rank, W, drop_last, True, 7, 3
+        orders.append(ld._order())
+        lens.append(len(ld))
+        chunks = list(orders[-1].split(B))
+        if chunks and drop_last and chunks[-1].numel() < B:
+            chunks.pop()
+        assert len(chunks) == lens[-1]
+    assert len(set(lens)) == 1 and len({o.numel() for o in orders}) == 1
+    seen = torch.cat(orders)
+    if drop_last:
+        assert seen.numel() == (n // W) * W and seen.unique().numel() == seen.numel()
+    else:
+        assert seen.numel() == -(-n // W) * W and seen.unique().numel() == n      # every clip at least once
+
+
 def test_save_predictions_follows_the_reference(tmp_path):
     from pedestrians_video_2_carla_amd.data.base.base_datamodule import BaseDataModule
     from pedestrians_video_2_carla_amd.data.base.subset_io import load_subset
