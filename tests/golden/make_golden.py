@@ -577,6 +577,108 @@ def golden_models_extra():
         npz('model_' + name, frames=frames, n_params=sum(p.numel() for p in model.parameters()), **outs, **sd)
 
 
+class StandInPoseTransformer(torch.nn.Module):
+    """Stand-in for the THIRD-PARTY transformer ``third_party/PoseFormer common/model_poseformer.PoseTransformer`` (empty
+    git submodule in the reference checkout, like pytorch3d a package the image lacks): same constructor keywords, same
+    call contract -- (B, num_frame, J, in_chans) -> (B, 1, J, 3), the centre-frame pose -- computed by a small fixed map
+    (a linear map of the flattened window followed by tanh, so that every frame and joint of the window matters and the
+    order of the windows is visible in the result). It lets the REFERENCE's own wrapper ``PoseFormer.forward`` /
+    ``eval_slice`` (pose_former.py:114-127) run unmodified; the transformer's arithmetic stays parity-unpinned."""
+
+    def __init__(self, num_frame=9, num_joints=26, in_chans=2, **kwargs):
+        super().__init__()
+        self.num_joints = num_joints
+        g = torch.Generator().manual_seed(97)
+        self.map = torch.nn.Linear(num_frame * num_joints * in_chans, num_joints * 3)
+        with torch.no_grad():
+            self.map.weight.copy_(torch.randn(self.map.weight.shape, generator=g) * 0.05)
+            self.map.bias.copy_(torch.randn(self.map.bias.shape, generator=g) * 0.1)
+
+    def forward(self, x):
+        return torch.tanh(self.map(x.reshape(x.shape[0], -1))).view(x.shape[0], 1, self.num_joints, 3)
+
+
+def golden_wrappers():
+    """Two behaviours the reference OWNS around third-party / framework code, run from the reference's own classes:
+    (a) the PoseFormer window wrapper (pose_former.py:117-127) + eval_slice (114-115) for clip_length 30 and 81, with the
+        stand-in above in place of the absent third-party transformer;
+    (b) teacher forcing in Seq2Seq.forward / _decode_frame / _teacher_forcing (seq2seq.py:245-288, 323-349), train mode,
+        Seq2SeqEmbeddings: frames_force and clip_force on pose_2d, frames_force on pose_changes (6-D targets through
+        matrix_to_rotation_6d); dropout 0 so that the only random draw is the forcing decision, which is recorded as the
+        uniform numbers torch.rand returned; output, a weighted-sum loss and every parameter gradient are stored."""
+    if not os.path.isdir(REF_SRC):
+        sys.exit('reference tree not present: the committed .npz files are the artefact to use')
+    install_standins()
+    sys.path.insert(0, REF_SRC)
+    import pedestrians_video_2_carla  # noqa: F401
+    import importlib
+    # the stand-in is registered under the reference's import path of the third-party package (pose_former.py:6)
+    for name in ('pedestrians_video_2_carla.third_party', 'pedestrians_video_2_carla.third_party.pose_former'):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            sys.modules[name] = m
+    tp = types.ModuleType('pedestrians_video_2_carla.third_party.pose_former.model_poseformer')
+    tp.PoseTransformer = StandInPoseTransformer
+    sys.modules[tp.__name__] = tp
+    from pedestrians_video_2_carla.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla.modules.flow.output_types import MovementsModelOutputType as MT
+    pf_mod = importlib.import_module('pedestrians_video_2_carla.modules.movements.pose_former.pose_former')
+    assert pf_mod.PoseFormerModel is StandInPoseTransformer, 'the reference fell back to its NotAvailable dummy'
+    out = {}
+    for T in (30, 81):
+        g = torch.Generator().manual_seed(200 + T)
+        model = pf_mod.PoseFormer(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, clip_length=T).eval()
+        x = torch.randn(3, T, 26, 2, generator=g)
+        with torch.no_grad():
+            y = model(x)
+        sl = model.eval_slice
+        out.update({f'T{T}_x': x, f'T{T}_out': y, f'T{T}_eval_slice': np.array([sl.start, sl.stop])})
+        assert model.output_type == MT.absolute_loc
+    inner = StandInPoseTransformer()
+    npz('pose_former_wrapper', standin_weight=inner.map.weight, standin_bias=inner.map.bias, **out)
+
+    from pedestrians_video_2_carla.modules.movements.seq2seq.seq2seq_embeddings import Seq2SeqEmbeddings
+    from pytorch3d.transforms import euler_angles_to_matrix
+    out = {}
+    B, T = 5, 16
+    small = dict(hidden_size=32, single_joint_embeddings_size=8)        # small models: the fixture stores weights + gradients
+    for tag, kw in (('frames_pose_2d', dict(movements_output_type=MT.pose_2d, teacher_mode='frames_force', teacher_force_ratio=0.3, **small)),
+                    ('clip_pose_2d', dict(movements_output_type=MT.pose_2d, teacher_mode='clip_force', teacher_force_ratio=0.4, **small)),
+                    ('frames_pose_changes', dict(movements_output_type=MT.pose_changes, teacher_mode='frames_force',
+                                                 teacher_force_ratio=0.3, hidden_size=16, single_joint_embeddings_size=8))):
+        torch.manual_seed(22742)
+        model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, p_dropout=0.0, **kw).train()
+        g = torch.Generator().manual_seed(31)
+        x = torch.randn(B, T, 26, 2, generator=g)
+        if kw['movements_output_type'] == MT.pose_2d:
+            targets = {'projection_2d_transformed': torch.randn(B, T, 26, 2, generator=g)}
+            w = torch.randn(B, T, 26, 2, generator=g)
+        else:
+            ang = (torch.rand(B, T, 26, 3, generator=g) * 2 - 1) * 0.3
+            targets = {'pose_changes': euler_angles_to_matrix(ang, 'XYZ')}
+            w = torch.randn(B, T, 26, 3, 3, generator=g)
+        shape = (1, B) if kw['teacher_mode'] == 'clip_force' else (T, B)
+        torch.manual_seed(777)
+        uniform = torch.rand(shape)                       # what the reference's one torch.rand call returns after this seed
+        torch.manual_seed(777)
+        y = model(x, targets)
+        loss = (y * w).sum()
+        loss.backward()
+        out.update({f'{tag}__x': x, f'{tag}__w': w, f'{tag}__uniform': uniform, f'{tag}__out': y, f'{tag}__loss': loss})
+        out.update({f'{tag}__target__{k}': v for k, v in targets.items()})
+        out.update({f'{tag}__sd__{k}': v for k, v in model.state_dict().items()})
+        out.update({f'{tag}__grad__{k}': p.grad for k, p in model.named_parameters()})
+        # the forced rows of the OUTPUT equal the targets (input and output are one tensor in _decode_frame)
+        idx = (uniform < kw['teacher_force_ratio'])
+        idx = idx.repeat(T, 1) if kw['teacher_mode'] == 'clip_force' else idx
+        assert idx.any() and not idx.all()
+        if kw['movements_output_type'] == MT.pose_2d:
+            forced = y.permute(1, 0, 2, 3)[idx]
+            assert torch.equal(forced, targets['projection_2d_transformed'].permute(1, 0, 2, 3)[idx])
+    npz('teacher_forcing', **out)
+
+
 def golden_metrics_extra():
     """Section 9b (the rest): the reference's own MultiinputWrapper (metrics/multiinput_wrapper.py) around a
     mean-squared-error base metric, and MissingJointsRatio (metrics/missing_joints_ratio.py), run on two batches each.
@@ -649,6 +751,8 @@ if __name__ == '__main__':
         golden_losses_extra()
     elif sys.argv[1:] == ['collate']:
         golden_collate()
+    elif sys.argv[1:] == ['wrappers']:
+        golden_wrappers()
     elif sys.argv[1:] == ['metrics']:
         install_standins()
         sys.path.insert(0, REF_SRC)

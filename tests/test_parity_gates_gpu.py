@@ -64,6 +64,45 @@ def test_loss_curve_at_the_benchmark_configuration_default_init():
     assert dev_gpu[0] <= 1e-4
 
 
+def test_loss_curve_at_the_benchmark_configuration_conditioned_init_strict():
+    """The strict gate of BASELINE.json's north_star ("loss curve matching CPU reference to 1e-4") AT the benchmark
+    configuration: B = 256, T = 16, 10 % missing input joints, 200 optimizer steps of the two-launch step (K13, replayed as its
+    recorded call), against the CPU pipeline (LinearAE fp32 + fp32 oracle + AdamW) step by step, 1e-4 relative with no
+    allowance. The init is the conditioned one of tests/test_flow_gpu.py (last-layer bias = identity rotations: with the
+    default init a1/|a1| of near-zero 6-D outputs makes ANY fp32 run chaotic -- that run is the smoke test above); the fp64
+    curve is printed beside it."""
+    from pedestrians_video_2_carla_amd.trainer import Trainer
+    steps, B = 200, 256
+    d = dev()
+
+    def conditioned():
+        flow, dm = make(B=B, missing=0.1)
+        last = flow.movements_model._LinearAE__decoder[4]
+        with torch.no_grad():
+            last.bias.copy_(torch.tensor([1., 0., 0., 0., 1., 0.]).repeat(26))
+        return flow, dm
+
+    flow_g, dm = conditioned()
+    flow_32, _ = conditioned()
+    flow_64, _ = conditioned()
+    batch = dm.generate_batch(d)
+    assert float((batch[0] == 0).all(-1).float().mean()) > 0.05, 'the missing-joint deformation is on'
+    tg = Trainer(device=d, use_graph=True).setup(flow_g, dm)
+    gpu = torch.stack([tg.train_step(flow_g, batch, i).clone() for i in range(steps)]).double().cpu()
+    assert getattr(flow_g, '_pair_counts', None) is not None and tg._direct is not None, 'the two-launch step, direct replay'
+    cpu32 = _cpu_curve(flow_32, batch, steps, torch.float32)
+    ref64 = _cpu_curve(flow_64, batch, steps, torch.float64)
+    dev_32 = ((gpu - cpu32).abs() / cpu32.abs())
+    dev_64 = ((gpu - ref64).abs() / ref64.abs())
+    cpu_64 = ((cpu32 - ref64).abs() / ref64.abs())
+    print(f'strict curve B={B} conditioned init, 10% missing: {float(gpu[0]):.4f} -> {float(gpu[-1]):.4f}; max rel dev GPU vs '
+          f'CPU fp32 {float(dev_32.max()):.2e} (step {int(dev_32.argmax())}), GPU vs fp64 {float(dev_64.max()):.2e}, CPU fp32 vs '
+          f'fp64 {float(cpu_64.max()):.2e}')
+    assert torch.isfinite(gpu).all() and gpu[-1] < 0.5 * gpu[0]
+    assert float(dev_32.max()) < 1e-4, f'GPU vs CPU fp32: {float(dev_32.max()):.3e} at step {int(dev_32.argmax())}'
+    assert float(dev_64.max()) < 1e-4, f'GPU vs fp64: {float(dev_64.max()):.3e} at step {int(dev_64.argmax())}'
+
+
 def test_cfg5_pose_head_absolute_loc_t81_body25_targets():
     """PoseFormer's head (BASELINE.json configs[4]): absolute_loc output, clip_length 81, eval_slice (4, 77), targets in the
     BODY_25 layout (21 common joints) -- losses and grad_y vs the oracle."""
