@@ -177,7 +177,7 @@ def grad_loss_pointers(g0=None, g1=None, g2=None, vector=None):
 
 def build(verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into csrc/libp2c_hip.so (hipcc cross-compiles without a GPU)."""
-    res = subprocess.run(['make', '-C', os.path.join(_HERE, 'csrc')], capture_output=True, text=True)
+    res = subprocess.run(['make', '-j', str(min(os.cpu_count() or 1, 8)), '-C', os.path.join(_HERE, 'csrc')], capture_output=True, text=True)
     if verbose or res.returncode:
         print(res.stdout, res.stderr)
     if res.returncode:
