@@ -125,6 +125,12 @@ P2C_API int p2c_pose_head_set_time_parallel_max_batch(int32_t max_b);
  * configuration without world motion run the packed-fp32 clip-sequential kernels (two clips per lane, v_pk_fma_f32) --
  * parity-tested, currently slower than the scalar kernels. min_b < 0 only queries. */
 P2C_API int p2c_pose_head_set_packed_min_batch(int32_t min_b);
+/* Batches of at least `min_b` clips (default 8192, env P2C_CHAIN_MIN_B) that the time-parallel kernels do not take run the
+ * chain-lane kernels (csrc/p2c_pose_head_chain.hip: eight clips per wavefront, a lane owns up to four consecutive bones)
+ * when the configuration is the training one: 6-D kind, lean outputs, no world motion, no external gradients, targets in
+ * the CARLA joint layout with two channels. Otherwise, and below min_b, the joint-lane kernels run. Same function, fp32
+ * rounding order differs in the kinematic chain. min_b < 0 only queries. Returns the previous value. */
+P2C_API int p2c_pose_head_set_chain_min_batch(int32_t min_b);
 
 /* Forward: fills loss_sums, losses, final_rel_rot and any non-NULL out_* tensor. Two launches on `stream`
  * (pose head + deterministic reduction of the per-wave partial sums); with desc->defer_loss_finalize = 1 / 2 one launch

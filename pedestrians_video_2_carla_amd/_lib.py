@@ -7,7 +7,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libp2c_hip.so')
+LIB_PATH = os.environ.get('P2C_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libp2c_hip.so')    # (P2C_LIB_PATH: A/B builds, tools only)
 P2C_JOINTS = 26
 
 KIND = {'pose_changes_6d': 0, 'pose_changes': 1, 'relative_rot_6d': 2, 'relative_rot': 3, 'absolute_loc': 4}
@@ -105,6 +105,7 @@ SYMBOLS = {
     'p2c_pose_head_workspace_floats': (_i64, [_i32]),
     'p2c_pose_head_set_time_parallel_max_batch': (ctypes.c_int, [ctypes.c_int32]),
     'p2c_pose_head_set_packed_min_batch': (ctypes.c_int, [ctypes.c_int32]),
+    'p2c_pose_head_set_chain_min_batch': (ctypes.c_int, [ctypes.c_int32]),
     'p2c_pose_head_fwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp]),
     'p2c_pose_head_bwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.POINTER(_vp * 3), _vp, _vp, _vp, _vp, _vp]),
     'p2c_normalize_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _i32, _ip,

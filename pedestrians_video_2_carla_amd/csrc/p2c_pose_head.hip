@@ -758,6 +758,13 @@ static inline bool use_pk(const p2c_pose_head_desc &d) {
   return (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D) && !d.dloc && !d.drot &&
          d.B >= pk_min_b() && !use_tp(d);
 }
+// chain-lane kernels for large batches (p2c_pose_head_chain.hip)
+bool p2c_internal_chain_supported(const p2c_pose_head_desc &d);
+unsigned p2c_internal_chain_waves(int B);
+int p2c_internal_chain_fwd(const p2c_pose_head_desc &d, hipStream_t stream);
+int p2c_internal_chain_bwd(const p2c_pose_head_desc &d, const GradLosses &gl, float *grad_y, hipStream_t stream);
+static inline bool use_chain(const p2c_pose_head_desc &d) { return !use_tp(d) && !use_pk(d) && p2c_internal_chain_supported(d); }
+
 static inline unsigned grid_pk(int B) {
   const int waves = (B + 3) / 4;
   return (unsigned)((waves + kBlock / 64 - 1) / (kBlock / 64));
@@ -796,6 +803,14 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
     return e0 == hipSuccess ? 0 : (int)e0;
   }
   const dim3 tp_grid((unsigned)d.B), tp_block(tp_threads(d.T)), pk_grid(grid_pk(d.B));
+  if (!mat && use_chain(d)) {            // large batch of the training configuration: eight clips per wavefront
+    rc = p2c_internal_chain_fwd(d, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, (int)p2c_internal_chain_waves(d.B),
+                       n3_elems_host(d), d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
+    hipError_t ec = hipGetLastError();
+    return ec == hipSuccess ? 0 : (int)ec;
+  }
 #define P2C_LAUNCH_ROT_FWD(KIND)                                                                                \
   if (mat) hipLaunchKernelGGL((pose_head_rot_fwd<KIND, true>), grid, block, 0, stream, d);                      \
   else if (tp) hipLaunchKernelGGL((pose_head_rot_fwd_tp<KIND>), tp_grid, tp_block, tp_lds_bytes(d.T), stream, d); \
@@ -850,6 +865,10 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
   const float *ga = grad_absolute_pose_loc, *gp = grad_projection_2d_transformed, *gr = grad_absolute_pose_rot;
   if (gr && d.kind != P2C_KIND_POSE_CHANGES_6D && d.kind != P2C_KIND_RELATIVE_ROT_6D)
     return P2C_E_ENUM;      // rotation-loss gradients go through the tangent-space backward of the 6-D kinds
+  if (!ga && !gp && !gr && use_chain(d)) {
+    if (d.kind == P2C_KIND_POSE_CHANGES_6D && !d.final_rel_rot) return P2C_E_NULL;
+    return p2c_internal_chain_bwd(d, grad_losses, grad_y, stream);
+  }
   switch (d.kind) {
     case P2C_KIND_POSE_CHANGES_6D:
       if (!d.final_rel_rot) return P2C_E_NULL;

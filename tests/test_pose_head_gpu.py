@@ -21,19 +21,21 @@ def dev():
     return torch.device('cuda:0')
 
 
-@pytest.fixture(autouse=True, params=['time_parallel', 'clip_sequential', 'packed'])
+@pytest.fixture(autouse=True, params=['time_parallel', 'clip_sequential', 'packed', 'chain'])
 def kernel_variant(request):
-    """Every case runs three times: with the time-parallel kernels (small batches, the default choice below 2048 clips),
-    with the clip-sequential scalar ones (mid-size batches, and every configuration the others do not cover) and with the
-    packed-fp32 clip-sequential ones (large batches). Only lean 6-D calls have variants; for the rest the setting is a
-    no-op."""
+    """Every case runs four times: with the time-parallel kernels (small batches, the default choice below 2048 clips),
+    with the joint-lane clip-sequential ones (every configuration the others do not cover), with the packed-fp32
+    clip-sequential ones (opt-in) and with the chain-lane kernels (large batches of the training configuration: eight clips
+    per wavefront, csrc/p2c_pose_head_chain.hip). Only lean 6-D calls have variants; for the rest the setting is a no-op."""
     from pedestrians_video_2_carla_amd import _lib
     lib = _lib.lib()
     prev_tp = lib.p2c_pose_head_set_time_parallel_max_batch(1 << 30 if request.param == 'time_parallel' else 0)
     prev_pk = lib.p2c_pose_head_set_packed_min_batch(0 if request.param == 'packed' else 1 << 30)
+    prev_ch = lib.p2c_pose_head_set_chain_min_batch(0 if request.param == 'chain' else 1 << 30)
     yield request.param
     lib.p2c_pose_head_set_time_parallel_max_batch(prev_tp)
     lib.p2c_pose_head_set_packed_min_batch(prev_pk)
+    lib.p2c_pose_head_set_chain_min_batch(prev_ch)
 
 
 def close(a, b, what, rtol=RTOL, fp32_ref=None):
@@ -45,6 +47,22 @@ def close(a, b, what, rtol=RTOL, fp32_ref=None):
     if fp32_ref is not None:
         bound = max(bound, 2.0 * (fp32_ref.detach().double().cpu() - b).abs().max().item())
     assert math.isfinite(err) and err <= bound, f'{what}: max err {err:.3e} vs scale {scale:.3e} (bound {bound:.3e})'
+
+
+def close_per_clip(a, b, what, fp32_ref, rtol=RTOL, noise=8.0):
+    """Per clip: max|a - b| <= max(rtol * max|b| of THAT clip, noise x the error the fp32 oracle itself makes on that clip).
+    Tighter than ``close`` for the well-conditioned clips of a batch (their own gradient scale counts, not the batch's), and
+    explicit about the ill-conditioned ones: a clip whose projected hips-neck distance is a fraction of a pixel carries
+    gradients of 1e4..1e5 that cancel down to 1e3 along the kinematic chain -- any fp32 evaluation, the reference's included,
+    is off by 1e-5..1e-4 of the result there, by an amount that depends on the summation order."""
+    a, b, r = (t.detach().double().cpu() for t in (a, b, fp32_ref))
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    dims = tuple(range(1, a.ndim))
+    err, scale, ref_err = (a - b).abs().amax(dims), b.abs().amax(dims), (r - b).abs().amax(dims)
+    bound = torch.maximum(rtol * scale, noise * ref_err) + 1e-30
+    worst = int((err / bound).argmax())
+    assert torch.isfinite(err).all() and bool((err <= bound).all()), \
+        f'{what}: clip {worst}: err {float(err[worst]):.3e} vs scale {float(scale[worst]):.3e}, fp32 oracle err {float(ref_err[worst]):.3e}'
 
 
 def run_hip(y, spec, skel_type, dloc=None, drot=None, gt2d=None, gt3d=None, want=None, grad=True,
@@ -362,3 +380,81 @@ def test_deferred_loss_finalize_equals_the_separate_launch(kind, B, T, mode):
         assert torch.equal(l2.vector, mat_vec)
     assert torch.equal(got_g, ref_g)
     torch.testing.assert_close(got_vec, ref_vec, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize('kind', ['pose_changes_6d', 'relative_rot_6d'])
+@pytest.mark.parametrize('transform', ['none', 'hips_neck', 'bbox', 'hips_neck_bbox'])
+@pytest.mark.parametrize('B,T', [(1, 1), (7, 5), (8, 16), (37, 7), (129, 16), (9, 33)])
+def test_chain_lane_kernels_lean_forward_and_backward(kind, transform, B, T, kernel_variant):
+    """The chain-lane kernels (eight clips per wavefront, csrc/p2c_pose_head_chain.hip) on LEAN calls -- the only ones their
+    forward takes: every loss requested on its own, ragged batches (partly filled wavefronts, T != 16), all four transforms,
+    masked target joints, both 6-D kinds, an eval slice; against the fp64 oracle, and against the joint-lane kernels."""
+    if kernel_variant != 'chain':
+        pytest.skip('runs once, under the chain variant')
+    from pedestrians_video_2_carla_amd import _lib
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    y, st, gt2, gt3, gt2_px = _random_case(B, T, seed=B * 1000 + T)
+    if transform == 'none':
+        gt2 = gt2_px
+    elif transform != 'hips_neck_bbox':
+        gt2 = O.normalize(gt2_px.double(), transform)[0].float()
+    sl = (1, T - 1) if T > 4 else (0, T)
+    spec = PoseHeadSpec(kind=kind, transform=transform, eval_slice=sl)
+    for upstream in ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0), (0.3, -0.7, 1.1)):
+        losses, outs, grad = run_hip(y, spec, st, gt2d=gt2, gt3d=gt3, want=(), upstream=upstream)
+        assert not outs
+        o, gref = run_oracle(y, kind, st, gt2d=gt2, gt3d=gt3, upstream=upstream, transform=transform, eval_slice=slice(*sl))
+        _, g32 = run_oracle(y, kind, st, gt2d=gt2, gt3d=gt3, upstream=upstream, dtype=torch.float32, transform=transform,
+                            eval_slice=slice(*sl))
+        for i, k in enumerate(('loc_2d', 'loc_3d', 'loc_2d_3d')):
+            close(losses[i], o[k], f'{k} {upstream}')
+        close_per_clip(grad, gref, f'grad {upstream}', g32)
+    lib = _lib.lib()
+    lib.p2c_pose_head_set_chain_min_batch(1 << 30)                      # the joint-lane kernels on the same call
+    try:
+        l_old, _, g_old = run_hip(y, spec, st, gt2d=gt2, gt3d=gt3, want=(), upstream=upstream)
+    finally:
+        lib.p2c_pose_head_set_chain_min_batch(0)
+    l_new, _, g_new = run_hip(y, spec, st, gt2d=gt2, gt3d=gt3, want=(), upstream=upstream)
+    close(l_new.vector, l_old.vector, 'losses, chain vs joint lanes', rtol=1e-4)
+    close_per_clip(g_new, gref, 'gradient, chain lanes (last upstream)', g32)
+    close_per_clip(g_old, gref, 'gradient, joint lanes (last upstream)', g32)
+
+
+def test_chain_lane_kernels_bbox_fallback_frames_and_single_targets(kernel_variant, monkeypatch):
+    """hips_neck_bbox where the fallback really runs: with the principal point moved off the image (spec.camera) the hips and
+    the neck project to negative pixels ("missing", tensors.py:16) while the legs stay visible, so the scale comes from the
+    bounding box of the visible joints and its gradient goes through the first joint holding each extreme; mixed with clips
+    of the default camera's kind via a per-clip root turn. Then calls with only one of the two targets."""
+    if kernel_variant != 'chain':
+        pytest.skip('runs once, under the chain variant')
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    B, T = 19, 6
+    y, st, gt2, gt3, _ = _random_case(B, T, seed=99, missing=0.05)
+    cam = (400.0, -600.0, -160.0, 3.1, 1.2)
+    orig = O.project
+    monkeypatch.setattr(O, 'project', lambda a, w, r: orig(a, w, r, cx=cam[1], cy=cam[2]))
+    spec = PoseHeadSpec(kind='pose_changes_6d', transform='hips_neck_bbox', camera=cam)
+    losses, _, grad = run_hip(y, spec, st, gt2d=gt2, gt3d=gt3, want=())
+    o, gref = run_oracle(y, 'pose_changes_6d', st, gt2d=gt2, gt3d=gt3)
+    _, g32 = run_oracle(y, 'pose_changes_6d', st, gt2d=gt2, gt3d=gt3, dtype=torch.float32)
+    hips = o['projection_2d'][:, :, 1, :2]
+    assert bool((hips < 1e-5).all(-1).any()), 'the case must contain frames whose hips count as missing'
+    close(losses[2], o['loc_2d_3d'], 'loss, bbox fallback frames')
+    # In frames where no joint (or a single one) stays visible the box has no extent: the normalised pose is nan -> 0 in the
+    # forward (normalizer.py:30), and torch's autograd then yields NaN gradients for the whole clip (0 x NaN), where the kernels
+    # pass a zero gradient through that frame. Gradients are compared on the clips whose reference gradient is finite.
+    finite = torch.isfinite(gref).all(-1).all(-1).all(-1)
+    assert 8 <= int(finite.sum()) < B and bool((hips[finite] < 1e-5).all(-1).any())
+    assert torch.isfinite(grad).all()
+    close(grad[finite], gref[finite], 'grad, bbox fallback frames', fp32_ref=g32[finite])
+    monkeypatch.setattr(O, 'project', orig)
+    spec = PoseHeadSpec(kind='pose_changes_6d', transform='hips_neck_bbox')
+    l2, _, g2 = run_hip(y, spec, st, gt2d=gt2, gt3d=None, want=(), upstream=(1.0, 0.0, 0.0))
+    o2, gr2 = run_oracle(y, 'pose_changes_6d', st, gt2d=gt2, gt3d=None, upstream=(1.0, 0.0, 0.0))
+    close(l2[0], o2['loc_2d'], 'loc_2d alone')
+    close(g2, gr2, 'grad, loc_2d alone')
+    l3, _, g3 = run_hip(y, spec, st, gt2d=None, gt3d=gt3, want=(), upstream=(0.0, 1.0, 0.0))
+    o3, gr3 = run_oracle(y, 'pose_changes_6d', st, gt2d=None, gt3d=gt3, upstream=(0.0, 1.0, 0.0))
+    close(l3[1], o3['loc_3d'], 'loc_3d alone')
+    close(g3, gr3, 'grad, loc_3d alone')

@@ -43,9 +43,17 @@ def main():
         desc = ops._fill_desc(spec, y, st, None, None, gt2, gt3, bufs, {})
         gl = torch.tensor([0.0, 0.0, 1.0], **f32)
         gy = torch.empty_like(y)
-        for variant, max_b, min_pk in (('time_parallel', 1 << 30, 1 << 30), ('clip_sequential', 0, 1 << 30), ('packed', 0, 0)):
+        variants = (('time_parallel', 1 << 30, 1 << 30, 1 << 30), ('joint_lane', 0, 1 << 30, 1 << 30), ('packed', 0, 0, 1 << 30),
+                    ('chain_lane', 0, 1 << 30, 0))
+        only = os.environ.get('KBENCH_VARIANTS')
+        for variant, max_b, min_pk, min_chain in variants:
+            if only and variant not in only.split(','):
+                continue
+            if variant == 'time_parallel' and B > 8192:
+                continue
             prev = lib.p2c_pose_head_set_time_parallel_max_batch(max_b)
             prev_pk = lib.p2c_pose_head_set_packed_min_batch(min_pk)
+            prev_ch = lib.p2c_pose_head_set_chain_min_batch(min_chain)
             with torch.cuda.stream(stream):
                 s = stream.cuda_stream
                 tf = graph_time(lambda: _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), s), 'fwd'), stream)
@@ -54,8 +62,10 @@ def main():
                     stream)
             lib.p2c_pose_head_set_time_parallel_max_batch(prev)
             lib.p2c_pose_head_set_packed_min_batch(prev_pk)
+            lib.p2c_pose_head_set_chain_min_batch(prev_ch)
             print(json.dumps(dict(B=B, variant=variant, fwd_us=round(tf, 2), bwd_us=round(tb, 2),
-                                  fwd_GBps=round(FWD_B * B / tf / 1e3, 1), bwd_GBps=round(BWD_B * B / tb / 1e3, 1))))
+                                  fwd_GBps=round(FWD_B * B / tf / 1e3, 1), bwd_GBps=round(BWD_B * B / tb / 1e3, 1),
+                                  fwd_frac=round(FWD_B * B / tf / 1e3 / 8000, 3), bwd_frac=round(BWD_B * B / tb / 1e3 / 8000, 3))), flush=True)
 
 
 if __name__ == '__main__':
