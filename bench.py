@@ -20,7 +20,8 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   step_breakdown_us  device time of every launch of the step at the benchmark batch (graph-timed, HIP events)
   roofline     the launch that takes the most time in the step: algorithmic flops (vs the 157.3 TFLOP/s fp32 MFMA peak) or
                bytes (vs 8 TB/s HBM) per launch / measured duration, PMC traffic; `other` = the rest
-  roofline_sweep  the pose-head kernels at B = 256, 1024, 8192, 65536 (the step at B=256 is latency-bound by construction)
+  roofline_sweep  the pose-head kernels p2c_pose_head_fwd / _bwd dispatch to at B = 256, 1024, 8192, 16384, 65536 (time-parallel,
+                  joint-lane, chain-lane by batch; each kernel timed alone, the forward op with its loss reduction beside it)
   extra_configs  BASELINE.json configs[1] (B = 1024), configs[2] (autoencoder, Seq2SeqEmbeddings, B = 512) and one GPU's share
                  of configs[4] (PoseFormer, clip_length 81, B = 32) on this GPU
   cpu_baseline the op-for-op CPU port of the reference step (oracle/reference_port.py) timed on this host's cores:
@@ -108,8 +109,11 @@ def kernel_times(device, B, reps=20):
     with torch.cuda.stream(stream):
         s = stream.cuda_stream
 
-        def fwd():
+        def fwd():                  # the forward op: the pose-head kernel + the one-workgroup loss reduction behind it
             _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), s), 'fwd')
+
+        def fwd_kernel():           # the pose-head kernel alone (what rocprofv3's per-kernel average is compared with)
+            _lib.check(lib.p2c_pose_head_fwd_launch(ctypes.byref(desc), 1, s), 'fwd kernel')
 
         def bwd():
             _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), _lib.grad_loss_pointers(vector=gl.data_ptr()), None, None, None, gy.data_ptr(), s), 'bwd')
@@ -123,7 +127,7 @@ def kernel_times(device, B, reps=20):
         fwd()
         bwd()
         stream.synchronize()
-        for name, fn in (('fwd', fwd), ('bwd', bwd), ('train', train)):
+        for name, fn in (('fwd_op', fwd), ('fwd', fwd_kernel), ('bwd', bwd), ('train', train)):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=stream):
                 for _ in range(reps):
@@ -137,8 +141,19 @@ def kernel_times(device, B, reps=20):
                 graph.replay()
             e1.record(stream)
             e1.synchronize()
-            out[name] = e0.elapsed_time(e1) * 1e3 / (reps * rounds)      # us per launch (fwd: head + 1-block reduce)
+            out[name] = e0.elapsed_time(e1) * 1e3 / (reps * rounds)      # us per launch (fwd_op: head + 1-block reduce)
     return out
+
+
+def head_kernel_names(B):
+    """The pose-head kernels p2c_pose_head_fwd / _bwd dispatch to at batch B (6-D kind, lean outputs, T = 16): time-parallel up
+    to P2C_TP_MAX_B (2048), chain-lane from P2C_CHAIN_MIN_B (8192), joint-lane clip-sequential between."""
+    tp, ch = int(os.environ.get('P2C_TP_MAX_B', '2048')), int(os.environ.get('P2C_CHAIN_MIN_B', '8192'))
+    if B <= tp:
+        return {'fwd': 'pose_head_rot_fwd_tp<6D>', 'bwd': 'pose_head_rot_bwd_tangent_tp<6D>'}
+    if B >= ch:
+        return {'fwd': 'pose_head_chain_fwd<6D>', 'bwd': 'pose_head_chain_bwd<6D>'}
+    return {'fwd': 'pose_head_rot_fwd<6D>', 'bwd': 'pose_head_rot_bwd_tangent<6D>'}
 
 
 def _graph_us(fn, stream, reps=20, rounds=5):
@@ -728,7 +743,7 @@ def main():
         entries['train_clip_kernel']['hbm_view'] = roofline_entry('train_clip_kernel', B, ft['train_clip_kernel'], step_bytes)
     else:
         kt = kernel_times(device, B)
-        names = {'fwd': 'pose_head_rot_fwd<6D>(+loss_finalize)', 'bwd': 'pose_head_rot_bwd<6D>'}
+        names = head_kernel_names(B)
         per_clip = {'fwd': BYTES_FWD, 'bwd': BYTES_BWD}
         for w in ('fwd', 'bwd'):
             entries[names[w]] = with_traffic(roofline_entry(names[w], B, kt[w], per_clip[w]))
@@ -746,14 +761,17 @@ def main():
     result['roofline'] = entries.pop(dominant)
     result['roofline']['other'] = list(entries.values())
     if not args.no_sweep and world == 1:
-        names = {'fwd': 'pose_head_rot_fwd<6D>(+loss_finalize)', 'bwd': 'pose_head_rot_bwd<6D>'}
         per_clip = {'fwd': BYTES_FWD, 'bwd': BYTES_BWD}
         sweep = []
-        for Bs in (256, 1024, 8192, 65536):
+        for Bs in (256, 1024, 8192, 16384, 65536):
             k = kernel_times(device, Bs, reps=10 if Bs > 8192 else 20)
+            names = head_kernel_names(Bs)
             for which in ('fwd', 'bwd'):
-                sweep.append(roofline_entry(names[which], Bs, k[which], per_clip[which],
-                                            (traffic.get(f'{names[which]}@B{Bs}') or {}).get('bytes')))
+                e = roofline_entry(names[which], Bs, k[which], per_clip[which],
+                                   (traffic.get(f'{names[which]}@B{Bs}') or {}).get('bytes'))
+                if which == 'fwd':            # the op = this kernel + the one-workgroup loss reduction (a second launch)
+                    e['us_per_op_with_loss_finalize'] = round(k['fwd_op'], 2)
+                sweep.append(e)
         result['roofline_sweep'] = sweep
     if not args.no_extra_configs and world == 1:
         extra = {}

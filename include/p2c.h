@@ -136,6 +136,9 @@ P2C_API int p2c_pose_head_set_chain_min_batch(int32_t min_b);
  * (pose head + deterministic reduction of the per-wave partial sums); with desc->defer_loss_finalize = 1 / 2 one launch
  * (no reduction / only the per-clip count of unmasked target pairs) -- see the field's comment. */
 P2C_API int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream);
+/* Measurement hook (bench.py, rocprofv3 cross-check): the launches of p2c_pose_head_fwd one at a time. which = 1: the
+ * pose-head kernel alone, 2: the one-workgroup loss reduction alone, 3: both (= p2c_pose_head_fwd). */
+P2C_API int p2c_pose_head_fwd_launch(const p2c_pose_head_desc *desc, int32_t which, void *stream);
 
 /* Backward (recompute): grad_y has the layout of desc->y. `grad_losses` = host array of three device pointers (each
  * NULL = no gradient, or one float): the upstream gradients of (loc_2d, loc_3d, loc_2d_3d) -- for a 3-vector gradient g

@@ -643,13 +643,25 @@ __global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc
 // deterministic second stage of the loss reduction (fixed order, fp64 accumulators)
 // =====================================================================================================================
 __global__ __launch_bounds__(256) void loss_finalize(const float *partials, int n_waves, float n3_elems, int has2d,
-                                                     int has3d, float *loss_sums, float *losses) {
+                                                      int has3d, float *loss_sums, float *losses) {
+  // One workgroup, fixed order: thread i adds partials i, i + 256, ... (fp64), then a tree over the threads (p2c_train.hip's
+  // finalize_losses keeps the same order: bit-identical losses). Every partial is one 16-byte load, eight of them in flight per
+  // thread: with dword loads in a rolled loop this launch took 15 us for the 8192 partials of a 65 536-clip batch -- 6 % of
+  // the kernel whose sums it adds.
   __shared__ double sh[3][256];
+  const float4 *p4 = reinterpret_cast<const float4 *>(partials);
   double a = 0.0, b = 0.0, c = 0.0;
-  for (int i = threadIdx.x; i < n_waves; i += 256) {
-    a += (double)partials[i * 4 + 0];
-    b += (double)partials[i * 4 + 1];
-    c += (double)partials[i * 4 + 2];
+  int i = threadIdx.x;
+  for (; i + 7 * 256 < n_waves; i += 8 * 256) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p4[i + u * 256];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += (double)v[u].x, b += (double)v[u].y, c += (double)v[u].z;
+  }
+  for (; i < n_waves; i += 256) {
+    const float4 v = p4[i];
+    a += (double)v.x, b += (double)v.y, c += (double)v.z;
   }
   sh[0][threadIdx.x] = a, sh[1][threadIdx.x] = b, sh[2][threadIdx.x] = c;
   __syncthreads();
@@ -784,7 +796,8 @@ extern "C" int64_t p2c_pose_head_workspace_floats(int32_t B) {
   return seq > tp ? seq : tp;
 }
 
-extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) {
+// which: bit 0 = the pose-head kernel, bit 1 = the one-workgroup loss reduction behind it (p2c_pose_head_fwd_launch: measurement)
+static int pose_head_fwd_impl(const p2c_pose_head_desc *desc, void *stream_, int which) {
   int rc = validate(desc);
   if (rc) return rc;
   const p2c_pose_head_desc d = *desc;
@@ -804,8 +817,9 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
   }
   const dim3 tp_grid((unsigned)d.B), tp_block(tp_threads(d.T)), pk_grid(grid_pk(d.B));
   if (!mat && use_chain(d)) {            // large batch of the training configuration: eight clips per wavefront
-    rc = p2c_internal_chain_fwd(d, stream);
+    rc = (which & 1) ? p2c_internal_chain_fwd(d, stream) : 0;
     if (rc) return rc;
+    if (!(which & 2)) return 0;
     hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, (int)p2c_internal_chain_waves(d.B),
                        n3_elems_host(d), d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
     hipError_t ec = hipGetLastError();
@@ -815,7 +829,7 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
   if (mat) hipLaunchKernelGGL((pose_head_rot_fwd<KIND, true>), grid, block, 0, stream, d);                      \
   else if (tp) hipLaunchKernelGGL((pose_head_rot_fwd_tp<KIND>), tp_grid, tp_block, tp_lds_bytes(d.T), stream, d); \
   else hipLaunchKernelGGL((pose_head_rot_fwd<KIND, false>), grid, block, 0, stream, d)
-  switch (d.kind) {
+  if (which & 1) switch (d.kind) {
     case P2C_KIND_POSE_CHANGES_6D:
       if (pkd) hipLaunchKernelGGL((pk::pose_head_rot_fwd_pk<P2C_KIND_POSE_CHANGES_6D>), pk_grid, block, 0, stream, d);
       else { P2C_LAUNCH_ROT_FWD(P2C_KIND_POSE_CHANGES_6D); }
@@ -837,6 +851,7 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
 #undef P2C_LAUNCH_ROT_FWD
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  if (!(which & 2)) return 0;
   if (d.defer_loss_finalize && tp && !mat && !pkd && (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D))
     return 0;                            // p2c_pose_head_bwd's time-parallel kernel finishes the reduction
   int n_waves = tp ? d.B : (int)((pkd ? pk_grid.x : grid.x) * (kBlock / 64));
@@ -845,6 +860,12 @@ extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) 
                      d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int p2c_pose_head_fwd(const p2c_pose_head_desc *desc, void *stream_) { return pose_head_fwd_impl(desc, stream_, 3); }
+extern "C" int p2c_pose_head_fwd_launch(const p2c_pose_head_desc *desc, int32_t which, void *stream_) {
+  if (which < 1 || which > 3) return P2C_E_ENUM;
+  return pose_head_fwd_impl(desc, stream_, which);
 }
 
 extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *const grad_losses_[3],

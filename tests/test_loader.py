@@ -147,3 +147,28 @@ def test_device_loader_feeds_the_captured_train_step(tmp_path):
         curves[graph] = torch.stack(losses).cpu()
     assert len(curves[True]) == 8 and torch.isfinite(curves[True]).all()
     assert torch.equal(curves[True], curves[False])
+
+
+def test_save_predictions_hdf5_round_trip(tmp_path):
+    """The reference writes predictions as HDF5 (data/base/base_datamodule.py:560-630 -> _save_subset :468-508). This image has no
+    h5py, so the test runs only where it is installed; the .npz container above carries the same keys."""
+    pytest.importorskip('h5py')
+    import h5py
+    from pedestrians_video_2_carla_amd.data.base.base_datamodule import BaseDataModule
+    from pedestrians_video_2_carla_amd.data.base.subset_io import load_subset
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    dm = BaseDataModule(data_nodes=CARLA_SKELETON, clip_length=4, batch_size=3)
+    g = torch.Generator().manual_seed(2)
+    sliced = {'projection_2d_transformed': torch.randn(3, 4, 26, 3, generator=g), 'absolute_pose_loc': torch.randn(3, 4, 26, 3, generator=g),
+              'targets': {'absolute_pose_loc': torch.zeros(3, 4, 26, 3), 'world_loc': torch.zeros(3, 4, 3)}}
+    meta = {'age': ['adult', 'child', 'adult'], 'gender': ['male'] * 3, 'clip_id': torch.arange(3)}
+    out_dir = dm.save_predictions('run8', [(sliced, meta)], ['projection_2d_transformed', 'absolute_pose_loc'],
+                                  'projection_2d_transformed', str(tmp_path), predict_set_name='test', prefer_hdf5=True)
+    path = os.path.join(out_dir, 'test.hdf5')
+    with h5py.File(path, 'r') as f:                            # the reference's layout: chunks of one clip, labels as attributes
+        assert f['projection_2d'].shape == (3, 4, 26, 3) and f['projection_2d'].chunks == (1, 4, 26, 3)
+        assert f['meta/age'].dtype == np.uint16 and len(f['meta/age'].attrs['labels']) == 2
+    p2d, targets, m = load_subset(path)
+    assert np.array_equal(p2d, sliced['projection_2d_transformed'].numpy())
+    assert np.array_equal(targets['absolute_pose_loc'], sliced['absolute_pose_loc'].numpy())
+    assert m['age'] == meta['age'] and m['clip_id'].tolist() == [0, 1, 2]

@@ -220,3 +220,35 @@ def test_optimizer_step_is_not_skipped_when_the_fused_backward_did_not_run():
     torch.cuda.synchronize()
     assert float(trainer.optimizers[0].state[trainer.flat.flat_param]['step']) == 2.0
     assert not torch.equal(before, trainer.flat.flat_param.detach())
+
+
+def test_direct_replay_takes_new_batches_by_address():
+    """Direct replay (the captured step is one recorded C-ABI call): a new batch with the static batch's layout is not copied --
+    the call's four input addresses are pointed at its tensors and its target pairs counted -- and a batch that does not have
+    that layout (strings instead of the skeleton-type index; non-contiguous frames) goes through the copying path with the
+    addresses set back to the static buffers. Same losses, bit for bit, as eager on the same sequence of batches."""
+    flow, dm = make(B=48, missing=0.1)
+    eager_flow, _ = make(B=48, missing=0.1)
+    eager = _trainer(eager_flow, dm)
+    trainer = _trainer(flow, dm, use_graph=True)
+    batches = list(dm.train_batches(dev(), 9))
+    batches[3][2].pop('skel_type')                                       # -> copying path (meta of strings only)
+    wide = torch.zeros(48, 16, 26, 4, device=dev())
+    wide[..., :2] = batches[6][0]
+    batches[6] = (wide[..., :2], batches[6][1], batches[6][2])           # non-contiguous frames -> copying path
+    got, want, how = [], [], []
+    for i, b in enumerate(batches):
+        static_before = trainer._static_batch[0].clone() if trainer._static_batch is not None else None
+        got.append(trainer.train_step(flow, b, i).clone())
+        eb = (b[0].contiguous(), b[1], dict(b[2]))
+        want.append(eager.train_step(eager_flow, eb, i).clone())
+        how.append('handed over' if trainer._handed_over is b else 'copied')
+        if how[-1] == 'handed over':
+            assert torch.equal(trainer._static_batch[0], static_before), 'a handed-over batch is not copied'
+            assert trainer._direct['desc'].mlp.x == b[0].data_ptr()
+        elif i > 0:
+            assert trainer._direct['desc'].mlp.x == trainer._static_batch[0].data_ptr()
+    assert trainer._direct is not None
+    assert how == ['copied', 'handed over', 'handed over', 'copied', 'handed over', 'handed over', 'copied', 'handed over',
+                   'handed over'], how
+    assert torch.equal(torch.stack(got), torch.stack(want)), (torch.stack(got) - torch.stack(want)).abs().max()
