@@ -1,0 +1,220 @@
+// p2c_gemm.hip -- dense layers on fp32 MFMA with a fused epilogue (K16): C = epilogue(A op(B)).
+//
+// What it replaces: the library GEMMs behind every nn.Linear of the model plugins -- PoseTransformer's qkv / proj / fc1 / fc2
+// (reference modules/movements/pose_former/pose_former.py:62-76 binds the transformer; 2.8 TFLOP of fp32 GEMMs per cfg5 step)
+// and the input projections / input gradients around the Seq2Seq recurrences (movements/seq2seq/seq2seq.py:21-94) -- together
+// with the element-wise launches that followed them: bias, GELU (exact erf form, torch.nn.GELU()), its derivative in the
+// backward, the per-sample stochastic-depth factor and the residual add. fp32 in, fp32 accumulate: v_mfma_f32_32x32x2_f32 is
+// bit-for-bit an fmaf chain in k order (no TF32-like shortcut exists on gfx950), 64 FLOP/clk/SIMD = the fp32 peak.
+//
+//   trans_b = 1 ("NT"): B is (N, K) row-major -- y = x W^T, nn.Linear's forward;
+//   trans_b = 0 ("NN"): B is (K, N) row-major -- dx = dy W, its input gradient.
+//   epilogue, in this order:  v = acc + bias[n];  act 1: (aux_out = v;) v = gelu(v);  act 2: v *= gelu'(aux[m][n]);
+//                             v *= row_scale[m / rows_per_scale];  v += residual[m][n];  C[m][n] = v.
+//
+// Tiling: a workgroup of four wavefronts owns a 128 x BN tile of C (BN = 128: 2 x 2 waves of 64 x 64; BN = 64 / 32: 4 x 1 waves
+// of 32 x BN -- the spatial blocks of PoseFormer have 32..96 output features over 546 624 rows and are pure streaming).
+// K advances in steps of 32: the next A / B slabs (128 x 32 floats each: whole 128-byte lines per row) are loaded into
+// registers while the current ones are multiplied out of LDS, where they sit k-major ([k][m], pitch 129: conflict-free both
+// for the transposing stores and for the MFMA operand reads -- lane l reads row l & 31 of k-step l >> 5).
+// The weight gradient dW = dy^T x is K12 (p2c_atb.hip: K >> M, N).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/p2c.h"
+
+namespace p2c_gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 128, BK = 32, NTH = 256;
+constexpr int LDA = BM + 1;          // pitch of the k-major A slab (floats)
+
+__device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float z) {
+  return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * __expf(-0.5f * z * z);
+}
+
+// A slab (BM x BK) from a row-major (rows, K) matrix: thread t takes 16 consecutive k of row t >> 1 (two threads = one 128-byte line)
+struct SlabRegs {
+  f32x4 v[4];
+};
+template <bool VEC>
+__device__ __forceinline__ void load_rows(const float *base, int64_t ld, int row0, int n_rows, int k0, int K, SlabRegs &r, int rows_in_tile) {
+  const int row = (int)threadIdx.x >> 1, kq = ((int)threadIdx.x & 1) * 16;
+  const bool row_ok = row < rows_in_tile && row0 + row < n_rows;
+  const float *p = base + (int64_t)(row0 + (row_ok ? row : 0)) * ld + k0 + kq;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + kq + i * 4;
+    if (VEC) {
+      r.v[i] = (row_ok && k < K) ? *reinterpret_cast<const f32x4 *>(p + i * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.v[i][e] = (row_ok && k + e < K) ? p[i * 4 + e] : 0.f;
+    }
+  }
+}
+// ... into the k-major LDS slab [k][row] (pitch `ld`: odd -> the two threads of a row hit banks 16 apart)
+__device__ __forceinline__ void store_rows_transposed(float *slab, int ld, const SlabRegs &r) {
+  const int row = (int)threadIdx.x >> 1, kq = ((int)threadIdx.x & 1) * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) slab[(kq + i * 4 + e) * ld + row] = r.v[i][e];
+}
+// B slab for the NN form: (BK x BN) from a row-major (K, N) matrix, stored as it is ([k][n], pitch ldb_s)
+template <int BN, bool VEC>
+__device__ __forceinline__ void load_kn(const float *base, int64_t ld, int k0, int K, int n0, int N, SlabRegs &r) {
+  constexpr int PER = BK * BN / NTH;                 // floats per thread: 16 / 8 / 4
+  constexpr int TPR = BN / PER;                      // threads per k-row
+  const int k = (int)threadIdx.x / TPR, n = ((int)threadIdx.x % TPR) * PER;
+  const bool k_ok = k0 + k < K;
+  const float *p = base + (int64_t)(k0 + (k_ok ? k : 0)) * ld + n0 + n;
+#pragma unroll
+  for (int i = 0; i < PER / 4; ++i) {
+    if (VEC) {
+      r.v[i] = (k_ok && n0 + n + i * 4 < N) ? *reinterpret_cast<const f32x4 *>(p + i * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r.v[i][e] = (k_ok && n0 + n + i * 4 + e < N) ? p[i * 4 + e] : 0.f;
+    }
+  }
+}
+template <int BN>
+__device__ __forceinline__ void store_kn(float *slab, int ld, const SlabRegs &r) {
+  constexpr int PER = BK * BN / NTH, TPR = BN / PER;
+  const int k = (int)threadIdx.x / TPR, n = ((int)threadIdx.x % TPR) * PER;
+#pragma unroll
+  for (int i = 0; i < PER / 4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) slab[k * ld + n + i * 4 + e] = r.v[i][e];
+}
+
+template <int BN, bool TRANS_B, bool VEC>
+__global__ __launch_bounds__(NTH) void gemm_kernel(const p2c_gemm_desc d) {
+  constexpr int WM = (BN == 128) ? 2 : 4;            // waves along m
+  constexpr int TM = (BN == 128) ? 2 : 1;            // 32 x 32 MFMA tiles per wave along m ...
+  constexpr int TN = (BN == 128) ? 2 : BN / 32;      // ... and along n
+  constexpr int LDB = BN + 1;
+  __shared__ float As[BK * LDA];
+  __shared__ float Bs[BK * (BN + 4)];
+  const int n_tiles = (d.N + BN - 1) / BN;
+  const int tm = (int)blockIdx.x / n_tiles, tn = (int)blockIdx.x % n_tiles;     // neighbours share the A rows (L2)
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int li = lane & 31, lk = lane >> 5;
+  constexpr int ldb_s = TRANS_B ? LDB : BN + 4;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  SlabRegs ra, rb;
+  const int nk = (d.K + BK - 1) / BK;
+  auto fetch = [&](int kt) {
+    load_rows<VEC>(d.a, d.lda, m0, d.M, kt * BK, d.K, ra, BM);
+    if (TRANS_B) load_rows<VEC>(d.b, d.ldb, n0, d.N, kt * BK, d.K, rb, BN);
+    else load_kn<BN, VEC>(d.b, d.ldb, kt * BK, d.K, n0, d.N, rb);
+  };
+  auto commit = [&]() {
+    store_rows_transposed(As, LDA, ra);
+    if (TRANS_B) {
+      if ((int)threadIdx.x < BN * 2) store_rows_transposed(Bs, ldb_s, rb);
+    } else {
+      store_kn<BN>(Bs, ldb_s, rb);
+    }
+  };
+  fetch(0);
+  commit();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) fetch(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int k = ks * 2 + lk;
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = As[k * LDA + (wm * TM + a) * 32 + li];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = Bs[k * ldb_s + (wn * TN + b) * 32 + li];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      commit();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n0 + (wn * TN + b) * 32 + li;
+    if (n >= d.N) continue;
+    const float bias = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= d.M) continue;
+        float v = acc[a][b][r] + bias;
+        if (d.act == 1) {
+          if (d.aux_out) d.aux_out[(int64_t)m * d.ldaux + n] = v;
+          v = gelu(v);
+        } else if (d.act == 2) {
+          v *= gelu_grad(d.aux[(int64_t)m * d.ldaux + n]);
+        }
+        if (d.row_scale) v *= d.row_scale[m / d.rows_per_scale];
+        if (d.residual) v += d.residual[(int64_t)m * d.ldr + n];
+        d.c[(int64_t)m * d.ldc + n] = v;
+      }
+  }
+}
+
+template <int BN, bool TRANS_B>
+static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
+  const unsigned grid = (unsigned)(((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN));
+  if (vec) hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, true>), dim3(grid), dim3(NTH), 0, s, d);
+  else hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, false>), dim3(grid), dim3(NTH), 0, s, d);
+}
+
+}  // namespace p2c_gemm
+
+extern "C" int p2c_gemm(const p2c_gemm_desc *desc, void *stream_) {
+  using namespace p2c_gemm;
+  if (!desc || !desc->a || !desc->b || !desc->c) return P2C_E_NULL;
+  const p2c_gemm_desc d = *desc;
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.lda < d.K || d.ldc < d.N) return P2C_E_SHAPE;
+  if (d.ldb < (d.trans_b ? d.K : d.N)) return P2C_E_SHAPE;
+  if (d.act < 0 || d.act > 2 || (d.act == 2 && !d.aux) || ((d.aux || d.aux_out) && d.ldaux < d.N)) return P2C_E_ENUM;
+  if (d.row_scale && d.rows_per_scale <= 0) return P2C_E_SHAPE;
+  if (d.residual && d.ldr < d.N) return P2C_E_SHAPE;
+  if ((int64_t)((d.M + BM - 1) / BM) * ((d.N + 31) / 32) > 0x7fffffffll) return P2C_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream_;
+  // 16-byte loads need 16-byte aligned rows: every leading dimension a multiple of 4 floats, bases aligned, K (NT) / N (NN) too
+  auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = al(d.a) && al(d.b) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.K % 4 == 0 && (d.trans_b || d.N % 4 == 0);
+  const int bn = d.N > 64 ? 128 : (d.N > 32 ? 64 : 32);
+  if (d.trans_b) {
+    if (bn == 128) launch<128, true>(d, vec, s);
+    else if (bn == 64) launch<64, true>(d, vec, s);
+    else launch<32, true>(d, vec, s);
+  } else {
+    if (bn == 128) launch<128, false>(d, vec, s);
+    else if (bn == 64) launch<64, false>(d, vec, s);
+    else launch<32, false>(d, vec, s);
+  }
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
