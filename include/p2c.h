@@ -504,6 +504,29 @@ P2C_API int p2c_layernorm_bwd(const float *x, const float *gamma, const float *m
                       float *gx, float *g_gamma, float *g_beta, int32_t accumulate, float *partials, int64_t rows,
                       int32_t D, void *stream);
 
+/* ---- dense layers on fp32 MFMA with a fused epilogue (K16, csrc/p2c_gemm.hip) -----------------------------------------------------
+ * C (M, N) = epilogue(A (M, K) * op(B)): trans_b = 1: B is (N, K) row-major -- y = x W^T, the forward of torch.nn.Linear as the
+ * reference's model plugins use it (PoseTransformer qkv / proj / fc1 / fc2: modules/movements/pose_former/pose_former.py:62-76;
+ * the input projections of the Seq2Seq LSTMs: movements/seq2seq/seq2seq.py:36-38,72-73); trans_b = 0: B is (K, N) row-major --
+ * dx = dy W, its input gradient (the weight gradient dy^T x is p2c_atb). All row-major with leading dimensions in floats.
+ * Epilogue, in this order: v = acc + bias[n] (bias may be NULL); act = 1: aux_out[m][n] = v if aux_out != NULL, then
+ * v = gelu(v) (erf form, torch.nn.GELU()); act = 2: v *= gelu'(aux[m][n]) (the backward through that activation, aux = the
+ * stored pre-activation); v *= row_scale[m / rows_per_scale] if row_scale != NULL (per-sample stochastic-depth factor);
+ * v += residual[m][n] if residual != NULL; C[m][n] = v. C may alias residual. fp32 in, fp32 accumulate (an fmaf chain in k
+ * order). 16-byte loads when every base / leading dimension allows, dword loads otherwise. Returns 0 or P2C_E_*. */
+typedef struct p2c_gemm_desc {
+  int32_t M, N, K, trans_b;
+  const float *a; int64_t lda;
+  const float *b; int64_t ldb;
+  float *c; int64_t ldc;
+  const float *bias;
+  int32_t act, rows_per_scale;
+  const float *aux; float *aux_out; int64_t ldaux;
+  const float *row_scale;
+  const float *residual; int64_t ldr;
+} p2c_gemm_desc;
+P2C_API int p2c_gemm(const p2c_gemm_desc *desc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,14 @@ class AdamWDesc(ctypes.Structure):
                 ('zero_grad', ctypes.c_int32), ('scatter_idx', _f32p), ('scatter_dst', _f32p)]
 
 
+class GemmDesc(ctypes.Structure):
+    """p2c_gemm_desc (include/p2c.h)."""
+    _fields_ = [('M', ctypes.c_int32), ('N', ctypes.c_int32), ('K', ctypes.c_int32), ('trans_b', ctypes.c_int32),
+                ('a', _f32p), ('lda', ctypes.c_int64), ('b', _f32p), ('ldb', ctypes.c_int64), ('c', _f32p), ('ldc', ctypes.c_int64),
+                ('bias', _f32p), ('act', ctypes.c_int32), ('rows_per_scale', ctypes.c_int32), ('aux', _f32p), ('aux_out', _f32p),
+                ('ldaux', ctypes.c_int64), ('row_scale', _f32p), ('residual', _f32p), ('ldr', ctypes.c_int64)]
+
+
 class LstmDesc(ctypes.Structure):
     """p2c_lstm_desc (include/p2c.h)."""
     _fields_ = [('T', ctypes.c_int32), ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('gx', _f32p), ('h0', _f32p),
@@ -108,6 +116,7 @@ SYMBOLS = {
     'p2c_pose_head_set_chain_min_batch': (ctypes.c_int, [ctypes.c_int32]),
     'p2c_pose_head_fwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp]),
     'p2c_pose_head_fwd_launch': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.c_int32, _vp]),
+    'p2c_gemm': (ctypes.c_int, [ctypes.POINTER(GemmDesc), _vp]),
     'p2c_pose_head_bwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.POINTER(_vp * 3), _vp, _vp, _vp, _vp, _vp]),
     'p2c_normalize_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _i32, _ip,
                                          ctypes.c_float, _vp]),

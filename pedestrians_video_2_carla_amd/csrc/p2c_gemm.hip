@@ -23,7 +23,7 @@
 
 #include "../../include/p2c.h"
 
-namespace p2c_gemm {
+namespace p2c_gemm_impl {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -189,10 +189,10 @@ static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
   else hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, false>), dim3(grid), dim3(NTH), 0, s, d);
 }
 
-}  // namespace p2c_gemm
+}  // namespace p2c_gemm_impl
 
 extern "C" int p2c_gemm(const p2c_gemm_desc *desc, void *stream_) {
-  using namespace p2c_gemm;
+  using namespace p2c_gemm_impl;
   if (!desc || !desc->a || !desc->b || !desc->c) return P2C_E_NULL;
   const p2c_gemm_desc d = *desc;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || d.lda < d.K || d.ldc < d.N) return P2C_E_SHAPE;

@@ -24,11 +24,17 @@ import torch.nn.functional as F
 from torch import nn
 
 
-def _linear(layer: nn.Linear, x):
-    """``layer(x)``; fp32 on the GPU it runs through ``ops.dense``: library GEMM forward / input gradient, K12 (p2c_atb) for the
-    weight + bias gradient. The spatial blocks contract 546 624 rows (cfg5: 2 336 windows x 9 frames x 26 joints) into 32..96
-    x 32..64 outputs -- the BLAS pick for that shape took 0.99 ms per layer (16 per step), K12 streams it in 0.22. The
-    temporal blocks (21 024 rows, 832 x 2 496 outputs) are ordinary GEMMs and stay with the library."""
+def _fused(x) -> bool:
+    """fp32 tensors on the GPU outside autocast take the build's own dense kernels (K16 / K12)."""
+    return x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+
+
+def _linear(layer: nn.Linear, x, scale=None, residual=None):
+    """``layer(x)`` [``* scale`` per sample ``+ residual``]; fp32 on the GPU it runs through ``ops.dense``: K16 (csrc/p2c_gemm.hip,
+    fp32 MFMA with the bias, the stochastic-depth factor and the residual add in its epilogue) forward and for the input
+    gradient, K12 (p2c_atb) for the weight + bias gradient. The spatial blocks contract 546 624 rows (cfg5: 2 336 windows x 9
+    frames x 26 joints) into 32..96 x 32..64 outputs -- pure streaming; the temporal blocks (21 024 rows, 832 x 2 496 outputs)
+    are the step's 2.8 TFLOP."""
     if layer.in_features <= 4 and x.is_cuda:
         # Linear(2, E) over 546 624 keypoints: as a GEMM with K = 2 the library took 3.0 ms; as E-wide multiply-adds it is one
         # streaming pass (and its weight gradient two row reductions)
@@ -36,12 +42,17 @@ def _linear(layer: nn.Linear, x):
         for c in range(layer.in_features):
             y = y + x[..., c:c + 1] * layer.weight[:, c]
         return y
-    if (x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
-            and layer.in_features <= 128 and layer.out_features <= 128):
+    if _fused(x):
         from pedestrians_video_2_carla_amd import ops
         shp = x.shape
-        return ops.dense(x.reshape(-1, shp[-1]), layer.weight, layer.bias).view(*shp[:-1], layer.out_features)
-    return layer(x)
+        rows = x.reshape(-1, shp[-1])
+        res = None if residual is None else residual.reshape(-1, layer.out_features)
+        y = ops.dense(rows, layer.weight, layer.bias, scale, rows.shape[0] // shp[0] if scale is not None else 1, res)
+        return y.view(*shp[:-1], layer.out_features)
+    y = layer(x)
+    if scale is not None:
+        y = y * scale.view(-1, *([1] * (y.ndim - 1)))
+    return y if residual is None else y + residual
 
 
 def _norm(layer: nn.LayerNorm, x):
@@ -63,11 +74,22 @@ class _DropPath(nn.Module):
         self.p = float(p)
 
     def forward(self, x):
+        f = self.factor(x)
+        return x if f is None else x * f.view(-1, *([1] * (x.ndim - 1)))
+
+    def factor(self, x):
+        """(samples,) survivor factor 0 or 1 / (1 - p), or None when nothing is dropped: the fused layers apply it in the GEMM
+        epilogue that also adds the residual."""
         if self.p == 0.0 or not self.training:
-            return x
+            return None
         keep = 1.0 - self.p
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
-        return x * mask / keep
+        return x.new_empty(x.shape[0]).bernoulli_(keep).div_(keep)
+
+
+def _combine(y, scale, residual):
+    if scale is not None:
+        y = y * scale.view(-1, *([1] * (y.ndim - 1)))
+    return y if residual is None else y + residual
 
 
 class _Attention(nn.Module):
@@ -79,17 +101,22 @@ class _Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
 
-    def forward(self, x):
+    def forward(self, x, scale=None, residual=None):
+        """attention(x) [* scale per sample + residual]."""
         B, N, C = x.shape
         qkv = _linear(self.qkv, x).reshape(B, N, 3, self.num_heads, C // self.num_heads)
         if x.is_cuda and (self.attn_drop == 0.0 or not self.training):
             from pedestrians_video_2_carla_amd import ops
             if ops.small_attention_supported(N, self.num_heads, C // self.num_heads):      # K14: one launch each way
                 # (fp32 arithmetic also under bf16 autocast: the scores of 4-wide heads gain nothing from bf16 MFMA)
-                return self.proj_drop(_linear(self.proj, ops.small_attention(qkv.float(), self.scale)))
+                att = ops.small_attention(qkv.float(), self.scale)
+                if self.proj_drop.p == 0.0 or not self.training:       # projection, drop-path factor and residual: one launch
+                    return _linear(self.proj, att, scale, residual)
+                y = self.proj_drop(_linear(self.proj, att))
+                return _combine(y, scale, residual)
         q, k, v = qkv.permute(2, 0, 3, 1, 4)
         out = F.scaled_dot_product_attention(q, k, v, dropout_p=self.attn_drop if self.training else 0.0, scale=self.scale)
-        return self.proj_drop(_linear(self.proj, out.transpose(1, 2).reshape(B, N, C)))
+        return _combine(self.proj_drop(_linear(self.proj, out.transpose(1, 2).reshape(B, N, C))), scale, residual)
 
 
 class _Mlp(nn.Module):
@@ -97,8 +124,20 @@ class _Mlp(nn.Module):
         super().__init__()
         self.fc1, self.act, self.fc2, self.drop = nn.Linear(dim, hidden), nn.GELU(), nn.Linear(hidden, dim), nn.Dropout(drop)
 
-    def forward(self, x):
-        return self.drop(_linear(self.fc2, self.drop(self.act(_linear(self.fc1, x)))))
+    def forward(self, x, scale=None, residual=None):
+        """mlp(x) [* scale per sample + residual]; fp32 on the GPU without dropout: ``ops.mlp_gelu`` -- two K16 launches forward
+        (bias + GELU, then bias + factor + residual in the epilogues), two backward (gelu' in the epilogue of fc2's input
+        gradient)."""
+        if _fused(x) and (self.drop.p == 0.0 or not self.training) and isinstance(self.act, nn.GELU) \
+                and self.act.approximate == 'none':
+            from pedestrians_video_2_carla_amd import ops
+            shp = x.shape
+            rows = x.reshape(-1, shp[-1])
+            res = None if residual is None else residual.reshape(-1, self.fc2.out_features)
+            y = ops.mlp_gelu(rows, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, scale,
+                             rows.shape[0] // shp[0] if scale is not None else 1, res)
+            return y.view(*shp[:-1], self.fc2.out_features)
+        return _combine(self.drop(_linear(self.fc2, self.drop(self.act(_linear(self.fc1, x))))), scale, residual)
 
 
 class _Block(nn.Module):
@@ -110,8 +149,9 @@ class _Block(nn.Module):
         self.mlp = _Mlp(dim, int(dim * mlp_ratio), drop)
 
     def forward(self, x):
-        x = x + self.drop_path(self.attn(_norm(self.norm1, x)))
-        return x + self.drop_path(self.mlp(_norm(self.norm2, x)))
+        # (two draws per block and sample, attention first: the order of x + drop_path(attn) ; x + drop_path(mlp))
+        x = self.attn(_norm(self.norm1, x), self.drop_path.factor(x), x)
+        return self.mlp(_norm(self.norm2, x), self.drop_path.factor(x), x)
 
 
 class PoseTransformer(nn.Module):

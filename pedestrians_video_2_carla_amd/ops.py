@@ -1147,30 +1147,108 @@ def atb_group(problems: Sequence[dict]) -> list:
     return results
 
 
+def gemm(a: Tensor, b: Tensor, trans_b: bool, bias: Optional[Tensor] = None, act: int = 0, aux: Optional[Tensor] = None,
+         aux_out: Optional[Tensor] = None, row_scale: Optional[Tensor] = None, rows_per_scale: int = 1,
+         residual: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """K16 (csrc/p2c_gemm.hip): ``out = epilogue(a @ (b.T if trans_b else b))`` on fp32 MFMA, 2-D row-major operands with unit
+    inner stride. Epilogue order: + bias, act (1: GELU, storing the pre-activation in ``aux_out``; 2: times gelu'(``aux``)),
+    times ``row_scale[row // rows_per_scale]``, + ``residual``."""
+    a, b = _require_device(a, 'a'), _require_device(b, 'b')
+    if a.ndim != 2 or b.ndim != 2 or a.stride(1) != 1 or b.stride(1) != 1:
+        raise RuntimeError('gemm: 2-D operands with unit inner stride expected')
+    M, K = a.shape
+    N = b.shape[0] if trans_b else b.shape[1]
+    if (b.shape[1] if trans_b else b.shape[0]) != K:
+        raise RuntimeError(f'gemm: inner dimensions differ: {tuple(a.shape)} x {tuple(b.shape)} (trans_b={trans_b})')
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K, d.trans_b = M, N, K, int(bool(trans_b))
+    d.a, d.lda, d.b, d.ldb, d.c, d.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0)
+    d.bias = _ptr(None if bias is None else _require_device(bias, 'bias'))
+    d.act, d.rows_per_scale = int(act), int(rows_per_scale)
+    for t, name in ((aux, 'aux'), (aux_out, 'aux_out')):
+        if t is not None and (tuple(t.shape) != (M, N) or t.stride(1) != 1):
+            raise RuntimeError(f'gemm: {name} should be ({M}, {N}) with unit inner stride')
+    d.aux, d.aux_out = _ptr(aux), _ptr(aux_out)
+    d.ldaux = (aux if aux is not None else aux_out).stride(0) if (aux is not None or aux_out is not None) else 0
+    if row_scale is not None and row_scale.numel() * rows_per_scale < M:
+        raise RuntimeError('gemm: row_scale is too short')
+    d.row_scale = _ptr(None if row_scale is None else _require_device(row_scale, 'row_scale'))
+    if residual is not None and (tuple(residual.shape) != (M, N) or residual.stride(1) != 1):
+        raise RuntimeError(f'gemm: residual should be ({M}, {N}) with unit inner stride')
+    d.residual, d.ldr = _ptr(residual), (residual.stride(0) if residual is not None else 0)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.lib().p2c_gemm(ctypes.byref(d), _stream()), 'p2c_gemm')
+    return out
+
+
 class DenseFunction(torch.autograd.Function):
-    """y = x W^T + b over (rows, in) with the library GEMM forward and p2c_atb for the weight + bias gradient."""
+    """y = (x W^T + b) * scale[row // rows_per_scale] + residual over (rows, in): K16 forward and input gradient (the scale --
+    a per-sample stochastic-depth factor -- and the residual ride in the GEMM epilogues), K12 (p2c_atb) for the weight + bias
+    gradient."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        return torch.nn.functional.linear(x, w, b)
+    def forward(ctx, x, w, b, scale, rows_per_scale, residual):
+        ctx.save_for_backward(x, w, scale)
+        ctx.has_bias, ctx.rows_per_scale, ctx.has_residual = b is not None, rows_per_scale, residual is not None
+        return gemm(x, w, True, bias=b, row_scale=scale, rows_per_scale=rows_per_scale, residual=residual)
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, scale = ctx.saved_tensors
         gy = gy.contiguous()
-        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gx = gemm(gy, w, False, row_scale=scale, rows_per_scale=ctx.rows_per_scale) if ctx.needs_input_grad[0] else None
+        gys = gy if scale is None else (gy.view(scale.numel(), -1) * scale.view(-1, 1)).view_as(gy)
         sink = _sink(w)
-        gw, gb = atb(gy, x, bias=ctx.has_bias, out=sink, accumulate=sink is not None)
-        return gx, (None if sink is not None else gw), gb
+        gw, gb = atb(gys, x, bias=ctx.has_bias, out=sink, accumulate=sink is not None)
+        return gx, (None if sink is not None else gw), gb, None, None, (gy if ctx.has_residual else None)
 
 
-def dense(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
-    """``torch.nn.functional.linear`` for 2-D x whose backward runs p2c_atb (rows >> features)."""
-    if x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.shape[0] >= 1024:
-        return DenseFunction.apply(x, w, b)
-    return torch.nn.functional.linear(x, w, b)
+def dense(x: Tensor, w: Tensor, b: Optional[Tensor], scale: Optional[Tensor] = None, rows_per_scale: int = 1,
+          residual: Optional[Tensor] = None) -> Tensor:
+    """``torch.nn.functional.linear`` for 2-D x on the device (K16 + K12), optionally followed by a per-sample factor and a
+    residual add in the same launch; host tensors / other dtypes take the framework ops."""
+    if (x.is_cuda and x.dtype == torch.float32 and x.ndim == 2 and x.stride(1) == 1 and w.is_cuda and w.dtype == torch.float32
+            and w.stride(1) == 1 and not torch.is_autocast_enabled()):
+        return DenseFunction.apply(x, w, b, scale, rows_per_scale, None if residual is None else residual.contiguous())
+    y = torch.nn.functional.linear(x, w, b)
+    if scale is not None:
+        y = (y.view(scale.numel(), -1) * scale.view(-1, 1)).view_as(y)
+    return y if residual is None else y + residual
+
+
+class MlpFunction(torch.autograd.Function):
+    """y = (gelu(x W1^T + b1) W2^T + b2) * scale[row // rows_per_scale] + residual -- the feed-forward half of a transformer block
+    as two K16 launches forward (the first stores the pre-activation z beside gelu(z)) and two backward: d z comes out of the
+    second layer's input-gradient GEMM with gelu'(z) and the scale applied in its epilogue; weight gradients through K12."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, scale, rows_per_scale, residual):
+        z = torch.empty(x.shape[0], w1.shape[0], dtype=torch.float32, device=x.device)
+        a = gemm(x, w1, True, bias=b1, act=1, aux_out=z)
+        y = gemm(a, w2, True, bias=b2, row_scale=scale, rows_per_scale=rows_per_scale, residual=residual)
+        ctx.save_for_backward(x, w1, w2, z, a, scale)
+        ctx.rows_per_scale, ctx.has_residual = rows_per_scale, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w1, w2, z, a, scale = ctx.saved_tensors
+        gy = gy.contiguous()
+        dz = gemm(gy, w2, False, act=2, aux=z, row_scale=scale, rows_per_scale=ctx.rows_per_scale)
+        gys = gy if scale is None else (gy.view(scale.numel(), -1) * scale.view(-1, 1)).view_as(gy)
+        s2, s1 = _sink(w2), _sink(w1)
+        gw2, gb2 = atb(gys, a, bias=True, out=s2, accumulate=s2 is not None)
+        gw1, gb1 = atb(dz, x, bias=True, out=s1, accumulate=s1 is not None)
+        gx = gemm(dz, w1, False) if ctx.needs_input_grad[0] else None
+        return (gx, None if s1 is not None else gw1, gb1, None if s2 is not None else gw2, gb2, None, None,
+                gy if ctx.has_residual else None)
+
+
+def mlp_gelu(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, scale: Optional[Tensor] = None,
+             rows_per_scale: int = 1, residual: Optional[Tensor] = None) -> Tensor:
+    return MlpFunction.apply(x, w1, b1, w2, b2, scale, rows_per_scale, None if residual is None else residual.contiguous())
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -1402,13 +1480,13 @@ class EncoderStackFunction(torch.autograd.Function):
             _lib.check(lib.p2c_lstm_rec_fwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_fwd')
 
         with torch.cuda.device(x.device):
-            gx0 = torch.mm(x.view(B * T, I), w_in.t())                     # (B,T,4H) rows, bias-free
+            gx0 = gemm(x.view(B * T, I), w_in, True)                       # (B,T,4H) rows, bias-free (K16)
             rec(gx0, True, b_in_a, b_in_b, w_hh0, out0, acts0, cs0, 0)
             mask = None
             x1 = out0
             if train and p_drop > 0:
                 x1, mask = torch.native_dropout(out0, p_drop, True)
-            gx1 = torch.mm(x1.view(T * B, H), w_ih1.t())
+            gx1 = gemm(x1.view(T * B, H), w_ih1, True)
             rec(gx1, False, b_ih1, b_hh1, w_hh1, out1, acts1, cs1, 1)
         ctx.save_for_backward(x, w_in, b_in_a, b_in_b, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1, out0, x1, mask, out1, acts0, cs0, acts1, cs1)
         ctx.p_drop = p_drop
@@ -1438,7 +1516,7 @@ class EncoderStackFunction(torch.autograd.Function):
 
         with torch.cuda.device(x.device):
             rec(w_hh1, acts1, cs1, None, 1, g_gx1)
-            g_x1 = torch.mm(g_gx1.view(T * B, G), w_ih1).view(T, B, H)
+            g_x1 = gemm(g_gx1.view(T * B, G), w_ih1, False).view(T, B, H)
             if mask is not None:
                 g_x1 = torch.ops.aten.native_dropout_backward(g_x1, mask, 1.0 / (1.0 - ctx.p_drop))
             rec(w_hh0, acts0, cs0, g_x1, 0, g_gx0, g_gx0_bt)
