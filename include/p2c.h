@@ -526,6 +526,13 @@ typedef struct p2c_gemm_desc {
   const float *residual; int64_t ldr;
 } p2c_gemm_desc;
 P2C_API int p2c_gemm(const p2c_gemm_desc *desc, void *stream);
+/* The weight gradient of a WIDE dense layer, C (M, N) (+)= A^T B with A (K, M) and B (K, N) row-major over K = rows >> M, N
+ * (dW = dy^T x; p2c_atb covers layers of up to ~128 features): the same MFMA tiles, K split into slices that each write a slab
+ * of `workspace` (p2c_gemm_tn_workspace_floats(M, N, K) floats), added in slice order by a second launch -- bitwise
+ * reproducible. accumulate != 0 adds to C. */
+P2C_API int64_t p2c_gemm_tn_workspace_floats(int32_t M, int32_t N, int32_t K);
+P2C_API int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t M, int32_t N,
+                int32_t K, int32_t accumulate, float *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -92,6 +92,92 @@ __device__ __forceinline__ void store_kn(float *slab, int ld, const SlabRegs &r)
     for (int e = 0; e < 4; ++e) slab[k * ld + n + i * 4 + e] = r.v[i][e];
 }
 
+// TN form (weight gradients of wide layers, dW = dy^T x: A = dy is (K, M) row-major, B = x is (K, N) row-major, K = rows >> M, N):
+// split over K in `slices` (blockIdx.y), every slice writes its own (M, N) slab of the workspace, tn_finish_kernel adds the
+// slabs in slice order (bitwise reproducible, no atomics) into C, written or accumulated.
+struct TnArgs {
+  const float *a, *b;
+  float *ws, *c;
+  int64_t lda, ldb, ldc;
+  int32_t M, N, K, k_chunk, slices, accumulate;
+};
+template <int BN, bool VEC>
+__global__ __launch_bounds__(NTH) void gemm_tn_kernel(const TnArgs d) {
+  constexpr int WM = (BN == 128) ? 2 : 4, TM = (BN == 128) ? 2 : 1, TN = (BN == 128) ? 2 : BN / 32;
+  __shared__ float As[BK * (BM + 4)];
+  __shared__ float Bs[BK * (BN + 4)];
+  const int n_tiles = (d.N + BN - 1) / BN;
+  const int tm = (int)blockIdx.x / n_tiles, tn = (int)blockIdx.x % n_tiles;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave % WM, wn = wave / WM, li = lane & 31, lk = lane >> 5;
+  const int k_begin = (int)blockIdx.y * d.k_chunk, k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  SlabRegs ra, rb;
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  auto fetch = [&](int kt) {
+    load_kn<BM, VEC>(d.a, d.lda, k_begin + kt * BK, k_end, m0, d.M, ra);
+    load_kn<BN, VEC>(d.b, d.ldb, k_begin + kt * BK, k_end, n0, d.N, rb);
+  };
+  auto commit = [&]() {
+    store_kn<BM>(As, BM + 4, ra);
+    store_kn<BN>(Bs, BN + 4, rb);
+  };
+  if (nk > 0) {
+    fetch(0);
+    commit();
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) fetch(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      const int k = ks * 2 + lk;
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[a] = As[k * (BM + 4) + (wm * TM + a) * 32 + li];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[b] = Bs[k * (BN + 4) + (wn * TN + b) * 32 + li];
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      commit();
+      __syncthreads();
+    }
+  }
+  float *slab = d.ws + (int64_t)blockIdx.y * d.M * d.N;
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n0 + (wn * TN + b) * 32 + li;
+    if (n >= d.N) continue;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m < d.M) slab[(int64_t)m * d.N + n] = acc[a][b][r];
+      }
+  }
+}
+__global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
+  const int64_t total = (int64_t)d.M * d.N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int s = 0; s < d.slices; ++s) v += d.ws[(int64_t)s * total + i];
+    float *o = d.c + (i / d.N) * d.ldc + (i % d.N);
+    *o = d.accumulate ? *o + v : v;
+  }
+}
+
 template <int BN, bool TRANS_B, bool VEC>
 __global__ __launch_bounds__(NTH) void gemm_kernel(const p2c_gemm_desc d) {
   constexpr int WM = (BN == 128) ? 2 : 4;            // waves along m
@@ -190,6 +276,57 @@ static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
 }
 
 }  // namespace p2c_gemm_impl
+
+static int tn_slices(int M, int N, int K) {
+  using namespace p2c_gemm_impl;
+  // Every workgroup is MFMA-bound, so the launch takes as long as the busiest CU: pick the slice count whose grid fills the
+  // 256 CUs most evenly (tiles * slices close below a multiple of 256), with at least 16 k-steps per slice.
+  const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
+  int max_s = K / (16 * BK);
+  max_s = max_s < 1 ? 1 : (max_s > 32 ? 32 : max_s);
+  int best = 1;
+  double best_fill = 0.0;
+  for (int s = 1; s <= max_s; ++s) {
+    const int blocks = tiles * s, rounds = (blocks + 255) / 256;
+    const double fill = (double)blocks / (rounds * 256.0) - 0.004 * s;      // a slab costs a little workspace traffic
+    if (fill > best_fill) best_fill = fill, best = s;
+  }
+  return best;
+}
+extern "C" int64_t p2c_gemm_tn_workspace_floats(int32_t M, int32_t N, int32_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (int64_t)tn_slices(M, N, K) * M * N;
+}
+extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t M, int32_t N,
+                           int32_t K, int32_t accumulate, float *workspace, void *stream_) {
+  using namespace p2c_gemm_impl;
+  if (!a || !b || !c || !workspace) return P2C_E_NULL;
+  if (M <= 0 || N <= 0 || K <= 0 || lda < M || ldb < N || ldc < N) return P2C_E_SHAPE;
+  TnArgs d;
+  d.a = a, d.b = b, d.ws = workspace, d.c = c, d.lda = lda, d.ldb = ldb, d.ldc = ldc, d.M = M, d.N = N, d.K = K;
+  d.slices = tn_slices(M, N, K);
+  d.k_chunk = (((K + d.slices - 1) / d.slices) + BK - 1) / BK * BK;
+  d.accumulate = accumulate;
+  hipStream_t s = (hipStream_t)stream_;
+  auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = al(a) && al(b) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
+  const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  const dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + bn - 1) / bn)), (unsigned)d.slices);
+#define P2C_TN(BN_)                                                                         \
+  do {                                                                                      \
+    if (vec) hipLaunchKernelGGL((gemm_tn_kernel<BN_, true>), grid, dim3(NTH), 0, s, d);     \
+    else hipLaunchKernelGGL((gemm_tn_kernel<BN_, false>), grid, dim3(NTH), 0, s, d);        \
+  } while (0)
+  if (bn == 128) P2C_TN(128);
+  else if (bn == 64) P2C_TN(64);
+  else P2C_TN(32);
+#undef P2C_TN
+  const int64_t total = (int64_t)M * N;
+  hipLaunchKernelGGL(tn_finish_kernel, dim3((unsigned)((total + 1023) / 1024 < 4096 ? (total + 1023) / 1024 : 4096)), dim3(256), 0, s, d);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
 
 extern "C" int p2c_gemm(const p2c_gemm_desc *desc, void *stream_) {
   using namespace p2c_gemm_impl;

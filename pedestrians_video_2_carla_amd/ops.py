@@ -1183,6 +1183,33 @@ def gemm(a: Tensor, b: Tensor, trans_b: bool, bias: Optional[Tensor] = None, act
     return out
 
 
+def gemm_tn(a: Tensor, b: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    """K16, TN form (p2c_gemm_tn): ``out (+)= a^T b`` for a (K, M), b (K, N) with K = rows >> M, N -- the weight gradient of a
+    wide layer; K is split over workgroups and the slabs are added in a fixed order (bitwise reproducible)."""
+    a, b = _require_device(a, 'a'), _require_device(b, 'b')
+    if a.ndim != 2 or b.ndim != 2 or a.stride(1) != 1 or b.stride(1) != 1 or a.shape[0] != b.shape[0]:
+        raise RuntimeError('gemm_tn: (K, M) and (K, N) operands with unit inner stride expected')
+    K, M, N = a.shape[0], a.shape[1], b.shape[1]
+    if out is None:
+        out, accumulate = torch.empty(M, N, dtype=torch.float32, device=a.device), False
+    lib = _lib.lib()
+    ws = torch.empty(max(1, lib.p2c_gemm_tn_workspace_floats(M, N, K)), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.p2c_gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
+                                   int(bool(accumulate)), ws.data_ptr(), _stream()), 'p2c_gemm_tn')
+    return out
+
+
+WIDE_LAYER = 128      # layers with both feature counts above this take the MFMA TN GEMM for dW; K12 (exact-order VALU) below
+
+
+def weight_grad(gy: Tensor, x: Tensor, bias: bool, sink: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
+    """(dW, db) of y = x W^T + b from dY (rows, out) and X (rows, in), accumulated into ``sink`` (= W.grad) when given."""
+    if gy.shape[0] > 0 and gy.shape[1] > WIDE_LAYER and x.shape[1] > WIDE_LAYER:
+        return gemm_tn(gy, x, out=sink, accumulate=sink is not None), (gy.sum(0) if bias else None)
+    return atb(gy, x, bias=bias, out=sink, accumulate=sink is not None)
+
+
 class DenseFunction(torch.autograd.Function):
     """y = (x W^T + b) * scale[row // rows_per_scale] + residual over (rows, in): K16 forward and input gradient (the scale --
     a per-sample stochastic-depth factor -- and the residual ride in the GEMM epilogues), K12 (p2c_atb) for the weight + bias
@@ -1201,7 +1228,7 @@ class DenseFunction(torch.autograd.Function):
         gx = gemm(gy, w, False, row_scale=scale, rows_per_scale=ctx.rows_per_scale) if ctx.needs_input_grad[0] else None
         gys = gy if scale is None else (gy.view(scale.numel(), -1) * scale.view(-1, 1)).view_as(gy)
         sink = _sink(w)
-        gw, gb = atb(gys, x, bias=ctx.has_bias, out=sink, accumulate=sink is not None)
+        gw, gb = weight_grad(gys, x, ctx.has_bias, sink)
         return gx, (None if sink is not None else gw), gb, None, None, (gy if ctx.has_residual else None)
 
 
@@ -1239,8 +1266,8 @@ class MlpFunction(torch.autograd.Function):
         dz = gemm(gy, w2, False, act=2, aux=z, row_scale=scale, rows_per_scale=ctx.rows_per_scale)
         gys = gy if scale is None else (gy.view(scale.numel(), -1) * scale.view(-1, 1)).view_as(gy)
         s2, s1 = _sink(w2), _sink(w1)
-        gw2, gb2 = atb(gys, a, bias=True, out=s2, accumulate=s2 is not None)
-        gw1, gb1 = atb(dz, x, bias=True, out=s1, accumulate=s1 is not None)
+        gw2, gb2 = weight_grad(gys, a, True, s2)
+        gw1, gb1 = weight_grad(dz, x, True, s1)
         gx = gemm(dz, w1, False) if ctx.needs_input_grad[0] else None
         return (gx, None if s1 is not None else gw1, gb1, None if s2 is not None else gw2, gb2, None, None,
                 gy if ctx.has_residual else None)

@@ -39,6 +39,27 @@ def test_gemm_plain_matches_fp64(M, N, K, trans_b):
     assert rel(c, want) < 2e-6 * math.sqrt(K) + 1e-7
 
 
+@pytest.mark.parametrize('K,M,N', [(21024, 2496, 832), (21024, 832, 1664), (4000, 130, 200), (31, 129, 140), (1, 5, 3), (9000, 64, 33),
+                                   (2050, 257, 129)])
+def test_gemm_tn_matches_fp64_is_reproducible_and_accumulates(K, M, N):
+    """dW = dy^T x for wide layers: split-K slabs added in a fixed order -- same bits on every call; accumulate adds to the sink;
+    strided operands (column slices) take the dword loads."""
+    from pedestrians_video_2_carla_amd import ops
+    torch.manual_seed(K + M)
+    a, b = torch.randn(K, M, device=dev()), torch.randn(K, N, device=dev())
+    c = ops.gemm_tn(a, b)
+    want = a.double().t() @ b.double()
+    assert rel(c, want) < 2e-6 * math.sqrt(K) + 1e-7
+    assert torch.equal(c, ops.gemm_tn(a, b))
+    sink = torch.randn(M, N, device=dev())
+    before = sink.clone()
+    ops.gemm_tn(a, b, out=sink, accumulate=True)
+    assert rel(sink, before.double() + want) < 2e-6 * math.sqrt(K) + 1e-7
+    wide_a, wide_b = torch.randn(K, M + 3, device=dev()), torch.randn(K, N + 5, device=dev())
+    c2 = ops.gemm_tn(wide_a[:, 1:M + 1], wide_b[:, 2:N + 2])
+    assert rel(c2, wide_a[:, 1:M + 1].double().t() @ wide_b[:, 2:N + 2].double()) < 2e-6 * math.sqrt(K) + 1e-7
+
+
 def test_gemm_epilogue_and_strided_operands():
     """bias, GELU with the stored pre-activation, gelu' of a stored tensor, per-sample factor, residual (also aliased with the
     output), operands that are column slices of wider tensors (leading dimension > width; not 16-byte aligned -> dword loads)."""
