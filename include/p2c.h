@@ -448,6 +448,12 @@ P2C_API int p2c_collate_fwd(const p2c_collate_desc *desc, void *stream);
 P2C_API int64_t p2c_atb_workspace_floats(int64_t K, int32_t M, int32_t N, int32_t with_bias);
 P2C_API int p2c_atb(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int32_t M, int32_t N, float *C,
                     int64_t ldc, float *bias_out, int32_t accumulate, float *workspace, void *stream);
+/* The same with A's row k multiplied by a_scale[k / rows_per_scale] as it is loaded (NULL = p2c_atb): dY of a transformer
+ * sub-layer whose output carried a per-sample stochastic-depth factor (PoseTransformer blocks behind
+ * modules/movements/pose_former/pose_former.py:62-76), so that no scaled copy of dY is written first. */
+P2C_API int p2c_atb_scaled(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int32_t M, int32_t N, float *C,
+                    int64_t ldc, float *bias_out, int32_t accumulate, const float *a_scale, int64_t rows_per_scale,
+                    float *workspace, void *stream);
 
 /* Grouped form: up to 8 independent problems behind ONE launch pair (the backward of a Seq2Seq layer stack is a row of
  * these contractions). Per problem the fields of p2c_atb; bias_out2 = a second vector that receives the same column sums
@@ -494,15 +500,16 @@ P2C_API int p2c_attn_small_bwd(const float *qkv, const float *g_out, float *g_qk
  * torch.nn.LayerNorm(D) (biased variance, eps inside the root) as the build's PoseTransformer applies it (546 624 rows of 32,
  * 21 024 rows of 832; reference binding: modules/movements/pose_former/pose_former.py:33-76). x, y, gy, gx (rows, D)
  * row-major and 16-byte aligned, D % 4 == 0, D <= 1024; gamma / beta (D), any 4-byte alignment. Forward also writes mean and
- * rstd (rows) for the backward. Backward: gx, and g_gamma / g_beta written (accumulate = 0) or added to; partials =
- * p2c_layernorm_workspace_floats floats; two launches, fixed summation order. */
+ * rstd (rows) for the backward. Backward: gx (+ gx_add (rows, D) when not NULL: the gradient arriving over the residual
+ * connection that branches off in front of a pre-norm layer, added in the same pass), and g_gamma / g_beta written
+ * (accumulate = 0) or added to; partials = p2c_layernorm_workspace_floats floats; two launches, fixed summation order. */
 P2C_API int p2c_layernorm_supported(int32_t D);
 P2C_API int64_t p2c_layernorm_workspace_floats(int64_t rows, int32_t D);
 P2C_API int p2c_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
                       int64_t rows, int32_t D, float eps, void *stream);
 P2C_API int p2c_layernorm_bwd(const float *x, const float *gamma, const float *mean, const float *rstd, const float *gy,
-                      float *gx, float *g_gamma, float *g_beta, int32_t accumulate, float *partials, int64_t rows,
-                      int32_t D, void *stream);
+                      const float *gx_add, float *gx, float *g_gamma, float *g_beta, int32_t accumulate, float *partials,
+                      int64_t rows, int32_t D, void *stream);
 
 /* ---- dense layers on fp32 MFMA with a fused epilogue (K16, csrc/p2c_gemm.hip) -----------------------------------------------------
  * C (M, N) = epilogue(A (M, K) * op(B)): trans_b = 1: B is (N, K) row-major -- y = x W^T, the forward of torch.nn.Linear as the
@@ -529,10 +536,13 @@ P2C_API int p2c_gemm(const p2c_gemm_desc *desc, void *stream);
 /* The weight gradient of a WIDE dense layer, C (M, N) (+)= A^T B with A (K, M) and B (K, N) row-major over K = rows >> M, N
  * (dW = dy^T x; p2c_atb covers layers of up to ~128 features): the same MFMA tiles, K split into slices that each write a slab
  * of `workspace` (p2c_gemm_tn_workspace_floats(M, N, K) floats), added in slice order by a second launch -- bitwise
- * reproducible. accumulate != 0 adds to C. */
+ * reproducible. accumulate bit 0: add to C; bit 1: add to bias_out. row_scale (NULL = none): A's row k is multiplied by
+ * row_scale[k / rows_per_scale] as it is loaded (dy of a layer whose output carried a per-sample stochastic-depth factor).
+ * bias_out (M) or NULL: the column sums of the scaled A (= db) from the same pass. */
 P2C_API int64_t p2c_gemm_tn_workspace_floats(int32_t M, int32_t N, int32_t K);
 P2C_API int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t M, int32_t N,
-                int32_t K, int32_t accumulate, float *workspace, void *stream);
+                int32_t K, int32_t accumulate, const float *row_scale, int32_t rows_per_scale, float *bias_out,
+                float *workspace, void *stream);
 
 #ifdef __cplusplus
 }

@@ -118,7 +118,7 @@ SYMBOLS = {
     'p2c_pose_head_fwd_launch': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.c_int32, _vp]),
     'p2c_gemm': (ctypes.c_int, [ctypes.POINTER(GemmDesc), _vp]),
     'p2c_gemm_tn_workspace_floats': (_i64, [_i32, _i32, _i32]),
-    'p2c_gemm_tn': (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    'p2c_gemm_tn': (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     'p2c_pose_head_bwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.POINTER(_vp * 3), _vp, _vp, _vp, _vp, _vp]),
     'p2c_normalize_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _i32, _ip,
                                          ctypes.c_float, _vp]),
@@ -153,12 +153,13 @@ SYMBOLS = {
     'p2c_fold_bwd': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, ctypes.c_int32, _vp, _vp, _vp, _vp] + [ctypes.c_int32] * 4 + [_vp]),
     'p2c_atb_workspace_floats': (_i64, [_i64, _i32, _i32, _i32]),
     'p2c_atb': (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
+    'p2c_atb_scaled': (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _vp, _i64, _vp, _vp]),
     'p2c_graph_node_counts': (ctypes.c_int, [_vp, ctypes.POINTER(_i32), ctypes.POINTER(_i32)]),
     'p2c_copy_group': (ctypes.c_int, [_vp, _vp, _vp, _i32, _vp]),
     'p2c_layernorm_supported': (ctypes.c_int, [_i32]),
     'p2c_layernorm_workspace_floats': (_i64, [_i64, _i32]),
     'p2c_layernorm_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, ctypes.c_float, _vp]),
-    'p2c_layernorm_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
+    'p2c_layernorm_bwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
     'p2c_attn_small_supported': (ctypes.c_int, [_i32, _i32, _i32]),
     'p2c_attn_small_fwd': (ctypes.c_int, [_vp, _vp, ctypes.c_float, _i32, _i32, _i32, _i32, _vp]),
     'p2c_attn_small_bwd': (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _i32, _i32, _i32, _i32, _vp]),

@@ -25,6 +25,8 @@ struct Args {
   int64_t lda, ldb, ldc, K;
   int32_t M, N, ones, accumulate, ks, tiles;
   float *bias2;                 // second destination of the bias gradient (b_ih and b_hh of an LSTM layer receive the same sums)
+  const float *a_scale;         // row k of A is multiplied by a_scale[k / rows_per_scale] as it is loaded, or NULL
+  int64_t rows_per_scale;
 };
 
 // One wave accumulates a 32x32 block of C as 2x2 MFMA tiles; lane (r, kk) loads the column PAIRS 2r, 2r+1 of row kk of
@@ -59,6 +61,7 @@ __device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*r
       if (ok) {
         if (vec_a) av[u] = *reinterpret_cast<const f32x2 *>(ap + row * a.lda);
         else av[u] = (f32x2){col(ap, row * a.lda, m, a.M, false), col(ap, row * a.lda + 1, m + 1, a.M, false)};
+        if (a.a_scale) av[u] *= a.a_scale[row / a.rows_per_scale];
         if (vec_b) bv[u] = *reinterpret_cast<const f32x2 *>(bp + row * a.ldb);
         else bv[u] = (f32x2){col(bp, row * a.ldb, n, a.N, a.ones != 0), col(bp, row * a.ldb + 1, n + 1, a.N, a.ones != 0)};
       }
@@ -161,18 +164,25 @@ extern "C" int64_t p2c_atb_workspace_floats(int64_t K, int32_t M, int32_t N, int
   return (int64_t)slices_for(blocks, K) * blocks * 1024;
 }
 
-extern "C" int p2c_atb(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int32_t M, int32_t N, float *C,
-                       int64_t ldc, float *bias_out, int32_t accumulate, float *workspace, void *stream) {
+extern "C" int p2c_atb_scaled(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int32_t M, int32_t N, float *C,
+                              int64_t ldc, float *bias_out, int32_t accumulate, const float *a_scale, int64_t rows_per_scale,
+                              float *workspace, void *stream) {
   using namespace p2c_atb_impl;
   if (!A || !B || !C || !workspace) return P2C_E_NULL;
-  if (K < 0 || M < 1 || N < 1 || lda < M || ldb < N || ldc < N) return P2C_E_SHAPE;
-  Args a{A, B, C, bias_out, workspace, lda, ldb, ldc, K, M, N, bias_out ? 1 : 0, accumulate & 3, 1, 0, nullptr};
+  if (K < 0 || M < 1 || N < 1 || lda < M || ldb < N || ldc < N || (a_scale && rows_per_scale < 1)) return P2C_E_SHAPE;
+  Args a{A, B, C, bias_out, workspace, lda, ldb, ldc, K, M, N, bias_out ? 1 : 0, accumulate & 3, 1, 0, nullptr, a_scale,
+         rows_per_scale};
   a.tiles = ((M + 31) / 32) * ((N + a.ones + 31) / 32);      // 32x32 blocks of C
   a.ks = slices_for(a.tiles, K);
   hipLaunchKernelGGL(atb_kernel, dim3((unsigned)(a.tiles * a.ks)), dim3(64 * WAVES), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(atb_finish_kernel, dim3((unsigned)a.tiles), dim3(256), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+extern "C" int p2c_atb(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int32_t M, int32_t N, float *C,
+                       int64_t ldc, float *bias_out, int32_t accumulate, float *workspace, void *stream) {
+  return p2c_atb_scaled(A, lda, B, ldb, K, M, N, C, ldc, bias_out, accumulate, nullptr, 1, workspace, stream);
 }
 
 static int group_fill(const p2c_atb_problem *p, int32_t n, float *workspace, p2c_atb_impl::Group &g, int64_t *ws_total) {
@@ -188,7 +198,7 @@ static int group_fill(const p2c_atb_problem *p, int32_t n, float *workspace, p2c
     if (q.bias_out2 && !q.bias_out) return P2C_E_NULL;
     Args &a = g.p[i];
     a = Args{q.a, q.b, q.out, q.bias_out, workspace ? workspace + off : nullptr, q.a_stride, q.b_stride, q.out_stride, q.K,
-             q.M, q.N, q.bias_out ? 1 : 0, q.flags & 3, 1, 0, q.bias_out2};
+             q.M, q.N, q.bias_out ? 1 : 0, q.flags & 3, 1, 0, q.bias_out2, nullptr, 1};
     a.tiles = ((q.M + 31) / 32) * ((q.N + a.ones + 31) / 32);
     a.ks = slices_for(a.tiles, q.K);
     g.first[i + 1] = g.first[i] + a.tiles * a.ks;

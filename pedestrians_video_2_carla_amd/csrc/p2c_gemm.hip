@@ -100,6 +100,10 @@ struct TnArgs {
   float *ws, *c;
   int64_t lda, ldb, ldc;
   int32_t M, N, K, k_chunk, slices, accumulate;
+  const float *row_scale;       // A's row k is multiplied by row_scale[k / rows_per_scale] as it is loaded (dy of a layer whose
+  int32_t rows_per_scale;       // output went through a per-sample stochastic-depth factor), or NULL
+  float *bias, *ws_bias;        // column sums of the (scaled) A = the bias gradient, or NULL; (slices, M) slabs
+  int32_t bias_accumulate;
 };
 template <int BN, bool VEC>
 __global__ __launch_bounds__(NTH) void gemm_tn_kernel(const TnArgs d) {
@@ -120,8 +124,17 @@ __global__ __launch_bounds__(NTH) void gemm_tn_kernel(const TnArgs d) {
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
   SlabRegs ra, rb;
   const int nk = (k_end - k_begin + BK - 1) / BK;
+  constexpr int A_TPR = BM / (BK * BM / NTH);      // threads per k-row of the A slab (load_kn<BM>)
+  const bool sums = d.bias && tn == 0 && (int)threadIdx.x < BM;
+  float colsum = 0.f;
   auto fetch = [&](int kt) {
     load_kn<BM, VEC>(d.a, d.lda, k_begin + kt * BK, k_end, m0, d.M, ra);
+    if (d.row_scale) {
+      const int k = k_begin + kt * BK + (int)threadIdx.x / A_TPR;
+      const float f = k < k_end ? d.row_scale[k / d.rows_per_scale] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra.v[i] *= f;
+    }
     load_kn<BN, VEC>(d.b, d.ldb, k_begin + kt * BK, k_end, n0, d.N, rb);
   };
   auto commit = [&]() {
@@ -148,12 +161,17 @@ __global__ __launch_bounds__(NTH) void gemm_tn_kernel(const TnArgs d) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
+    if (sums) {
+#pragma unroll
+      for (int k = 0; k < BK; ++k) colsum += As[k * (BM + 4) + (int)threadIdx.x];
+    }
     __syncthreads();
     if (kt + 1 < nk) {
       commit();
       __syncthreads();
     }
   }
+  if (sums && m0 + (int)threadIdx.x < d.M) d.ws_bias[(int64_t)blockIdx.y * d.M + m0 + (int)threadIdx.x] = colsum;
   float *slab = d.ws + (int64_t)blockIdx.y * d.M * d.N;
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
@@ -175,6 +193,13 @@ __global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
     for (int s = 0; s < d.slices; ++s) v += d.ws[(int64_t)s * total + i];
     float *o = d.c + (i / d.N) * d.ldc + (i % d.N);
     *o = d.accumulate ? *o + v : v;
+  }
+  if (d.bias) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.M; i += (int64_t)gridDim.x * blockDim.x) {
+      float v = 0.f;
+      for (int s = 0; s < d.slices; ++s) v += d.ws_bias[(int64_t)s * d.M + i];
+      d.bias[i] = d.bias_accumulate ? d.bias[i] + v : v;
+    }
   }
 }
 
@@ -296,18 +321,22 @@ static int tn_slices(int M, int N, int K) {
 }
 extern "C" int64_t p2c_gemm_tn_workspace_floats(int32_t M, int32_t N, int32_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (int64_t)tn_slices(M, N, K) * M * N;
+  return (int64_t)tn_slices(M, N, K) * ((int64_t)M * N + M);
 }
 extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t M, int32_t N,
-                           int32_t K, int32_t accumulate, float *workspace, void *stream_) {
+                           int32_t K, int32_t accumulate, const float *row_scale, int32_t rows_per_scale, float *bias_out,
+                           float *workspace, void *stream_) {
   using namespace p2c_gemm_impl;
   if (!a || !b || !c || !workspace) return P2C_E_NULL;
   if (M <= 0 || N <= 0 || K <= 0 || lda < M || ldb < N || ldc < N) return P2C_E_SHAPE;
+  if (row_scale && rows_per_scale <= 0) return P2C_E_SHAPE;
   TnArgs d;
   d.a = a, d.b = b, d.ws = workspace, d.c = c, d.lda = lda, d.ldb = ldb, d.ldc = ldc, d.M = M, d.N = N, d.K = K;
   d.slices = tn_slices(M, N, K);
   d.k_chunk = (((K + d.slices - 1) / d.slices) + BK - 1) / BK * BK;
-  d.accumulate = accumulate;
+  d.accumulate = accumulate & 1, d.bias_accumulate = (accumulate >> 1) & 1;
+  d.row_scale = row_scale, d.rows_per_scale = rows_per_scale;
+  d.bias = bias_out, d.ws_bias = workspace + (int64_t)d.slices * M * N;
   hipStream_t s = (hipStream_t)stream_;
   auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = al(a) && al(b) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
@@ -342,7 +371,11 @@ extern "C" int p2c_gemm(const p2c_gemm_desc *desc, void *stream_) {
   // 16-byte loads need 16-byte aligned rows: every leading dimension a multiple of 4 floats, bases aligned, K (NT) / N (NN) too
   auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = al(d.a) && al(d.b) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.K % 4 == 0 && (d.trans_b || d.N % 4 == 0);
-  const int bn = d.N > 64 ? 128 : (d.N > 32 ? 64 : 32);
+  // the widest column tile that still gives every CU two workgroups; small problems (the 8 192-row projections around the
+  // Seq2Seq recurrences) take narrower tiles to reach more CUs
+  int bn = d.N > 64 ? 128 : (d.N > 32 ? 64 : 32);
+  const int64_t row_tiles = (d.M + BM - 1) / BM;
+  while (bn > 32 && row_tiles * ((d.N + bn - 1) / bn) < 512) bn >>= 1;
   if (d.trans_b) {
     if (bn == 128) launch<128, true>(d, vec, s);
     else if (bn == 64) launch<64, true>(d, vec, s);

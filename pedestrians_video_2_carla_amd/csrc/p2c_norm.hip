@@ -24,7 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int THREADS = 256;
 
 struct Args {
-  const float *x, *gamma, *beta, *gy;
+  const float *x, *gamma, *beta, *gy, *gx_add;
   float *y, *mean, *rstd, *gx, *g_gamma, *g_beta, *partials;
   int64_t rows;
   int32_t D, accumulate, n_blocks;
@@ -136,6 +136,7 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const Args a) {
         f32x4 o;
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] = rstd * (gg[k][c] - m1 - xh[k][c] * m2);
+        if (a.gx_add) o += *reinterpret_cast<const f32x4 *>(a.gx_add + r * D + (k * G + l) * 4);   // the residual branch's gradient
         *reinterpret_cast<f32x4 *>(a.gx + r * D + (k * G + l) * 4) = o;
       }
   }
@@ -227,15 +228,16 @@ extern "C" int p2c_layernorm_fwd(const float *x, const float *gamma, const float
 }
 
 extern "C" int p2c_layernorm_bwd(const float *x, const float *gamma, const float *mean, const float *rstd, const float *gy,
-                                 float *gx, float *g_gamma, float *g_beta, int32_t accumulate, float *partials, int64_t rows,
-                                 int32_t D, void *stream) {
+                                 const float *gx_add, float *gx, float *g_gamma, float *g_beta, int32_t accumulate,
+                                 float *partials, int64_t rows, int32_t D, void *stream) {
   using namespace p2c_norm;
   if (!x || !gamma || !mean || !rstd || !gy || !gx || !g_gamma || !g_beta || !partials) return P2C_E_NULL;
   if (!shape_ok(rows, D)) return P2C_E_SHAPE;
   if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15) != 0) return P2C_E_SHAPE;
   Args a{};
   a.x = x, a.gamma = gamma, a.mean = const_cast<float *>(mean), a.rstd = const_cast<float *>(rstd), a.gy = gy, a.gx = gx, a.g_gamma = g_gamma, a.g_beta = g_beta;
-  a.partials = partials, a.rows = rows, a.D = D, a.accumulate = accumulate;
+  a.partials = partials, a.rows = rows, a.D = D, a.accumulate = accumulate, a.gx_add = gx_add;
+  if (gx_add && (reinterpret_cast<uintptr_t>(gx_add) & 15) != 0) return P2C_E_SHAPE;
   a.n_blocks = blocks_for(rows, rows_per_block(D));
   if (rows > 0) {
     const dim3 grid((unsigned)a.n_blocks);

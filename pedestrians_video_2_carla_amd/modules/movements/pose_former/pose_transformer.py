@@ -148,8 +148,29 @@ class _Block(nn.Module):
         self.drop_path = _DropPath(drop_path)
         self.mlp = _Mlp(dim, int(dim * mlp_ratio), drop)
 
+    def _one_node(self, x) -> bool:
+        """fp32 on the GPU, no dropout inside the block, every layer with a bias: the whole block is one autograd node."""
+        if not _fused(x) or x.ndim != 3:
+            return False
+        a, m = self.attn, self.mlp
+        live = self.training
+        if live and (a.attn_drop != 0.0 or a.proj_drop.p != 0.0 or m.drop.p != 0.0):
+            return False
+        if not (isinstance(m.act, nn.GELU) and m.act.approximate == 'none' and isinstance(self.norm1, nn.LayerNorm)
+                and isinstance(self.norm2, nn.LayerNorm) and self.norm1.elementwise_affine and self.norm2.elementwise_affine
+                and self.norm1.bias is not None and self.norm2.bias is not None and a.qkv.bias is not None
+                and a.proj.bias is not None and m.fc1.bias is not None and m.fc2.bias is not None):
+            return False
+        from pedestrians_video_2_carla_amd import ops
+        return ops.transformer_block_supported(x, a.num_heads)
+
     def forward(self, x):
         # (two draws per block and sample, attention first: the order of x + drop_path(attn) ; x + drop_path(mlp))
+        if self._one_node(x):
+            from pedestrians_video_2_carla_amd import ops
+            f1, f2 = self.drop_path.factor(x), self.drop_path.factor(x)
+            return ops.transformer_block(x, f1, f2, self.attn.num_heads, self.attn.scale, self.norm1, self.attn.qkv,
+                                         self.attn.proj, self.norm2, self.mlp.fc1, self.mlp.fc2)
         x = self.attn(_norm(self.norm1, x), self.drop_path.factor(x), x)
         return self.mlp(_norm(self.norm2, x), self.drop_path.factor(x), x)
 

@@ -102,7 +102,7 @@ class Seq2SeqEmbeddings(Seq2Seq):
     def _encode(self, x):
         from .seq2seq import _fused_ok, _run_stack
         rnn = self.encoder.rnn
-        if not (self.fold_embeddings and _fused_ok(rnn, x) and rnn.bias):
+        if not (self.fold_embeddings and _fused_ok(rnn, x) and rnn.bias and not rnn.bidirectional):
             return super()._encode(x)
         B, T, J = x.shape[:3]
         E, G = self.single_joint_embeddings_size, 4 * rnn.hidden_size

@@ -1072,9 +1072,10 @@ def _sink(p: Tensor) -> Optional[Tensor]:
 
 
 def atb(a: Tensor, b: Tensor, bias: bool = False, out: Optional[Tensor] = None, bias_out: Optional[Tensor] = None,
-        accumulate: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+        accumulate: bool = False, a_scale: Optional[Tensor] = None, rows_per_scale: int = 1) -> Tuple[Tensor, Optional[Tensor]]:
     """(a^T b, column sums of a) for a (K, M), b (K, N) -- the dW / db of ``y = x W^T + b`` from dY = a and X = b -- in one
-    launch (p2c_atb). Rows may be strided views (row pitch = stride(0), unit column stride)."""
+    launch (p2c_atb). Rows may be strided views (row pitch = stride(0), unit column stride). ``a_scale``: row k of a is
+    multiplied by ``a_scale[k // rows_per_scale]`` as it is read."""
     lib = _lib.lib()
     a, b = (t if (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1) else _require_device(t, 'operand') for t in (a, b))
     K, M, N = a.shape[0], a.shape[1], b.shape[1]
@@ -1087,8 +1088,9 @@ def atb(a: Tensor, b: Tensor, bias: bool = False, out: Optional[Tensor] = None, 
         bias_out = torch.empty(M, dtype=torch.float32, device=a.device)
     ws = torch.empty(lib.p2c_atb_workspace_floats(K, M, N, int(bias)), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
-        _lib.check(lib.p2c_atb(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), K, M, N, out.data_ptr(), out.stride(0),
-                               _ptr(bias_out) if bias else None, flags, ws.data_ptr(), _stream()), 'p2c_atb')
+        _lib.check(lib.p2c_atb_scaled(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), K, M, N, out.data_ptr(), out.stride(0),
+                                      _ptr(bias_out) if bias else None, flags, _ptr(a_scale), int(rows_per_scale),
+                                      ws.data_ptr(), _stream()), 'p2c_atb')
     return out, (bias_out if bias else None)
 
 
@@ -1183,31 +1185,46 @@ def gemm(a: Tensor, b: Tensor, trans_b: bool, bias: Optional[Tensor] = None, act
     return out
 
 
-def gemm_tn(a: Tensor, b: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+def gemm_tn(a: Tensor, b: Tensor, out: Optional[Tensor] = None, accumulate: bool = False, bias: bool = False,
+            bias_out: Optional[Tensor] = None, a_scale: Optional[Tensor] = None, rows_per_scale: int = 1):
     """K16, TN form (p2c_gemm_tn): ``out (+)= a^T b`` for a (K, M), b (K, N) with K = rows >> M, N -- the weight gradient of a
-    wide layer; K is split over workgroups and the slabs are added in a fixed order (bitwise reproducible)."""
+    wide layer; K is split over workgroups and the slabs are added in a fixed order (bitwise reproducible). ``a_scale``: row k
+    of a times ``a_scale[k // rows_per_scale]``; ``bias``: also the column sums of the scaled a (written to / added into
+    ``bias_out``). Returns out, or (out, bias_out) with ``bias``."""
     a, b = _require_device(a, 'a'), _require_device(b, 'b')
     if a.ndim != 2 or b.ndim != 2 or a.stride(1) != 1 or b.stride(1) != 1 or a.shape[0] != b.shape[0]:
         raise RuntimeError('gemm_tn: (K, M) and (K, N) operands with unit inner stride expected')
     K, M, N = a.shape[0], a.shape[1], b.shape[1]
     if out is None:
         out, accumulate = torch.empty(M, N, dtype=torch.float32, device=a.device), False
+    flags = (1 if accumulate else 0) | (2 if (bias and bias_out is not None and accumulate) else 0)
+    if bias and bias_out is None:
+        bias_out = torch.empty(M, dtype=torch.float32, device=a.device)
     lib = _lib.lib()
     ws = torch.empty(max(1, lib.p2c_gemm_tn_workspace_floats(M, N, K)), dtype=torch.float32, device=a.device)
     with torch.cuda.device(a.device):
         _lib.check(lib.p2c_gemm_tn(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0), M, N, K,
-                                   int(bool(accumulate)), ws.data_ptr(), _stream()), 'p2c_gemm_tn')
-    return out
+                                   flags, _ptr(a_scale), int(rows_per_scale), _ptr(bias_out) if bias else None,
+                                   ws.data_ptr(), _stream()), 'p2c_gemm_tn')
+    return (out, bias_out) if bias else out
 
 
 WIDE_LAYER = 128      # layers with both feature counts above this take the MFMA TN GEMM for dW; K12 (exact-order VALU) below
 
 
-def weight_grad(gy: Tensor, x: Tensor, bias: bool, sink: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
-    """(dW, db) of y = x W^T + b from dY (rows, out) and X (rows, in), accumulated into ``sink`` (= W.grad) when given."""
-    if gy.shape[0] > 0 and gy.shape[1] > WIDE_LAYER and x.shape[1] > WIDE_LAYER:
-        return gemm_tn(gy, x, out=sink, accumulate=sink is not None), (gy.sum(0) if bias else None)
-    return atb(gy, x, bias=bias, out=sink, accumulate=sink is not None)
+def weight_grad(gy: Tensor, x: Tensor, w: Tensor, b: Optional[Tensor], scale: Optional[Tensor] = None, rows_per_scale: int = 1):
+    """(dW, db) of y = (x W^T + b) * scale[row // rows_per_scale] from dY (rows, out) and X (rows, in): the factor is applied
+    to dY's rows as they are read, db comes out of the same pass. Inside ``grad_sinks`` both are ADDED straight into
+    ``w.grad`` / ``b.grad`` and (None, None) is returned to autograd."""
+    sw = _sink(w)
+    sb = _sink(b) if (b is not None and sw is not None) else None
+    if b is not None and sb is None:
+        sw = None                                  # one accumulate flag for both: either both sinks or neither
+    fn = gemm_tn if (gy.shape[0] > 0 and gy.shape[1] > WIDE_LAYER and x.shape[1] > WIDE_LAYER) else atb
+    res = fn(gy, x, bias=b is not None, out=sw, bias_out=sb, accumulate=sw is not None, a_scale=scale,
+             rows_per_scale=rows_per_scale)
+    gw, gb = res if isinstance(res, tuple) else (res, None)
+    return (None if sw is not None else gw), (None if (b is None or sb is not None) else gb)
 
 
 class DenseFunction(torch.autograd.Function):
@@ -1218,7 +1235,7 @@ class DenseFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, scale, rows_per_scale, residual):
         ctx.save_for_backward(x, w, scale)
-        ctx.has_bias, ctx.rows_per_scale, ctx.has_residual = b is not None, rows_per_scale, residual is not None
+        ctx.bias, ctx.rows_per_scale, ctx.has_residual = b, rows_per_scale, residual is not None
         return gemm(x, w, True, bias=b, row_scale=scale, rows_per_scale=rows_per_scale, residual=residual)
 
     @staticmethod
@@ -1226,10 +1243,8 @@ class DenseFunction(torch.autograd.Function):
         x, w, scale = ctx.saved_tensors
         gy = gy.contiguous()
         gx = gemm(gy, w, False, row_scale=scale, rows_per_scale=ctx.rows_per_scale) if ctx.needs_input_grad[0] else None
-        gys = gy if scale is None else (gy.view(scale.numel(), -1) * scale.view(-1, 1)).view_as(gy)
-        sink = _sink(w)
-        gw, gb = weight_grad(gys, x, ctx.has_bias, sink)
-        return gx, (None if sink is not None else gw), gb, None, None, (gy if ctx.has_residual else None)
+        gw, gb = weight_grad(gy, x, w, ctx.bias, scale, ctx.rows_per_scale)
+        return gx, gw, gb, None, None, (gy if ctx.has_residual else None)
 
 
 def dense(x: Tensor, w: Tensor, b: Optional[Tensor], scale: Optional[Tensor] = None, rows_per_scale: int = 1,
@@ -1256,7 +1271,7 @@ class MlpFunction(torch.autograd.Function):
         a = gemm(x, w1, True, bias=b1, act=1, aux_out=z)
         y = gemm(a, w2, True, bias=b2, row_scale=scale, rows_per_scale=rows_per_scale, residual=residual)
         ctx.save_for_backward(x, w1, w2, z, a, scale)
-        ctx.rows_per_scale, ctx.has_residual = rows_per_scale, residual is not None
+        ctx.rows_per_scale, ctx.has_residual, ctx.b1, ctx.b2 = rows_per_scale, residual is not None, b1, b2
         return y
 
     @staticmethod
@@ -1264,13 +1279,10 @@ class MlpFunction(torch.autograd.Function):
         x, w1, w2, z, a, scale = ctx.saved_tensors
         gy = gy.contiguous()
         dz = gemm(gy, w2, False, act=2, aux=z, row_scale=scale, rows_per_scale=ctx.rows_per_scale)
-        gys = gy if scale is None else (gy.view(scale.numel(), -1) * scale.view(-1, 1)).view_as(gy)
-        s2, s1 = _sink(w2), _sink(w1)
-        gw2, gb2 = weight_grad(gys, a, True, s2)
-        gw1, gb1 = weight_grad(dz, x, True, s1)
+        gw2, gb2 = weight_grad(gy, a, w2, ctx.b2, scale, ctx.rows_per_scale)
+        gw1, gb1 = weight_grad(dz, x, w1, ctx.b1)
         gx = gemm(dz, w1, False) if ctx.needs_input_grad[0] else None
-        return (gx, None if s1 is not None else gw1, gb1, None if s2 is not None else gw2, gb2, None, None,
-                gy if ctx.has_residual else None)
+        return gx, gw1, gb1, gw2, gb2, None, None, (gy if ctx.has_residual else None)
 
 
 def mlp_gelu(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, scale: Optional[Tensor] = None,
@@ -1673,13 +1685,119 @@ class LayerNormFunction(torch.autograd.Function):
         ws = torch.empty(max(1, lib.p2c_layernorm_workspace_floats(rows, D)), dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             _lib.check(lib.p2c_layernorm_bwd(x.data_ptr(), weight.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gy.data_ptr(),
-                                             gx.data_ptr(), gw.data_ptr(), gb.data_ptr(), int(sw is not None), ws.data_ptr(),
-                                             rows, D, _stream()), 'p2c_layernorm_bwd')
+                                             None, gx.data_ptr(), gw.data_ptr(), gb.data_ptr(), int(sw is not None),
+                                             ws.data_ptr(), rows, D, _stream()), 'p2c_layernorm_bwd')
         return gx, (None if sw is not None else gw), (None if sb is not None else gb), None
 
 
 def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
     return LayerNormFunction.apply(x, weight, bias, eps)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one pre-norm transformer block as ONE autograd node (K15 + K16 + K14 + K12 launches only)
+# ----------------------------------------------------------------------------------------------------------------------
+def _ln_fwd(x2d: Tensor, w: Tensor, b: Tensor, eps: float):
+    lib = _lib.lib()
+    rows, D = x2d.shape
+    y = torch.empty_like(x2d)
+    stats = torch.empty(2, rows, dtype=torch.float32, device=x2d.device)
+    _lib.check(lib.p2c_layernorm_fwd(x2d.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats[0].data_ptr(),
+                                     stats[1].data_ptr(), rows, D, float(eps), _stream()), 'p2c_layernorm_fwd')
+    return y, stats
+
+
+def _ln_bwd(x2d: Tensor, w: Tensor, b: Tensor, stats: Tensor, gy: Tensor, gx_add: Optional[Tensor]):
+    """(gx [+ gx_add], g_gamma, g_beta); the parameter gradients go straight into their sinks when both exist (-> None)."""
+    lib = _lib.lib()
+    rows, D = x2d.shape
+    gx = torch.empty_like(x2d)
+    sw, sb = _sink(w), _sink(b)
+    if sw is None or sb is None:
+        sw = sb = None
+    gw = sw if sw is not None else torch.empty_like(w)
+    gb = sb if sb is not None else torch.empty_like(b)
+    ws = torch.empty(max(1, lib.p2c_layernorm_workspace_floats(rows, D)), dtype=torch.float32, device=x2d.device)
+    _lib.check(lib.p2c_layernorm_bwd(x2d.data_ptr(), w.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gy.data_ptr(),
+                                     _ptr(gx_add), gx.data_ptr(), gw.data_ptr(), gb.data_ptr(), int(sw is not None),
+                                     ws.data_ptr(), rows, D, _stream()), 'p2c_layernorm_bwd')
+    return gx, (None if sw is not None else gw), (None if sb is not None else gb)
+
+
+def transformer_block_supported(x: Tensor, heads: int) -> bool:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.ndim == 3 and not torch.is_autocast_enabled()):
+        return False
+    S, N, C = x.shape
+    return (C % heads == 0 and layer_norm_supported(x, C) and small_attention_supported(N, heads, C // heads)
+            and x.numel() * 4 < 2 ** 40)
+
+
+class TransformerBlockFunction(torch.autograd.Function):
+    """One pre-norm transformer block (PoseTransformer's ``Block``: x1 = x + f1 * proj(attention(norm1(x))),
+    x2 = x1 + f2 * fc2(gelu(fc1(norm2(x1)))), f1 / f2 per-sample stochastic-depth factors or None) over x (S, N, C) as a single
+    autograd node: 7 launches forward (2 LayerNorm, 4 GEMMs with bias / GELU / factor / residual in their epilogues, attention),
+    and backward 4 input-gradient GEMMs (gelu' and the factors in the epilogues), 4 weight + bias gradient launch pairs (the
+    factor applied to dY as it is read, results added straight into the parameter sinks inside ``grad_sinks``), attention, and
+    2 LayerNorm backward pairs that also ADD the gradient arriving over the residual connection. As separate autograd nodes the
+    same block cost one framework ``add`` per residual fan-in, one ``mul`` per factor, one ``sum`` per wide bias gradient and
+    one accumulate per parameter on top of these."""
+
+    @staticmethod
+    def forward(ctx, x, f1, f2, heads, scale, eps1, eps2, n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2):
+        x = _require_device(x, 'x').contiguous()
+        S, N, C = x.shape
+        rows = S * N
+        x2 = x.view(rows, C)
+        with torch.cuda.device(x.device):
+            h1, st1 = _ln_fwd(x2, n1w, n1b, eps1)
+            qkv = gemm(h1, wqkv, True, bias=bqkv)
+            att = torch.empty(rows, C, dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().p2c_attn_small_fwd(qkv.data_ptr(), att.data_ptr(), float(scale), S, N, heads, C // heads,
+                                                     _stream()), 'p2c_attn_small_fwd')
+            x1 = gemm(att, wproj, True, bias=bproj, row_scale=f1, rows_per_scale=N, residual=x2)
+            h2, st2 = _ln_fwd(x1, n2w, n2b, eps2)
+            z = torch.empty(rows, w1.shape[0], dtype=torch.float32, device=x.device)
+            a = gemm(h2, w1, True, bias=b1, act=1, aux_out=z)
+            out = gemm(a, w2, True, bias=b2, row_scale=f2, rows_per_scale=N, residual=x1)
+        ctx.save_for_backward(x2, h1, st1, qkv, att, x1, h2, st2, z, a, f1, f2)
+        ctx.params = (n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2)
+        ctx.geom = (S, N, C, heads, float(scale))
+        return out.view(S, N, C)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, h1, st1, qkv, att, x1, h2, st2, z, a, f1, f2 = ctx.saved_tensors
+        n1w, n1b, wqkv, bqkv, wproj, bproj, n2w, n2b, w1, b1, w2, b2 = ctx.params
+        S, N, C, heads, scale = ctx.geom
+        g = _require_device(g, 'grad').contiguous().view(S * N, C)
+        with torch.cuda.device(g.device):
+            dz = gemm(g, w2, False, act=2, aux=z, row_scale=f2, rows_per_scale=N)
+            gw2, gb2 = weight_grad(g, a, w2, b2, f2, N)
+            gw1, gb1 = weight_grad(dz, h2, w1, b1)
+            dh2 = gemm(dz, w1, False)
+            g1, gn2w, gn2b = _ln_bwd(x1, n2w, n2b, st2, dh2, g)                 # + the gradient over the second residual
+            datt = gemm(g1, wproj, False, row_scale=f1, rows_per_scale=N)
+            gwp, gbp = weight_grad(g1, att, wproj, bproj, f1, N)
+            dqkv = torch.empty_like(qkv)
+            _lib.check(_lib.lib().p2c_attn_small_bwd(qkv.data_ptr(), datt.data_ptr(), dqkv.data_ptr(), scale, S, N, heads,
+                                                     C // heads, _stream()), 'p2c_attn_small_bwd')
+            gwq, gbq = weight_grad(dqkv, h1, wqkv, bqkv)
+            gx = None
+            if ctx.needs_input_grad[0]:
+                dh1 = gemm(dqkv, wqkv, False)
+                gx, gn1w, gn1b = _ln_bwd(x2, n1w, n1b, st1, dh1, g1)             # + the gradient over the first residual
+                gx = gx.view(S, N, C)
+            else:                                                                # (x is data: only the LayerNorm parameters)
+                dh1 = gemm(dqkv, wqkv, False)
+                _, gn1w, gn1b = _ln_bwd(x2, n1w, n1b, st1, dh1, None)
+        return (gx, None, None, None, None, None, None, gn1w, gn1b, gwq, gbq, gwp, gbp, gn2w, gn2b, gw1, gb1, gw2, gb2)
+
+
+def transformer_block(x, f1, f2, heads, scale, norm1, qkv, proj, norm2, fc1, fc2) -> Tensor:
+    """``TransformerBlockFunction`` from the block's nn modules (LayerNorm / Linear with biases)."""
+    return TransformerBlockFunction.apply(x, f1, f2, int(heads), float(scale), float(norm1.eps), float(norm2.eps), norm1.weight,
+                                          norm1.bias, qkv.weight, qkv.bias, proj.weight, proj.bias, norm2.weight, norm2.bias,
+                                          fc1.weight, fc1.bias, fc2.weight, fc2.bias)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -60,6 +60,28 @@ def test_gemm_tn_matches_fp64_is_reproducible_and_accumulates(K, M, N):
     assert rel(c2, wide_a[:, 1:M + 1].double().t() @ wide_b[:, 2:N + 2].double()) < 2e-6 * math.sqrt(K) + 1e-7
 
 
+@pytest.mark.parametrize('K,M,N,per', [(9 * 500, 832, 256, 9), (26 * 300, 140, 200, 26), (26 * 300, 32, 96, 26), (64, 5, 3, 1)])
+def test_weight_gradient_with_row_factor_and_bias_in_one_pass(K, M, N, per):
+    """dW = (dy * f)^T x and db = column sums of dy * f, f per sample (K12 below 128 features, the K16 TN form above), written
+    and accumulated; same bits on every call."""
+    from pedestrians_video_2_carla_amd import ops
+    torch.manual_seed(K + N)
+    a, b = torch.randn(K, M, device=dev()), torch.randn(K, N, device=dev())
+    f = (torch.rand(K // per, device=dev()) > 0.3).float() / 0.7
+    a64 = a.double() * f.double().repeat_interleave(per).view(-1, 1)
+    for fn in (ops.gemm_tn, ops.atb):
+        c, db = fn(a, b, bias=True, a_scale=f, rows_per_scale=per)
+        assert rel(c, a64.t() @ b.double()) < 2e-6 * math.sqrt(K) + 1e-7
+        assert rel(db, a64.sum(0)) < 2e-6 * math.sqrt(K) + 1e-7
+        c2, db2 = fn(a, b, bias=True, a_scale=f, rows_per_scale=per)
+        assert torch.equal(c, c2) and torch.equal(db, db2)
+        sink, bsink = torch.randn(M, N, device=dev()), torch.randn(M, device=dev())
+        w0, b0 = sink.clone(), bsink.clone()
+        fn(a, b, bias=True, out=sink, bias_out=bsink, accumulate=True, a_scale=f, rows_per_scale=per)
+        assert rel(sink, w0.double() + a64.t() @ b.double()) < 2e-6 * math.sqrt(K) + 1e-7
+        assert rel(bsink, b0.double() + a64.sum(0)) < 2e-6 * math.sqrt(K) + 1e-7
+
+
 def test_gemm_epilogue_and_strided_operands():
     """bias, GELU with the stored pre-activation, gelu' of a stored tensor, per-sample factor, residual (also aliased with the
     output), operands that are column slices of wider tensors (leading dimension > width; not 16-byte aligned -> dword loads)."""

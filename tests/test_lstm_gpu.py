@@ -82,6 +82,44 @@ def test_seq2seq_model_uses_the_fused_stack_and_matches_cpu():
         close(pg.grad, pc.grad, 'grad ' + n, rtol=bound(p32.grad, pc.grad))
 
 
+@pytest.mark.parametrize('embeddings', [False, True])
+def test_bidirectional_seq2seq_runs_on_the_hip_recurrence_and_matches_cpu(embeddings, monkeypatch):
+    """bidirectional=True (reference seq2seq.py:36-38,72-73: encoder AND decoder stacks are bidirectional, fc reads 2H): the
+    reverse direction is the same HIP recurrence over the time-flipped sequence. Whole model against the same module in fp64 on
+    the CPU (nn.LSTM); nn.LSTM.forward must not be entered on the GPU side."""
+    import copy
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2Seq, Seq2SeqEmbeddings
+    d = dev()
+    torch.manual_seed(11)
+    cls = Seq2SeqEmbeddings if embeddings else Seq2Seq
+    model = cls(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d, p_dropout=0.0,
+                bidirectional=True, hidden_size=32).train()
+    cpu = copy.deepcopy(model).double()
+    cpu32 = copy.deepcopy(model)
+    x, up = torch.randn(7, 6, 26, 2), torch.randn(7, 6, 26, 2)
+    yr = cpu(x.double())
+    (yr * up.double()).sum().backward()
+    y32 = cpu32(x)
+    (y32 * up).sum().backward()
+    gpu = model.to(d)
+
+    def refuse(*a, **k):
+        raise AssertionError('nn.LSTM.forward entered: the bidirectional stack left the HIP path')
+    monkeypatch.setattr(torch.nn.LSTM, 'forward', refuse)
+    y = gpu(x.to(d))
+    (y * up.to(d)).sum().backward()
+    monkeypatch.undo()
+
+    def bound(a32, a64):
+        return max(1e-4, 2.0 * (a32.double() - a64).abs().max().item() / (a64.abs().max().item() + 1e-30))
+    close(y, yr, 'model output', rtol=bound(y32, yr))
+    for (n, pg), (_, pc), (_, p32) in zip(gpu.named_parameters(), cpu.named_parameters(), cpu32.named_parameters()):
+        assert pg.grad is not None, n
+        close(pg.grad, pc.grad, 'grad ' + n, rtol=bound(p32.grad, pc.grad))
+
+
 def test_no_cpu_fallback():
     from pedestrians_video_2_carla_amd import ops, _lib
     with pytest.raises(_lib.P2CError):
