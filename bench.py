@@ -572,9 +572,10 @@ def extra_config(device, name, steps=100, warmup=10):
         out['shared_spatial'] = arm(share_spatial=True)
         out['shared_spatial_bf16'] = arm(share_spatial=True, compute_dtype=torch.bfloat16)
         out['note'] = ('transformer arithmetic parity-unpinned (third-party source absent); attention = K14 (p2c_attn_small), LayerNorm = '
-                       'K15 (p2c_layernorm), spatial weight gradients = K12, GEMMs = library (the four temporal blocks are 2.8 TFLOP '
-                       'per step = 17.8 ms at the fp32 MFMA peak); the pose head is the HIP absolute_loc kernel; stochastic depth '
-                       '(0.2) on')
+                       'K15 (p2c_layernorm), every dense layer = K16 (p2c_gemm / p2c_gemm_tn: fp32 MFMA with bias / GELU / '
+                       'stochastic-depth factor / residual in the epilogue; no library GEMM in the step), narrow weight gradients = K12; '
+                       'a block is one autograd node. The four temporal blocks are 2.8 TFLOP per step = 17.8 ms at the fp32 MFMA '
+                       'peak; the pose head is the HIP absolute_loc kernel; stochastic depth (0.2) on')
         out['windows_per_step'] = B * (81 - 9 + 1)
     else:
         # the recurrences (K7b encoder layers, K7c decoder loop) priced against the fp32 MFMA peak: 2*T*B*H*4H flop per
@@ -583,9 +584,9 @@ def extra_config(device, name, steps=100, warmup=10):
         out['roofline'] = [mfma_entry(k, B, rt[k], fl) for k, fl in rflops.items()]
         out['note'] = ('the time-loop launches are latency chains (one to three workgroup barriers per time step); at B <= 4096 they '
                        'run 4 sequences per workgroup on v_mfma_f32_4x4x1_16B (128 workgroups at B = 512), above that 16 on '
-                       'v_mfma_f32_16x16x4. The step is 24 launches: fold, 2 projection GEMMs, 2 + 2 encoder recurrences, '
-                       'dropout, decoder fwd / bwd with the frame-invariant terms inside, 2 grouped weight-gradient pairs, '
-                       'loss, AdamW')
+                       'v_mfma_f32_16x16x4. The step is 24 launches: fold, 2 projection GEMMs + 1 input-gradient GEMM (K16: no '
+                       'library GEMM in the step), 2 + 2 encoder recurrences, dropout, decoder fwd / bwd with the frame-invariant '
+                       'terms inside, 2 grouped weight-gradient pairs, loss, AdamW')
     return out
 
 

@@ -25,4 +25,7 @@ def euler_angles_to_matrix(euler_angles: Tensor, convention: str = 'XYZ') -> Ten
         rows = {'X': (o, z, z, z, c, -s, z, s, c), 'Y': (c, z, s, z, o, z, -s, z, c), 'Z': (c, -s, z, s, c, z, z, z, o)}[k]
         return torch.stack(rows, -1).reshape(a.shape + (3, 3))
     m = [axis(k, euler_angles[..., i]) for i, k in enumerate(convention)]
-    return m[0] @ m[1] @ m[2]
+
+    def mm3(a, b):       # 3x3 products as element-wise work: the synthetic data module composes (B, T, 26) of them per batch,
+        return (a.unsqueeze(-1) * b.unsqueeze(-3)).sum(-2)      # which as a batched library GEMM took ~1 ms per call
+    return mm3(mm3(m[0], m[1]), m[2])

@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-end evidence, run on the GPU box from the repo root:  bash tools/collect_profiles.sh OUTDIR
+# (kernel-trace + stats of the driver's bench command, PMC traffic passes -- FETCH_SIZE and WRITE_SIZE in separate runs, never
+# combined with other trace domains -- for the train step and the pose-head kernels, cfg3 / cfg5 step traces).
+set -o pipefail
+OUT=${1:-gpurun_out/r03}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+python bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || exit 1
+echo "bench done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench_stats" -- python3 bench.py --no-extra-configs --no-cpu-baseline > "$OUT/bench_stats.log" 2>&1 || exit 1
+echo "stats done"
+for B in 256 1024; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_step_b${B}_$C" -- python3 tools/prof_step.py $B 30 > "$OUT/pmc_step_${B}_$C.log" 2>&1 || exit 1
+  done
+done
+echo "step pmc done"
+for B in 256 1024 8192 16384 65536; do
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_head_b${B}_$C" -- python3 tools/prof_kernels.py $B 5 > "$OUT/pmc_head_${B}_$C.log" 2>&1 || exit 1
+  done
+done
+echo "head pmc done"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5_trace" -- python3 tools/bench_poseformer.py 32 5 > "$OUT/cfg5_trace.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg3_trace" -- python3 tools/bench_seq2seq.py 512 30 graph > "$OUT/cfg3_trace.log" 2>&1 || exit 1
+echo "all done"

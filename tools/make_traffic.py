@@ -22,6 +22,13 @@ GROUPS = {
     'mlp_bwd(+reduce+adamw)': ('mlp_bwd_kernel', 'mlp_wgrad_kernel', 'mlp_reduce_kernel', 'mlp_reduce_small_kernel'),
     'adamw': ('adamw_kernel',),
     'train_clip_kernel': ('train_clip_kernel',),
+    # the names bench.py's roofline_sweep uses (head_kernel_names): one kernel each, the forward without its finalize launch
+    'pose_head_rot_fwd_tp<6D>': ('pose_head_rot_fwd_tp<0',),
+    'pose_head_rot_bwd_tangent_tp<6D>': ('pose_head_rot_bwd_tangent_tp<0',),
+    'pose_head_rot_fwd<6D>': ('pose_head_rot_fwd<0, false>',),
+    'pose_head_rot_bwd_tangent<6D>': ('pose_head_rot_bwd_tangent<0>',),
+    'pose_head_chain_fwd<6D>': ('pose_head_chain_fwd<0>',),
+    'pose_head_chain_bwd<6D>': ('pose_head_chain_bwd<0>',),
     'train_wgrad_kernel(+adamw+loss)': ('train_wgrad_kernel',),
 }
 
