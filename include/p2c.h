@@ -108,6 +108,14 @@ typedef struct p2c_pose_head_desc {
    * the forward call only counts the unmasked target pairs: the backward kernel, which recomputes the pose head anyway,
    * produces the losses as well as grad_y (+ the finalize launch). Ignored for every other kernel family. */
   int32_t defer_loss_finalize;
+  /* ---- rot_3d (loss/rot_3d.py:9-37), 6-D kinds only (P2C_E_ENUM otherwise) ----
+   * gt_rot: targets['absolute_pose_rot'] (B,T,gt3d_joints,3,3) or NULL. When set, the forward also sums the squared difference
+   * between the absolute joint rotations of the kinematic chain and gt_rot over the joints gmap3d maps and the frames [t0,t1):
+   * loss_sums must hold 6 floats ([4] = sum_sq_rot, [5] = n_elems_rot) and losses 4 ([3] = rot_3d = their quotient); nothing
+   * else is written (no absolute_pose_rot tensor). The backward adds 2 (A - gt) grad_loss_rot / n as a torque in its
+   * tangent-space pass. The joint-lane kernels run (time-parallel or clip-sequential, defer_loss_finalize ignored). */
+  const float *gt_rot;
+  const float *grad_loss_rot;   /* p2c_pose_head_bwd: device scalar, upstream gradient of rot_3d; NULL = none */
 } p2c_pose_head_desc;
 
 /* library / build identification: "p2c-hip <version> gfx950" */

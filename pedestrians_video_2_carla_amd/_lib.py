@@ -36,6 +36,7 @@ class PoseHeadDesc(ctypes.Structure):
         ('out_shift', _f32p), ('out_scale', _f32p), ('out_relative_pose_loc', _f32p),
         ('out_relative_pose_rot', _f32p), ('out_absolute_pose_loc', _f32p), ('out_absolute_pose_rot', _f32p),
         ('out_world_loc', _f32p), ('out_world_rot', _f32p), ('defer_loss_finalize', _i32),
+        ('gt_rot', _f32p), ('grad_loss_rot', _f32p),
     ]
 
 

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
   W.rot = identity();
   W.loc = v3(0.f, 0.f, 0.f);
   HeadAcc acc{0.f, 0.f, 0.f};
+  float rot_acc = 0.f;
 
   // two register sets for the frame inputs, used alternately: the loads of frame t+1 are in flight while frame t is
   // computed, and no register-to-register copies are needed at the end of an iteration
@@ -80,7 +81,12 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
     }
     M3 A = R;
     V3 x = l;
-    fk_doubling<MAT>(L, A, x);
+    if (d.gt_rot) {                      // rot_3d fused: the complete absolute rotation is needed also on the lean path
+      fk_doubling<true>(L, A, x);
+      rot_acc += rot_loss_term(d, L, t, A);
+    } else {
+      fk_doubling<MAT>(L, A, x);
+    }
     if (MAT && L.active && d.out_absolute_pose_rot) store_m3(d.out_absolute_pose_rot, jf, A);
     world_step(d, L, t, W);
     if (MAT && W.on) world_store(d, L, t, W);
@@ -100,10 +106,11 @@ __global__ __launch_bounds__(256) void pose_head_rot_fwd(const p2c_pose_head_des
   if (L.active && K::SCAN && d.final_rel_rot) store_m3(d.final_rel_rot, (size_t)L.clip * J + L.j, R);
 
   float s2 = wave_sum(acc.sum2), c2 = wave_sum(acc.cnt2), s3 = wave_sum(acc.sum3);
+  const float sr = d.gt_rot ? wave_sum(rot_acc) : 0.f;
   if (L.lane == 0) {
     size_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     float *p = d.partials + wave * 4;
-    p[0] = s2, p[1] = c2, p[2] = s3, p[3] = 0.f;
+    p[0] = s2, p[1] = c2, p[2] = s3, p[3] = sr;
   }
 }
 
@@ -265,6 +272,7 @@ __global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(
   }
   float coef2 = 0.f, coef3 = 0.f;
   loss_coefs(d, grad_losses, coef2, coef3);
+  const float coefr = rot_coef(d);
 
   World W;
   W.on = (d.dloc != nullptr) || (d.drot != nullptr);
@@ -301,8 +309,9 @@ __global__ __launch_bounds__(256, P2C_BWD_WAVES) void pose_head_rot_bwd_tangent(
     V3 SubF = shfl(PF, L.base + L.sub_end) - (PF - F);
     V3 SubX = shfl(PX, L.base + L.sub_end) - (PX - FX);
     V3 tau = SubX - cross(SubF, x);
-    if (g_rot_ext) {
-      const V3 tm = rotation_torque(g_rot_ext, ((size_t)L.clip * T + t) * J + L.j, A, L.active);
+    if (g_rot_ext || coefr != 0.f) {
+      V3 tm = g_rot_ext ? rotation_torque(g_rot_ext, ((size_t)L.clip * T + t) * J + L.j, A, L.active) : v3(0.f, 0.f, 0.f);
+      if (coefr != 0.f) tm = tm + rot_loss_torque(d, L, t, A, coefr);          // rot_3d fused: G = coef (A - gt)
       const V3 PT = v3(group_prefix(tm.x), group_prefix(tm.y), group_prefix(tm.z));
       tau = tau + (shfl(PT, L.base + L.sub_end) - (PT - tm));
     }
@@ -411,15 +420,16 @@ __global__ __launch_bounds__(1024) void pose_head_rot_fwd_tp(const p2c_pose_head
 
   // one partial per clip, waves added in frame order
   float s2 = wave_sum(acc.sum2), c2 = wave_sum(acc.cnt2), s3 = wave_sum(acc.sum3);
+  const float sr = d.gt_rot ? wave_sum(rot_loss_term(d, L, t, A)) : 0.f;       // rot_3d fused
   float *red = tp_lds + 2 * plane;
   __syncthreads();
-  if (L.lane == 0) red[wave * 3 + 0] = s2, red[wave * 3 + 1] = c2, red[wave * 3 + 2] = s3;
+  if (L.lane == 0) red[wave * 4 + 0] = s2, red[wave * 4 + 1] = c2, red[wave * 4 + 2] = s3, red[wave * 4 + 3] = sr;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float a = 0.f, b = 0.f, cc = 0.f;
-    for (int w = 0; w < n_waves; ++w) a += red[w * 3], b += red[w * 3 + 1], cc += red[w * 3 + 2];
+    float a = 0.f, b = 0.f, cc = 0.f, rr = 0.f;
+    for (int w = 0; w < n_waves; ++w) a += red[w * 4], b += red[w * 4 + 1], cc += red[w * 4 + 2], rr += red[w * 4 + 3];
     float *p = d.partials + (size_t)L.clip * 4;
-    p[0] = a, p[1] = b, p[2] = cc, p[3] = 0.f;
+    p[0] = a, p[1] = b, p[2] = cc, p[3] = rr;
   }
 }
 
@@ -515,8 +525,10 @@ __global__ __launch_bounds__(1024) void pose_head_rot_bwd_tangent_tp(const p2c_p
   V3 SubF = shfl(PF, L.base + L.sub_end) - (PF - F);
   V3 SubX = shfl(PX, L.base + L.sub_end) - (PX - FX);
   V3 tau = SubX - cross(SubF, x);
-  if (g_rot_ext) {
-    const V3 tm = rotation_torque(g_rot_ext, ((size_t)L.clip * T + (t < T ? t : 0)) * J + L.j, A, L.active);
+  const float coefr = TRAIN ? 0.f : rot_coef(d);
+  if (g_rot_ext || coefr != 0.f) {
+    V3 tm = g_rot_ext ? rotation_torque(g_rot_ext, ((size_t)L.clip * T + (t < T ? t : 0)) * J + L.j, A, L.active) : v3(0.f, 0.f, 0.f);
+    if (coefr != 0.f) tm = tm + rot_loss_torque(d, L, t, A, coefr);            // rot_3d fused: G = coef (A - gt)
     const V3 PT = v3(group_prefix(tm.x), group_prefix(tm.y), group_prefix(tm.z));
     tau = tau + (shfl(PT, L.base + L.sub_end) - (PT - tm));
   }
@@ -643,35 +655,40 @@ __global__ __launch_bounds__(256) void pose_head_absloc(const p2c_pose_head_desc
 // deterministic second stage of the loss reduction (fixed order, fp64 accumulators)
 // =====================================================================================================================
 __global__ __launch_bounds__(256) void loss_finalize(const float *partials, int n_waves, float n3_elems, int has2d,
-                                                      int has3d, float *loss_sums, float *losses) {
+                                                      int has3d, float *loss_sums, float *losses, float nrot_elems) {
   // One workgroup, fixed order: thread i adds partials i, i + 256, ... (fp64), then a tree over the threads (p2c_train.hip's
   // finalize_losses keeps the same order: bit-identical losses). Every partial is one 16-byte load, eight of them in flight per
   // thread: with dword loads in a rolled loop this launch took 15 us for the 8192 partials of a 65 536-clip batch -- 6 % of
   // the kernel whose sums it adds.
-  __shared__ double sh[3][256];
+  __shared__ double sh[4][256];
   const float4 *p4 = reinterpret_cast<const float4 *>(partials);
-  double a = 0.0, b = 0.0, c = 0.0;
+  double a = 0.0, b = 0.0, c = 0.0, r = 0.0;       // r: slot 3 of a partial = the rot_3d sum when gt_rot is set (nrot_elems > 0)
   int i = threadIdx.x;
   for (; i + 7 * 256 < n_waves; i += 8 * 256) {
     float4 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = p4[i + u * 256];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a += (double)v[u].x, b += (double)v[u].y, c += (double)v[u].z;
+    for (int u = 0; u < 8; ++u) a += (double)v[u].x, b += (double)v[u].y, c += (double)v[u].z, r += (double)v[u].w;
   }
   for (; i < n_waves; i += 256) {
     const float4 v = p4[i];
-    a += (double)v.x, b += (double)v.y, c += (double)v.z;
+    a += (double)v.x, b += (double)v.y, c += (double)v.z, r += (double)v.w;
   }
-  sh[0][threadIdx.x] = a, sh[1][threadIdx.x] = b, sh[2][threadIdx.x] = c;
+  sh[0][threadIdx.x] = a, sh[1][threadIdx.x] = b, sh[2][threadIdx.x] = c, sh[3][threadIdx.x] = r;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) {
       sh[0][threadIdx.x] += sh[0][threadIdx.x + s];
       sh[1][threadIdx.x] += sh[1][threadIdx.x + s];
       sh[2][threadIdx.x] += sh[2][threadIdx.x + s];
+      sh[3][threadIdx.x] += sh[3][threadIdx.x + s];
     }
     __syncthreads();
+  }
+  if (threadIdx.x == 0 && nrot_elems > 0.f) {
+    loss_sums[4] = (float)sh[3][0], loss_sums[5] = nrot_elems;
+    losses[3] = (float)(sh[3][0] / (double)nrot_elems);
   }
   if (threadIdx.x == 0) {
     double s2 = sh[0][0], n2 = sh[1][0], s3 = sh[2][0];
@@ -717,6 +734,12 @@ static int validate(const p2c_pose_head_desc *d) {
   }
   if (d->gt2d && (d->gt2d_channels < 2 || n2 != d->n_common2d)) return P2C_E_SHAPE;
   if (d->gt3d && n3 != d->n_common3d) return P2C_E_SHAPE;
+  if (d->gt_rot) {                                   // rot_3d fused: 6-D kinds, the joint map of the 3-D targets
+    if (d->kind != P2C_KIND_POSE_CHANGES_6D && d->kind != P2C_KIND_RELATIVE_ROT_6D) return P2C_E_ENUM;
+    if (n3 != d->n_common3d || d->gt3d_joints < 1) return P2C_E_SHAPE;
+    for (int j = 0; j < P2C_JOINTS; ++j)
+      if (d->gmap3d[j] < -1 || d->gmap3d[j] >= d->gt3d_joints) return P2C_E_INDEX;
+  }
   return 0;
 }
 
@@ -767,7 +790,7 @@ extern "C" int p2c_pose_head_set_packed_min_batch(int32_t min_b) {
   return prev;
 }
 static inline bool use_pk(const p2c_pose_head_desc &d) {
-  return (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D) && !d.dloc && !d.drot &&
+  return (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D) && !d.dloc && !d.drot && !d.gt_rot &&
          d.B >= pk_min_b() && !use_tp(d);
 }
 // chain-lane kernels for large batches (p2c_pose_head_chain.hip)
@@ -775,7 +798,9 @@ bool p2c_internal_chain_supported(const p2c_pose_head_desc &d);
 unsigned p2c_internal_chain_waves(int B);
 int p2c_internal_chain_fwd(const p2c_pose_head_desc &d, hipStream_t stream);
 int p2c_internal_chain_bwd(const p2c_pose_head_desc &d, const GradLosses &gl, float *grad_y, hipStream_t stream);
-static inline bool use_chain(const p2c_pose_head_desc &d) { return !use_tp(d) && !use_pk(d) && p2c_internal_chain_supported(d); }
+static inline bool use_chain(const p2c_pose_head_desc &d) {
+  return !use_tp(d) && !use_pk(d) && !d.gt_rot && p2c_internal_chain_supported(d);
+}
 
 static inline unsigned grid_pk(int B) {
   const int waves = (B + 3) / 4;
@@ -784,10 +809,13 @@ static inline unsigned grid_pk(int B) {
 static inline float n3_elems_host(const p2c_pose_head_desc &d) {
   return (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
 }
+static inline float nrot_elems_host(const p2c_pose_head_desc &d) {
+  return d.gt_rot ? (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 9.0) : 0.f;
+}
 static inline unsigned tp_threads(int T) { return 64u * (unsigned)((T + 1) / 2); }
 static inline size_t tp_lds_bytes(int T) {
   const size_t waves = (size_t)(T + 1) / 2;
-  return (2 * waves * 2 * GROUP * 9 + waves * 3) * sizeof(float);
+  return (2 * waves * 2 * GROUP * 9 + waves * 4) * sizeof(float);
 }
 
 extern "C" int64_t p2c_pose_head_workspace_floats(int32_t B) {
@@ -800,7 +828,8 @@ extern "C" int64_t p2c_pose_head_workspace_floats(int32_t B) {
 static int pose_head_fwd_impl(const p2c_pose_head_desc *desc, void *stream_, int which) {
   int rc = validate(desc);
   if (rc) return rc;
-  const p2c_pose_head_desc d = *desc;
+  p2c_pose_head_desc d = *desc;
+  if (d.gt_rot) d.defer_loss_finalize = 0;            // rot_3d fused: the forward kernel runs and its sums are finalized here
   hipStream_t stream = (hipStream_t)stream_;
   dim3 grid(grid_for(d.B)), block(kBlock);
   const bool mat = d.out_pose_changes || d.out_projection_2d || d.out_projection_2d_transformed || d.out_shift ||
@@ -821,7 +850,7 @@ static int pose_head_fwd_impl(const p2c_pose_head_desc *desc, void *stream_, int
     if (rc) return rc;
     if (!(which & 2)) return 0;
     hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, (int)p2c_internal_chain_waves(d.B),
-                       n3_elems_host(d), d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
+                       n3_elems_host(d), d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses, 0.f);
     hipError_t ec = hipGetLastError();
     return ec == hipSuccess ? 0 : (int)ec;
   }
@@ -857,7 +886,7 @@ static int pose_head_fwd_impl(const p2c_pose_head_desc *desc, void *stream_, int
   int n_waves = tp ? d.B : (int)((pkd ? pk_grid.x : grid.x) * (kBlock / 64));
   float n3 = (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
   hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, n_waves, n3,
-                     d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
+                     d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses, nrot_elems_host(d));
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -876,7 +905,7 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
   if (!grad_y) return P2C_E_NULL;
   p2c_pose_head_desc d = *desc;
   // the forward skipped its finalize launch only for the lean time-parallel 6-D kernels (same rule as p2c_pose_head_fwd)
-  if (!(use_tp(d) && !use_pk(d) && (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D)))
+  if (!(use_tp(d) && !use_pk(d) && (d.kind == P2C_KIND_POSE_CHANGES_6D || d.kind == P2C_KIND_RELATIVE_ROT_6D)) || d.gt_rot)
     d.defer_loss_finalize = 0;
   hipStream_t stream = (hipStream_t)stream_;
   dim3 grid(grid_for(d.B)), block(kBlock);
@@ -932,7 +961,7 @@ extern "C" int p2c_pose_head_bwd(const p2c_pose_head_desc *desc, const float *co
   if (e != hipSuccess) return (int)e;
   if (d.defer_loss_finalize == 2) {      // the kernel above left one (sum_sq_2d, n, sum_sq_3d) per clip
     hipLaunchKernelGGL(loss_finalize, dim3(1), dim3(256), 0, stream, (const float *)d.partials, d.B, n3_elems_host(d),
-                       d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses);
+                       d.gt2d ? 1 : 0, d.gt3d ? 1 : 0, d.loss_sums, d.losses, 0.f);
     e = hipGetLastError();
   }
   return e == hipSuccess ? 0 : (int)e;

@@ -557,6 +557,36 @@ __device__ __forceinline__ V3 rotation_torque(const float *g_rot_ext, size_t joi
   return v3(P.m[7] - P.m[5], P.m[2] - P.m[6], P.m[3] - P.m[1]);
 }
 
+// rot_3d fused (p2c_pose_head_desc.gt_rot): difference between this lane's absolute rotation and its target, or false when the
+// joint / frame takes no part (not a common joint, outside the eval slice, idle lane)
+__device__ __forceinline__ bool rot_difference(const p2c_pose_head_desc &d, const LaneCtx &L, int t, const M3 &A, M3 &D) {
+  if (!(L.active && L.gm3 >= 0 && t >= d.t0 && t < d.t1 && t < d.T)) return false;
+  const float *g = d.gt_rot + ((((size_t)L.clip * d.T + t) * d.gt3d_joints) + L.gm3) * 9;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) D.m[i] = A.m[i] - g[i];
+  return true;
+}
+__device__ __forceinline__ float rot_loss_term(const p2c_pose_head_desc &d, const LaneCtx &L, int t, const M3 &A) {
+  M3 D;
+  if (!rot_difference(d, L, t, A, D)) return 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) s = fmaf(D.m[i], D.m[i], s);
+  return s;
+}
+// its torque: G = coef (A - gt) in place of an upstream gradient tensor (rotation_torque above)
+__device__ __forceinline__ V3 rot_loss_torque(const p2c_pose_head_desc &d, const LaneCtx &L, int t, const M3 &A, float coef) {
+  M3 D;
+  if (!rot_difference(d, L, t, A, D)) return v3(0.f, 0.f, 0.f);
+  const M3 P = mulTN(A, D);
+  return v3(P.m[7] - P.m[5], P.m[2] - P.m[6], P.m[3] - P.m[1]) * coef;
+}
+__device__ __forceinline__ float rot_coef(const p2c_pose_head_desc &d) {       // d rot_3d / d A = 2 (A - gt) / n
+  if (!d.gt_rot || !d.grad_loss_rot) return 0.f;
+  const float n = d.loss_sums[5];
+  return n > 0.f ? 2.f * *d.grad_loss_rot / n : 0.f;
+}
+
 template <int KIND>
 struct KindTraits {
   static constexpr bool SIXD = (KIND == P2C_KIND_POSE_CHANGES_6D || KIND == P2C_KIND_RELATIVE_ROT_6D);

@@ -647,6 +647,7 @@ extern "C" int p2c_train_step_launch(const p2c_train_step_desc *desc, const floa
       d.out_relative_pose_loc || d.out_relative_pose_rot || d.out_absolute_pose_loc || d.out_absolute_pose_rot ||
       d.out_world_loc || d.out_world_rot)
     return P2C_E_ENUM;                                            // lean outputs only
+  if (d.gt_rot) return P2C_E_ENUM;                                // rot_3d runs through p2c_pose_head_fwd / _bwd
   int rc = p2c_internal_validate_pose_head(&d);
   if (rc) return rc;
   if ((reinterpret_cast<uintptr_t>(m.x) & 15) || (reinterpret_cast<uintptr_t>(m.w_image) & 15) ||

@@ -2,8 +2,9 @@
 
 Registered: the modes of the hot path (loc_2d, loc_3d, loc_2d_3d -- fused into the HIP pose head when
 they are the only ones requested) and the rotation losses of §8f rank 2 (rot_3d, loc_rot_3d, loc_2d_loc_rot_3d,
-weighted_loc_2d_loc_rot_3d), which run on the materialised ``absolute_pose_rot`` and back-propagate through the tangent-space
-HIP backward; cum_pose_changes and per_joint_loc_2d as plain tensor ops (cold path). Not registered: pose_changes, heatmaps,
+weighted_loc_2d_loc_rot_3d): with a 6-D rotation output their rot_3d term comes out of the same lean pose-head launches
+(p2c_pose_head_desc.gt_rot: target rotations read, nothing written); with matrix outputs they run on the materialised
+``absolute_pose_rot`` and back-propagate through the tangent-space HIP backward; cum_pose_changes and per_joint_loc_2d as plain tensor ops (cold path). Not registered: pose_changes, heatmaps,
 common_loc_2d (deprecated) -- same call contract, addable without touching the flows.
 """
 from enum import Enum

@@ -107,11 +107,11 @@ class ProjectionModule(nn.Module):
 
     def fused_losses(self, pose_inputs_batch, world_loc_change_batch, world_rot_change_batch, identity_world: bool,
                      spec_kwargs: dict, gt2d: Optional[Tensor], gt3d: Optional[Tensor],
-                     want: Sequence[str] = ()) -> Tuple[Tensor, Dict[str, Tensor]]:
+                     want: Sequence[str] = (), gt_rot: Optional[Tensor] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
         """Train path: projection + transform + loc_2d/loc_3d/loc_2d_3d in one launch; ``want`` adds materialised
         tensors on request. Returns (losses (3,), outputs)."""
         kind = self.kernel_kind(pose_inputs_batch)
         y = self._check_ready(pose_inputs_batch)
         dloc, drot, absolute = self._world_args(world_loc_change_batch, world_rot_change_batch, identity_world)
         spec = ops.PoseHeadSpec(kind=kind, world_absolute=absolute, **spec_kwargs)
-        return ops.pose_head(y, spec, self._skel_type, dloc, drot, gt2d, gt3d, want=want)
+        return ops.pose_head(y, spec, self._skel_type, dloc, drot, gt2d, gt3d, want=want, gt_rot=gt_rot)

@@ -77,7 +77,7 @@ def joint_maps(out_idx, in_idx, n_gt_joints: int = J) -> Tuple[int, ...]:
 
 
 def _fill_desc(spec: PoseHeadSpec, y: Tensor, skel_type: Tensor, dloc, drot, gt2d, gt3d, bufs: Dict[str, Tensor],
-               outs: Dict[str, Tensor]) -> PoseHeadDesc:
+               outs: Dict[str, Tensor], gt_rot: Optional[Tensor] = None, grad_rot: Optional[Tensor] = None) -> PoseHeadDesc:
     B, T = y.shape[0], y.shape[1]
     d = PoseHeadDesc()
     d.B, d.T = B, T
@@ -110,6 +110,9 @@ def _fill_desc(spec: PoseHeadSpec, y: Tensor, skel_type: Tensor, dloc, drot, gt2
         d.gt2d, d.gt2d_joints, d.gt2d_channels = gt2d.data_ptr(), gt2d.shape[-2], gt2d.shape[-1]
     if gt3d is not None:
         d.gt3d, d.gt3d_joints = gt3d.data_ptr(), gt3d.shape[-2]
+    if gt_rot is not None:                       # rot_3d fused: the 3-D joint map applies (loss/rot_3d.py:31-35)
+        d.gt_rot, d.gt3d_joints = gt_rot.data_ptr(), gt_rot.shape[-3]
+        d.grad_loss_rot = _ptr(grad_rot)
     d.partials, d.loss_sums, d.losses = (bufs[k].data_ptr() for k in ('partials', 'loss_sums', 'losses'))
     d.final_rel_rot = _ptr(bufs.get('final_rel_rot'))
     for k, t in outs.items():
@@ -159,16 +162,17 @@ def available_outputs(spec: PoseHeadSpec, world: bool) -> Tuple[str, ...]:
 
 
 class PoseLosses:
-    """(loc_2d, loc_3d, loc_2d_3d) of one fused pose-head call.
+    """(loc_2d, loc_3d, loc_2d_3d [, rot_3d when ``gt_rot`` was given]) of one fused pose-head call.
 
     ``losses[i]`` / ``losses.loc_2d_3d`` are 0-dim tensors that are outputs of the autograd node themselves: calling
     ``backward`` on one of them reaches the HIP backward without any select/scatter kernel in between. ``losses.vector``
     is the same three numbers as one (3,) tensor (also differentiable)."""
     names = ('loc_2d', 'loc_3d', 'loc_2d_3d')
 
-    def __init__(self, vector: Tensor, scalars: Sequence[Tensor]):
+    def __init__(self, vector: Tensor, scalars: Sequence[Tensor], rot_3d: Optional[Tensor] = None):
         self.vector = vector
         self.scalars = tuple(scalars)
+        self.rot_3d = rot_3d
 
     def __getitem__(self, i):
         return self.scalars[self.names.index(i)] if isinstance(i, str) else self.scalars[i]
@@ -212,7 +216,7 @@ class PoseHeadFunction(torch.autograd.Function):
     """(losses (3,), loc_2d, loc_3d, loc_2d_3d [, materialised tensors]) = f(model output y)."""
 
     @staticmethod
-    def forward(ctx, y, spec: PoseHeadSpec, skel_type, dloc, drot, gt2d, gt3d, want: Tuple[str, ...]):
+    def forward(ctx, y, spec: PoseHeadSpec, skel_type, dloc, drot, gt2d, gt3d, want: Tuple[str, ...], gt_rot=None):
         lib = _lib.lib()
         y = _require_device(y, 'pose_inputs')
         skel_type = _require_device(skel_type, 'skel_type', torch.int32)
@@ -222,12 +226,20 @@ class PoseHeadFunction(torch.autograd.Function):
         gt3d = None if gt3d is None else _require_device(gt3d, 'gt3d')
         _check_shapes(spec, y, skel_type, dloc, drot, gt2d, gt3d)
         B, T = y.shape[0], y.shape[1]
+        if gt_rot is not None:
+            gt_rot = _require_device(gt_rot, 'gt_rot')
+            if spec.kind not in ('pose_changes_6d', 'relative_rot_6d'):
+                raise RuntimeError('rot_3d is fused for the 6-D kinds only')
+            if gt_rot.ndim != 5 or tuple(gt_rot.shape[:2]) != (B, T) or tuple(gt_rot.shape[3:]) != (3, 3) \
+                    or max(spec.gmap3d) >= gt_rot.shape[2] or (gt3d is not None and gt3d.shape[2] != gt_rot.shape[2]):
+                raise RuntimeError(f'gt_rot should have shape ({B}, {T}, joints, 3, 3), got {tuple(gt_rot.shape)}')
         dev = y.device
         f32 = dict(dtype=torch.float32, device=dev)
+        losses4 = torch.empty(4, **f32)             # loc_2d, loc_3d, loc_2d_3d | rot_3d (written when gt_rot is given)
         bufs = {
             'partials': torch.empty(lib.p2c_pose_head_workspace_floats(B), **f32),
-            'loss_sums': torch.empty(4, **f32),
-            'losses': torch.empty(3, **f32),
+            'loss_sums': torch.empty(6, **f32),
+            'losses': losses4,
         }
         if spec.kind in ('pose_changes_6d', 'pose_changes'):
             bufs['final_rel_rot'] = torch.empty(B, J, 3, 3, **f32)
@@ -236,15 +248,15 @@ class PoseHeadFunction(torch.autograd.Function):
         for k in want:
             full = torch.zeros if (k.startswith('projection_2d_') and (t0, t1) != (0, T)) else torch.empty
             outs[k] = full((B, T) + _OUT_SHAPES[k], **f32)
-        desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, outs)
+        desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, outs, gt_rot)
         # lean training forward inside deferred_loss_finalize(): the backward publishes the loss values
-        ctx.deferred = (_DEFER_LOSS_FINALIZE if (not want and ctx.needs_input_grad[0]
+        ctx.deferred = (_DEFER_LOSS_FINALIZE if (not want and ctx.needs_input_grad[0] and gt_rot is None
                                                  and spec.kind in ('pose_changes_6d', 'relative_rot_6d')) else 0)
         desc.defer_loss_finalize = int(ctx.deferred)
         with torch.cuda.device(dev):
             _lib.check(lib.p2c_pose_head_fwd(ctypes.byref(desc), _stream()), 'p2c_pose_head_fwd')
         ctx.spec, ctx.want = spec, want
-        ctx.save_for_backward(y, skel_type, dloc, drot, gt2d, gt3d, bufs['loss_sums'], bufs.get('final_rel_rot'))
+        ctx.save_for_backward(y, skel_type, dloc, drot, gt2d, gt3d, bufs['loss_sums'], bufs.get('final_rel_rot'), gt_rot)
         ctx.bufs = bufs
         result = [outs[k] for k in want]
         rot_diff = spec.kind in ('pose_changes_6d', 'relative_rot_6d')      # rot_3d-type losses: tangent-space backward
@@ -253,14 +265,14 @@ class PoseHeadFunction(torch.autograd.Function):
                    and not (k == 'absolute_pose_rot' and rot_diff)]
         ctx.mark_non_differentiable(*nondiff)
         ctx.set_materialize_grads(False)
-        vec = bufs['losses']
-        return (vec, vec[0], vec[1], vec[2], *result)       # the scalars are views of the vector: no device work
+        vec = losses4[:3]
+        return (vec, vec[0], vec[1], vec[2], losses4[3], *result)       # views of one buffer: no device work
 
     @staticmethod
-    def backward(ctx, g_losses, g0, g1, g2, *g_outs):
+    def backward(ctx, g_losses, g0, g1, g2, g_rot3d, *g_outs):
         lib = _lib.lib()
         spec = ctx.spec
-        y, skel_type, dloc, drot, gt2d, gt3d, loss_sums, final_rel_rot = ctx.saved_tensors
+        y, skel_type, dloc, drot, gt2d, gt3d, loss_sums, final_rel_rot, gt_rot = ctx.saved_tensors
         bufs = dict(ctx.bufs)
         bufs['loss_sums'] = loss_sums
         if final_rel_rot is not None:
@@ -283,22 +295,25 @@ class PoseHeadFunction(torch.autograd.Function):
             gl = _lib.grad_loss_pointers(vector=g_losses.data_ptr())
         else:
             gl = _lib.grad_loss_pointers(*[_ptr(g) for g in scalars])
-        desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, {})
+        g_rot3d = None if (g_rot3d is None or gt_rot is None) else _require_device(g_rot3d, 'grad rot_3d')
+        desc = _fill_desc(spec, y, skel_type, dloc, drot, gt2d, gt3d, bufs, {}, gt_rot, g_rot3d)
         desc.defer_loss_finalize = int(ctx.deferred)
         grad_y = torch.empty_like(y)
         with torch.cuda.device(y.device):
             _lib.check(lib.p2c_pose_head_bwd(ctypes.byref(desc), gl, _ptr(g_abs), _ptr(g_projt), _ptr(g_rot),
                                              grad_y.data_ptr(), _stream()), 'p2c_pose_head_bwd')
-        return grad_y, None, None, None, None, None, None, None
+        return grad_y, None, None, None, None, None, None, None, None
 
 
 def pose_head(y: Tensor, spec: PoseHeadSpec, skel_type: Tensor, dloc: Optional[Tensor] = None,
               drot: Optional[Tensor] = None, gt2d: Optional[Tensor] = None, gt3d: Optional[Tensor] = None,
-              want: Sequence[str] = ()) -> Tuple[Tensor, Dict[str, Tensor]]:
-    """Fused pose head. Returns (PoseLosses, {name: materialised tensor for name in want})."""
+              want: Sequence[str] = (), gt_rot: Optional[Tensor] = None) -> Tuple[Tensor, Dict[str, Tensor]]:
+    """Fused pose head. Returns (PoseLosses, {name: materialised tensor for name in want}). ``gt_rot`` =
+    targets['absolute_pose_rot']: the rot_3d loss (loss/rot_3d.py:9-37) comes out of the same launches (``losses.rot_3d``) --
+    the target rotations are read, no rotation tensor is written (6-D kinds)."""
     want = tuple(want)
-    res = PoseHeadFunction.apply(y, spec, skel_type, dloc, drot, gt2d, gt3d, want)
-    return PoseLosses(res[0], res[1:4]), dict(zip(want, res[4:]))
+    res = PoseHeadFunction.apply(y, spec, skel_type, dloc, drot, gt2d, gt3d, want, gt_rot)
+    return PoseLosses(res[0], res[1:4], res[4] if gt_rot is not None else None), dict(zip(want, res[5:]))
 
 
 # ----------------------------------------------------------------------------------------------------------------------

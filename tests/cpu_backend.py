@@ -10,7 +10,7 @@ import torch
 from oracle import pose_head as O
 
 
-def oracle_pose_head(y, spec, skel_type, dloc=None, drot=None, gt2d=None, gt3d=None, want=()):
+def oracle_pose_head(y, spec, skel_type, dloc=None, drot=None, gt2d=None, gt3d=None, want=(), gt_rot=None):
     out_idx = [j for j, g in enumerate(spec.gmap2d) if g >= 0]
     in_idx = [g for g in spec.gmap2d if g >= 0]
     full = out_idx == list(range(26)) and in_idx == list(range(26))
@@ -20,6 +20,11 @@ def oracle_pose_head(y, spec, skel_type, dloc=None, drot=None, gt2d=None, gt3d=N
                     mask_missing_joints=spec.mask_missing_joints, eval_slice=slice(*spec.eval_slice))
     nan = torch.tensor(float('nan'))
     losses = torch.stack([o.get('loc_2d', nan), o.get('loc_3d', nan), o.get('loc_2d_3d', nan)])
+    if gt_rot is not None:            # (the CPU plumbing tests use the location losses only; the attribute mirrors ops.PoseLosses)
+        frames = slice(*spec.eval_slice)
+        pred = o['absolute_pose_rot'][:, frames]
+        losses.rot_3d = torch.nn.functional.mse_loss(pred if full else pred[:, :, out_idx],
+                                                     gt_rot[:, frames] if full else gt_rot[:, frames][:, :, in_idx])
     return losses, {k: o[k] for k in want}
 
 

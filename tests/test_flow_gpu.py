@@ -303,9 +303,11 @@ def test_validation_updates_device_metrics():
     assert flow.compute_metrics(sync=False) == {}                  # reset
 
 
-def test_rotation_loss_modes_train_through_the_generic_path():
-    """loc_2d_loc_rot_3d (reference loss/loc_2d_loc_rot_3d.py): value and parameter gradients vs LinearAE-on-CPU + oracle."""
+def test_rotation_loss_modes_train_on_the_lean_path(monkeypatch):
+    """loc_2d_loc_rot_3d (reference loss/loc_2d_loc_rot_3d.py): value and parameter gradients vs LinearAE-on-CPU + oracle. The
+    rotation loss rides in the lean pose-head launches (p2c_pose_head_desc.gt_rot): no tensor is materialised in training."""
     import copy
+    from pedestrians_video_2_carla_amd import ops
     d = dev()
     flow, dm = make(loss_modes=('loc_2d_loc_rot_3d',), B=6, missing=0.0)
     flow.attach_datamodule(dm)
@@ -313,7 +315,16 @@ def test_rotation_loss_modes_train_through_the_generic_path():
     batch = dm.generate_batch(d)
     frames, targets, meta = batch
     flow.on_train_batch_start(batch, 0)
+    calls = []
+    real = ops.pose_head
+
+    def spy(*a, **k):
+        calls.append((tuple(k.get('want', ())), k.get('gt_rot') is not None))
+        return real(*a, **k)
+    monkeypatch.setattr(ops, 'pose_head', spy)
     out = flow.training_step(batch, 0)
+    monkeypatch.undo()
+    assert calls == [((), True)], calls                   # one lean call that carries the rotation targets
     out['loss'].backward()
     cpu_model = copy.deepcopy(flow.movements_model).cpu().double()
     cpu_model.rotation_output_format = 'rotation_6d'

@@ -342,6 +342,75 @@ def test_gradient_through_absolute_rotations(kind):
     close(yd.grad, y64.grad, 'grad through rotations')
 
 
+@pytest.mark.parametrize('kind', ['pose_changes_6d', 'relative_rot_6d'])
+@pytest.mark.parametrize('body25,sl', [(False, (None, None)), (True, (2, 6))])
+def test_rot_3d_fused_into_the_lean_pose_head(kind, body25, sl, kernel_variant):
+    """rot_3d (reference loss/rot_3d.py:9-37) out of the lean launches: the forward reads targets['absolute_pose_rot'] and
+    writes no rotation tensor, the backward turns 2 (A - gt) / n into torques. Value and grad_y -- alone, together with the
+    location losses, with the BODY_25 joint map and an eval slice -- against autograd of the fp64 oracle; and the same numbers
+    as the route over the materialised absolute_pose_rot + torch's mse_loss."""
+    from pedestrians_video_2_carla_amd import ops
+    from pedestrians_video_2_carla_amd.data.base.skeleton import get_common_indices
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.data.openpose.skeleton import BODY_25_SKELETON
+    d = dev()
+    gen = torch.Generator().manual_seed(23)
+    B, T = 7, 9
+    y = torch.randn(B, T, 26, 6, generator=gen)
+    y[..., 0] += 1.5
+    y[..., 4] += 1.5
+    st = torch.randint(0, 4, (B,), generator=gen)
+    Jg = 25 if body25 else 26
+    gt_rot = O.rotation_6d_to_matrix(torch.randn(B, T, Jg, 6, generator=gen).double())
+    gt3 = torch.randn(B, T, Jg, 3, generator=gen)
+    gt2 = torch.randn(B, T, Jg, 2, generator=gen)
+    family = kernel_variant          # (the packed / chain settings fall back to the joint-lane clip-sequential kernels here)
+    if body25:
+        out_idx, in_idx = get_common_indices(BODY_25_SKELETON, CARLA_SKELETON)
+        gmap = ops.joint_maps(out_idx, in_idx, Jg)
+        o_idx, i_idx = list(out_idx), list(in_idx)
+    else:
+        out_idx, in_idx, gmap = slice(None), slice(None), tuple(range(26))
+        o_idx = i_idx = None
+    spec = ops.PoseHeadSpec(kind=kind, gmap2d=gmap, gmap3d=gmap, eval_slice=sl, hips_lane=-1 if body25 else 1)
+    if True:
+        for with_loc in (False, True):
+            yd = y.to(d).requires_grad_(True)
+            losses, _ = ops.pose_head(yd, spec, st.to(d).int(), gt2d=gt2.to(d) if with_loc else None,
+                                      gt3d=gt3.to(d) if with_loc else None, gt_rot=gt_rot.float().to(d))
+            total = losses.rot_3d * 0.7 + (losses.loc_2d_3d if with_loc else 0.0)
+            total.backward()
+            y64 = y.double().requires_grad_(True)
+            o = O.pose_head(y64, kind, st, gt2d=gt2.double() if with_loc else None, gt3d=gt3.double() if with_loc else None,
+                            out_idx=o_idx, in_idx=i_idx, hips_col=None if body25 else 1, eval_slice=slice(*sl))
+            frames = slice(*sl)
+            rot = torch.nn.functional.mse_loss(o['absolute_pose_rot'][:, frames][:, :, out_idx], gt_rot[:, frames][:, :, in_idx])
+            (rot * 0.7 + (o['loc_2d_3d'] if with_loc else 0.0)).backward()
+            close(losses.rot_3d, rot, f'rot_3d ({family}, loc {with_loc})')
+            close(yd.grad, y64.grad, f'grad_y ({family}, loc {with_loc})')
+        # the materialising route gives the same loss and gradient
+        ya = y.to(d).requires_grad_(True)
+        _, outs = ops.pose_head(ya, spec, st.to(d).int(), want=('absolute_pose_rot',))
+        frames = slice(*sl)
+        via = torch.nn.functional.mse_loss(outs['absolute_pose_rot'][:, frames][:, :, out_idx],
+                                           gt_rot.float().to(d)[:, frames][:, :, in_idx])
+        via.backward()
+        yb = y.to(d).requires_grad_(True)
+        lb, _ = ops.pose_head(yb, spec, st.to(d).int(), gt_rot=gt_rot.float().to(d))
+        lb.rot_3d.backward()
+        close(lb.rot_3d, via, 'fused vs materialised value', rtol=1e-5)
+        close(yb.grad, ya.grad, 'fused vs materialised gradient', rtol=1e-4)
+
+
+def test_rot_3d_fusion_is_refused_for_matrix_kinds():
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    y = torch.eye(3, device=d).expand(2, 3, 26, 3, 3).contiguous()
+    with pytest.raises(RuntimeError):
+        ops.pose_head(y, ops.PoseHeadSpec(kind='pose_changes'), torch.zeros(2, dtype=torch.int32, device=d),
+                      gt_rot=torch.eye(3, device=d).expand(2, 3, 26, 3, 3).contiguous())
+
+
 def test_rotation_gradient_is_refused_for_matrix_kinds():
     from pedestrians_video_2_carla_amd import ops, _lib
     d = dev()
