@@ -362,6 +362,10 @@ typedef struct p2c_decoder_desc {
   float *out_bt;
   float *g_k0, *g_k1, *g_hid0, *g_hid1;
   int32_t g_out_bt;
+  /* teacher forcing (seq2seq.py:272-288,323-349), both or neither: force (T,B) 0 / 1 and target (T,B,O). Where force[t][b] != 0
+   * frame t of clip b -- the stored output AND the next step's input -- is target[t][b]; its rows of d out_total are zero (the
+   * reference writes the targets into the output tensor itself: those rows carry neither loss nor gradient). */
+  const float *force, *target;
 } p2c_decoder_desc;
 P2C_API int p2c_decoder_fwd(const p2c_decoder_desc *desc, void *stream);
 P2C_API int p2c_decoder_bwd(const p2c_decoder_desc *desc, void *stream);

@@ -89,7 +89,7 @@ class DecoderDesc(ctypes.Structure):
         (n, _f32p) for n in ('k0', 'c0', 'k1', 'c1', 'w_ih0', 'w_ih1', 'w_fc', 'b_fc', 'x0', 'drop', 'out', 'acts0', 'acts1',
                              'h0d', 'h1', 'g_out', 'g_gates0', 'g_gates1', 'g_outtot', 'g_c0', 'g_c1',
                              'hid0', 'hid1', 'w_hh0', 'w_hh1', 'b0a', 'b0b', 'b1a', 'b1b', 'kw0', 'kw1', 'out_bt',
-                             'g_k0', 'g_k1', 'g_hid0', 'g_hid1')] + [('g_out_bt', ctypes.c_int32)]
+                             'g_k0', 'g_k1', 'g_hid0', 'g_hid1')] + [('g_out_bt', ctypes.c_int32), ('force', _f32p), ('target', _f32p)]
 
 
 class AtbProblem(ctypes.Structure):

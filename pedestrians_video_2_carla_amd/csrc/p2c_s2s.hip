@@ -45,6 +45,8 @@ struct Args {
   float *out_bt;                         // (B,T,O) second copy of out in the model's output layout, or NULL
   float *g_k0, *g_k1, *g_hid0, *g_hid1;  // (B,4H) = sum_t d gates_l, (B,H) = g_k_l W_hh_l; or NULL
   int32_t T, B, O, g_out_bt;             // g_out_bt: g_out is laid out (B,T,O)
+  // teacher forcing (seq2seq.py:283-288): where force[t][b] != 0 the frame's output -- and so the next input -- IS target[t][b]
+  const float *force, *target;           // (T,B) 0 / 1, (T,B,O); or both NULL
 };
 
 
@@ -171,6 +173,14 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
     f32x4 acc[4], ai, af, ag, ao, h;
     const f32x4 m = mask;                            // this step's dropout mask was requested one step ahead
     mask = bload4(step_rows(a.drop, (t + 1 < T) ? t + 1 : t, B, H), off1);
+    // teacher forcing: flag and target features of this step, requested now, used behind the fc product (NULL: zeros)
+    const float forced = bload1(step_rows(a.force, t, B, 1), b * 4);
+    f32x4 tgt;
+    {
+      const __amdgpu_buffer_rsrc_t rtg = step_rows(a.target, t, B, O);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tgt[r] = bload1(rtg, offo[r]);
+    }
     // ---- layer 0
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = k0r[q];
@@ -211,6 +221,7 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
       o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ffc[ks + 1], h1T[(4 * ks + 4 + g) * TP + c], o2, 0, 0, 0);
     }
     o += o2;
+    if (forced != 0.f) o = tgt;
     const __amdgpu_buffer_rsrc_t ro = step_rows(a.out, t, B, O), rb = bt_rows(a.out_bt, t, B, T, O);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -263,8 +274,9 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
   // The rows a step reads (loss gradient, saved gates of both layers, dropout mask) are requested at the top of the previous
   // step and pinned at its end (a round trip to rows of a fresh 8 MB tensor measured longer than one 64-MFMA chain):
   // requested at their use, each of the three groups would put that round trip on the critical path of the step.
-  struct Saved { f32x4 go, a1[4], a0[4], m; };
+  struct Saved { f32x4 go, a1[4], a0[4], m; float forced; };
   auto fetch = [&](int t, Saved &s) {
+    s.forced = bload1(step_rows(a.force, t, B, 1), b * 4);
     const __amdgpu_buffer_rsrc_t rg = a.g_out_bt ? bt_rows(a.g_out, t, B, T, O) : step_rows(a.g_out, t, B, O);
     const __amdgpu_buffer_rsrc_t r1 = step_rows(a.acts1, t, B, G4), r0 = step_rows(a.acts0, t, B, G4);
 #pragma unroll
@@ -275,6 +287,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
   };
   auto pin_all = [&](Saved &s) {
     pin(s.go), pin(s.m);
+    asm volatile("" : "+v"(s.forced));
 #pragma unroll
     for (int q = 0; q < 4; ++q) pin(s.a1[q]), pin(s.a0[q]);
   };
@@ -287,6 +300,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
     fetch(t > 0 ? t - 1 : 0, nx);                    // (the last step re-reads its own rows: no branch in the body)
     // ---- d out_t (loss + the next step's input gradient), this wave's 16 output features
     f32x4 dout = dx + sv.go;                         // (features >= O: zero fragments gave dx = 0, the OOB load gave 0)
+    if (sv.forced != 0.f) dout = zero4();            // a forced frame is the target: no gradient reaches the decoder through it
     const __amdgpu_buffer_rsrc_t rt = step_rows(a.g_outtot, t, B, O);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -466,6 +480,8 @@ __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
   for (int t = 0; t < T; ++t) {
     const float m = mask;
     mask = bload1(step_rows(a.drop, (t + 1 < T) ? t + 1 : t, B, H), offh);
+    const float forced = bload1(step_rows(a.force, t, B, 1), b * 4);     // teacher forcing (NULL tensors read as zero)
+    const float tgt = bload1(step_rows(a.target, t, B, O), offo);
     f32x4 act;
     float h;
     // ---- layer 0
@@ -483,7 +499,8 @@ __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
     bstore1(step_rows(a.h1, t, B, H), offh, h);
     lds_barrier();
     // ---- fc
-    const float o = quarter_product<16>(ffc, h1s[s] + q * 16, q) + bfc;
+    float o = quarter_product<16>(ffc, h1s[s] + q * 16, q) + bfc;
+    if (forced != 0.f) o = tgt;                      // (features >= O: the out-of-range load gave zero)
     xs[s][u] = o;                                    // next step's input (features >= O are exactly zero)
     bstore1(step_rows(a.out, t, B, O), offo, o);
     bstore1(bt_rows(a.out_bt, t, B, T, O), offb, o);
@@ -521,8 +538,9 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
   f32x4 dk0 = zero4(), dk1 = zero4();                // sum_t d gates_l = the gradient of k_l
   const bool has_drop = a.drop != nullptr;
 
-  struct Saved { f32x4 a1, a0; float go, m; };
+  struct Saved { f32x4 a1, a0; float go, m, forced; };
   auto fetch = [&](int t, Saved &sv) {
+    sv.forced = bload1(step_rows(a.force, t, B, 1), b * 4);
     sv.go = bload1(a.g_out_bt ? bt_rows(a.g_out, t, B, T, O) : step_rows(a.g_out, t, B, O), offi);
     sv.a1 = load_gates1(step_rows(a.acts1, t, B, G4), offg);
     sv.a0 = load_gates1(step_rows(a.acts0, t, B, G4), offg);
@@ -530,7 +548,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
   };
   auto pin_all = [&](Saved &sv) {
     pin(sv.a1), pin(sv.a0);
-    asm volatile("" : "+v"(sv.go), "+v"(sv.m));
+    asm volatile("" : "+v"(sv.go), "+v"(sv.m), "+v"(sv.forced));
   };
   Saved nx = {};
   if (T > 0) fetch(T - 1, nx);
@@ -541,7 +559,8 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
     const Saved sv = nx;
     fetch(t > 0 ? t - 1 : 0, nx);                    // (the last step re-reads its own rows: no branch in the body)
     // ---- d out_t (loss + the next step's input gradient)
-    const float dout = dx + sv.go;                   // features >= O: zero fragments gave dx = 0, the OOB load 0
+    const float dout = sv.forced != 0.f ? 0.f : dx + sv.go;   // features >= O: zero fragments gave dx = 0, the OOB load 0;
+                                                              // a forced frame is the target: no gradient through it
     dos[s][u] = dout;
     bstore1(step_rows(a.g_outtot, t, B, O), offo, dout);
     lds_barrier();
@@ -634,6 +653,8 @@ static int fill(Args &a, const p2c_decoder_desc *d) {
   a.hid0 = d->hid0, a.hid1 = d->hid1, a.w_hh0 = d->w_hh0, a.w_hh1 = d->w_hh1, a.b0a = d->b0a, a.b0b = d->b0b, a.b1a = d->b1a;
   a.b1b = d->b1b, a.kw0 = d->kw0, a.kw1 = d->kw1, a.out_bt = d->out_bt, a.g_k0 = d->g_k0, a.g_k1 = d->g_k1;
   a.g_hid0 = d->g_hid0, a.g_hid1 = d->g_hid1, a.g_out_bt = d->g_out_bt;
+  if ((d->force != nullptr) != (d->target != nullptr)) return P2C_E_NULL;
+  a.force = d->force, a.target = d->target;
   return 0;
 }
 

@@ -165,9 +165,12 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         batch_size, clip_length = original_shape[:2]
         hidden, cell = self._encode(x)
         needs_forcing, forced, force_idx = self._teacher_forcing(targets)
-        if not needs_forcing and type(self)._decode_frame is Seq2Seq._decode_frame and self._decoder_loop_fusable(x):
-            # K7c: the T decoder steps (frozen encoder state, output fed back) are ONE HIP launch
-            return self._format_output(original_shape, self._fused_decoder(hidden, cell, clip_length), batch_first=True)
+        if type(self)._decode_frame is Seq2Seq._decode_frame and self._decoder_loop_fusable(x):
+            # K7c: the T decoder steps (frozen encoder state, output fed back, forced frames replaced in the launch) are ONE HIP
+            # launch
+            out = self._fused_decoder(hidden, cell, clip_length, force_idx if needs_forcing else None,
+                                      forced if needs_forcing else None)
+            return self._format_output(original_shape, out, batch_first=True)
         step_in = torch.zeros((batch_size, self.decoder.output_size), device=x.device, dtype=x.dtype)     # <sos>
         outputs = []
         for t in range(clip_length):
@@ -205,7 +208,8 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         return (_fused_ok(rnn, x) and rnn.bias and not rnn.bidirectional and isinstance(self.decoder.fc_out, nn.Linear)
                 and ops.decoder_loop_supported(rnn.hidden_size, rnn.num_layers, self.decoder.output_size))
 
-    def _fused_decoder(self, hidden: Tensor, cell: Tensor, clip_length: int) -> Tensor:
+    def _fused_decoder(self, hidden: Tensor, cell: Tensor, clip_length: int, force_idx: Tensor = None,
+                       forced: Tensor = None) -> Tensor:
         from pedestrians_video_2_carla_amd import ops
         rnn, fc = self.decoder.rnn, self.decoder.fc_out
         # (the decoder state is the encoder's for every frame: its recurrent terms k_l = b_ih_l + b_hh_l + W_hh_l hidden_l are
@@ -217,7 +221,7 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
             if ones is None or ones.shape != shape or ones.device != hidden.device or ones.dtype != hidden.dtype:
                 ones = self._drop_ones = torch.ones(shape, device=hidden.device, dtype=hidden.dtype)
             drop = torch.nn.functional.dropout(ones, rnn.dropout, True)
-        return ops.decoder_stack(hidden, cell, rnn, fc, clip_length, drop)            # (B,T,O)
+        return ops.decoder_stack(hidden, cell, rnn, fc, clip_length, drop, force_idx, forced)            # (B,T,O)
 
     def _format_output(self, original_shape, outputs, batch_first: bool = False):
         if not batch_first:

@@ -1393,7 +1393,8 @@ class DecoderStackFunction(torch.autograd.Function):
     the two sum_t reductions and the two permute copies of the output and its gradient (cfg3: ~30 launches)."""
 
     @staticmethod
-    def forward(ctx, hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc, drop, T: int):
+    def forward(ctx, hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc, drop, T: int,
+                force=None, target=None):
         lib = _lib.lib()
         names = ('hidden', 'cell', 'weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0', 'weight_ih_l1', 'weight_hh_l1',
                  'bias_ih_l1', 'bias_hh_l1', 'fc_out.weight', 'fc_out.bias')
@@ -1419,18 +1420,24 @@ class DecoderStackFunction(torch.autograd.Function):
         if kw is not None:
             d.kw0, d.kw1 = kw[0].data_ptr(), kw[1].data_ptr()
         d.drop = _ptr(drop)
+        if force is not None:            # teacher forcing: (T,B) 0 / 1 flags and the (T,B,O) target frames
+            force = _require_device(force, 'force flags').contiguous()
+            target = _require_device(target, 'forced targets').contiguous()
+            if tuple(force.shape) != (T, B) or tuple(target.shape) != (T, B, O):
+                raise RuntimeError(f'decoder stack: force should be ({T}, {B}) and target ({T}, {B}, {O})')
+            d.force, d.target = force.data_ptr(), target.data_ptr()
         d.out, d.out_bt, d.acts0, d.acts1, d.h0d, d.h1 = (t.data_ptr() for t in (out, out_bt, acts0, acts1, h0d, h1))
         with torch.cuda.device(hidden.device):
             _lib.check(lib.p2c_decoder_fwd(ctypes.byref(d), _stream()), 'p2c_decoder_fwd')
         ctx.save_for_backward(hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc, drop,
-                              out, acts0, acts1, h0d, h1)
+                              out, acts0, acts1, h0d, h1, force, target)
         return out_bt
 
     @staticmethod
     def backward(ctx, g_out_bt):
         lib = _lib.lib()
         (hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc, drop,
-         out, acts0, acts1, h0d, h1) = ctx.saved_tensors
+         out, acts0, acts1, h0d, h1, force, target) = ctx.saved_tensors
         T, B, O = out.shape
         H = hidden.shape[2]
         G = 4 * H
@@ -1446,6 +1453,8 @@ class DecoderStackFunction(torch.autograd.Function):
         d.drop = _ptr(drop)
         d.acts0, d.acts1, d.h0d, d.h1 = acts0.data_ptr(), acts1.data_ptr(), h0d.data_ptr(), h1.data_ptr()
         d.g_out, d.g_out_bt = g_out_bt.data_ptr(), 1
+        if force is not None:
+            d.force, d.target = force.data_ptr(), target.data_ptr()
         d.g_gates0, d.g_gates1, d.g_outtot = gg0.data_ptr(), gg1.data_ptr(), gtot.data_ptr()
         d.g_c0, d.g_c1, d.g_hid0, d.g_hid1 = g_cell[0].data_ptr(), g_cell[1].data_ptr(), g_hidden[0].data_ptr(), g_hidden[1].data_ptr()
         d.g_k0, d.g_k1 = g_k[0].data_ptr(), g_k[1].data_ptr()
@@ -1477,16 +1486,19 @@ class DecoderStackFunction(torch.autograd.Function):
                 for bn in biases:
                     ret[bn] = res[w][1]
         return (g_hidden, g_cell, ret['w_ih0'], ret['w_hh0'], ret['b_ih0'], ret['b_hh0'], ret['w_ih1'], ret['w_hh1'],
-                ret['b_ih1'], ret['b_hh1'], ret['w_fc'], ret['b_fc'], None, None)
+                ret['b_ih1'], ret['b_hh1'], ret['w_fc'], ret['b_fc'], None, None, None, None)
 
 
-def decoder_stack(hidden: Tensor, cell: Tensor, rnn, fc, T: int, drop: Optional[Tensor] = None) -> Tensor:
+def decoder_stack(hidden: Tensor, cell: Tensor, rnn, fc, T: int, drop: Optional[Tensor] = None, force: Optional[Tensor] = None,
+                  target: Optional[Tensor] = None) -> Tensor:
     """Seq2Seq's decoder (2-layer ``nn.LSTM`` ``rnn`` with biases + ``nn.Linear`` ``fc``) unrolled over T frames from the
-    encoder state; returns the frames batch-first, (B,T,O)."""
+    encoder state; returns the frames batch-first, (B,T,O). Teacher forcing: where ``force`` (T,B) is non-zero the frame IS
+    ``target`` (T,B,O) -- output and next input -- and passes no gradient (reference seq2seq.py:283-288)."""
     _prefer_rocblas_once()
     return DecoderStackFunction.apply(hidden, cell, rnn.weight_ih_l0, rnn.weight_hh_l0, rnn.bias_ih_l0, rnn.bias_hh_l0,
                                       rnn.weight_ih_l1, rnn.weight_hh_l1, rnn.bias_ih_l1, rnn.bias_hh_l1, fc.weight, fc.bias,
-                                      drop, T)
+                                      drop, T, None if force is None else force.to(torch.float32),
+                                      None if force is None else target.detach())
 
 
 def encoder_stack_supported(rnn, x: Tensor, flip: bool = False) -> bool:

@@ -120,6 +120,44 @@ def test_bidirectional_seq2seq_runs_on_the_hip_recurrence_and_matches_cpu(embedd
         close(pg.grad, pc.grad, 'grad ' + n, rtol=bound(p32.grad, pc.grad))
 
 
+@pytest.mark.parametrize('tile', ['narrow', 'wide'])
+@pytest.mark.parametrize('mode', ['frames_force', 'clip_force'])
+def test_teacher_forcing_inside_the_decoder_launch(tile, mode, monkeypatch):
+    """Teacher forcing (reference seq2seq.py:272-288,323-349) in K7c: forced frames are replaced by their targets inside the one
+    decoder launch (output AND next input, no gradient through them). Against the per-step path of the same model (K7b layer
+    launches + torch.where, the path tests/test_reference_wrappers.py pins to the reference's own run) with the same draws:
+    output and every parameter gradient."""
+    import copy
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2Seq
+    d = dev()
+    monkeypatch.setenv('P2C_REC_TILE', tile)
+    torch.manual_seed(17)
+    model = Seq2Seq(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_2d, p_dropout=0.0,
+                    teacher_mode=mode, teacher_force_ratio=0.4).to(d).train()
+    twin = copy.deepcopy(model)
+    B, T = 21, 12
+    x, up = torch.randn(B, T, 26, 2, device=d), torch.randn(B, T, 26, 2, device=d)
+    targets = {'projection_2d_transformed': torch.randn(B, T, 26, 2, device=d)}
+    assert model._decoder_loop_fusable(x)
+    torch.manual_seed(5)
+    y = model(x, targets)
+    (y * up).sum().backward()
+    monkeypatch.setattr(type(twin), '_decoder_loop_fusable', lambda self, x: False)
+    torch.manual_seed(5)
+    y_ref = twin(x, targets)
+    (y_ref * up).sum().backward()
+    monkeypatch.undo()
+    forced = (y == targets['projection_2d_transformed']).all(-1).all(-1)           # (B,T) frames that are their targets
+    assert 0.2 < float(forced.float().mean()) < 0.6
+    if mode == 'clip_force':
+        assert bool((forced.all(1) | (~forced).all(1)).all())
+    close(y, y_ref, 'forced decoder output', rtol=2e-5)
+    for (n, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
+        close(p.grad, q.grad, 'grad ' + n, rtol=2e-4)
+
+
 def test_no_cpu_fallback():
     from pedestrians_video_2_carla_amd import ops, _lib
     with pytest.raises(_lib.P2CError):
