@@ -147,6 +147,50 @@ struct ClipArgs {
   int32_t identity_maps;   // gmap2d[j] == gmap3d[j] == j for every joint (host-checked)
 };
 
+// ---- the weight image by LDS-DMA (round 3 experiment, OFF: build with EXTRA=-DP2C_TRAIN_DMA_IMAGE=1) ------------------------
+// The 70 KB image is a straight copy HBM -> LDS; staged through registers (stage_issue / stage_commit, K8) it arrives at
+// ~11 B/clk per CU. Variant: every wave issues ALL its 1 KB pieces at once (buffer_load ... lds: no registers held, no LDS
+// store instructions) and a layer waits for the pieces it reads with s_waitcnt vmcnt(n) (vector-memory operations retire in
+// order). Correct (bitwise tests pass) but SLOWER: train_clip_kernel 19.0 vs 18.1 us at B = 256, equal at B = 1024. The ~25
+// ordinary loads a wave issues behind its pieces (targets, tables, counts) cannot retire before them and make every counted
+// wait cover the whole image, so the per-layer pipelining of the staged rounds is lost; issuing the pieces after those loads
+// would put them behind the skel_type -> table address chain.
+#ifndef P2C_TRAIN_DMA_IMAGE
+#define P2C_TRAIN_DMA_IMAGE 0
+#endif
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+constexpr int IMG_CHUNKS = ((S::w_total() >> 2) + 63) / 64;          // 1 KB pieces (64 lanes x 16 B)
+__device__ __forceinline__ void image_dma_issue(const float *w_image, float *lds, int wave, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w_image), 0, S::w_total() * 4, 0x00020000);
+  const unsigned base = (unsigned)(uintptr_t)(lds_void_ptr)lds;
+  constexpr int total4 = S::w_total() >> 2;
+#pragma unroll
+  for (int i = 0; i < (IMG_CHUNKS + WAVES - 1) / WAVES; ++i) {
+    const int c = wave + i * WAVES;                                  // (wave-uniform)
+    if (c < IMG_CHUNKS && c * 64 + lane < total4)                    // the last piece is partial: its tail lanes stay out (the LDS
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(uintptr_t)(base + c * 1024), 16, (c * 64 + lane) * 16, 0, 0, 0);   // behind the image is live)
+  }
+}
+// this wave's pieces of layers 0..l have landed (pieces are issued in ascending order, wave w owns pieces w, w + WAVES, ...)
+__device__ __forceinline__ void image_dma_wait(int l, int wave) {
+  const int end4 = (l + 1 >= NLAY) ? (S::w_total() >> 2) : ((S::w_off(l + 1) + 3) >> 2);
+  const int bound = (end4 + 63) / 64;                                // pieces [0, bound) hold layers 0..l
+  const int mine = wave < IMG_CHUNKS ? (IMG_CHUNKS - wave + WAVES - 1) / WAVES : 0;
+  const int before = wave < bound ? (bound - wave + WAVES - 1) / WAVES : 0;
+  switch (mine - before) {                                           // my pieces that may still be on their way
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+  }
+}
+
 template <int KIND>
 __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_head_desc d, const ph::GradLosses gl,
                                                                 const ClipArgs m) {
@@ -158,7 +202,7 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   L.lane = threadIdx.x & 63, L.c = L.lane & 15, L.g = L.lane >> 4;
   L.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int nl = NLAY;
-  constexpr int total4 = S::w_total() >> 2;
+  [[maybe_unused]] constexpr int total4 = S::w_total() >> 2;
   float *H = lds + S::w_total();
   float *G = H + (S::h_off(nl) - S::h_off(1)) * TP;        // G_l lives at row h_off(l) of this base (l = 1..L)
   float *Y = G + S::h_off(nl) * TP;                        // y^T, later grad_y^T (= G_L)
@@ -171,9 +215,13 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
   // Persistent over clips: workgroup b walks clips b, b + gridDim.x, ... (grid = min(B, CUs)); the 84 KB weight image is staged
   // ONCE, during the first clip's forward. The first clip's x tile is requested first, then the image rounds.
   TileRegs xr;
-  ImageRegs wr;
   tile_issue(m.x, (int64_t)blockIdx.x * T, (int64_t)blockIdx.x * T + T, S::dims(0), true, xr);
+#if P2C_TRAIN_DMA_IMAGE
+  image_dma_issue(m.w_image, lds, L.wave, L.lane);
+#else
+  ImageRegs wr;
   stage_issue(m.w_image, total4, wr, 0, 0, issue_mark<S>(1));
+#endif
   // lane context of the pose head (= p2c::make_lane_tp) -- with identity joint maps (CARLA targets for a CARLA model, the
   // usual case) nothing in the prologue depends on a loaded value: every load is issued back to back. (The general maps
   // are kernel arguments indexed by lane, i.e. vector loads whose result the target addresses wait for.)
@@ -233,10 +281,16 @@ __global__ __launch_bounds__(64 * WAVES) void train_clip_kernel(const p2c_pose_h
     tile_issue(m.x, nxt * T, nxt < d.B ? nxt * T + T : 0, S::dims(0), true, xr);
   }
   for_layers(sh, 0, nl, [&](int ll) {
+#if P2C_TRAIN_DMA_IMAGE
+    if constexpr (first) image_dma_wait(ll, L.wave);
+    lds_barrier();
+    TT(0, 2 + ll);
+#else
     if constexpr (first) stage_commit(total4, wr, lds, 0, ll == 0 ? 0 : rounds_upto<S>(ll - 1), rounds_upto<S>(ll));
     lds_barrier();
     TT(0, 2 + ll);
     if constexpr (first) stage_issue(m.w_image, total4, wr, 0, issue_mark<S>(ll + 1), issue_mark<S>(ll + 2));
+#endif
     const bool last = (ll == nl - 1);
     layer_forward(L, lds + S::w_off(ll), S::ld(ll), S::dims(ll), S::dims(ll + 1), !last, H + S::h_off(ll) * TP,
                   last ? Y : H + S::h_off(ll + 1) * TP, nullptr, false, false);
