@@ -64,33 +64,56 @@ __device__ __forceinline__ void store_rows_transposed(float *slab, int ld, const
 #pragma unroll
     for (int e = 0; e < 4; ++e) slab[(kq + i * 4 + e) * ld + row] = r.v[i][e];
 }
-// B slab for the NN form: (BK x BN) from a row-major (K, N) matrix, stored as it is ([k][n], pitch ldb_s)
-template <int BN, bool VEC>
+// k-major slabs (B of the NN form, A and B of the TN form): (BK x W) floats from a row-major (K, W') matrix, stored as they are
+// ([k][n], pitch W + 4 floats: 16-byte aligned rows). 16-byte piece q = t + 256 i of the slab is row q / (W / 4), column piece
+// q % (W / 4): consecutive lanes take consecutive pieces -- whole 128-byte lines from memory and conflict-free ds_write_b128
+// into LDS. (The first version gave a thread 16 consecutive floats of a row and wrote them as dwords: lanes 64 bytes apart hit
+// 16 of 32 banks -- SQ_LDS_BANK_CONFLICT 35 M / 71 M cycles per NN / TN launch at 21 024 x 2 496 x 832, none in the NT form.)
+template <int W>
+struct KnMap {
+  static constexpr int PIECES = BK * W / 4 / NTH;        // pieces per thread: 4 / 2 / 1
+  static constexpr int PPR = W / 4;                      // pieces per k-row
+  __device__ static __forceinline__ int row(int i) { return ((int)threadIdx.x + i * NTH) / PPR; }
+  __device__ static __forceinline__ int col(int i) { return (((int)threadIdx.x + i * NTH) % PPR) * 4; }
+};
+template <int W, bool VEC>
 __device__ __forceinline__ void load_kn(const float *base, int64_t ld, int k0, int K, int n0, int N, SlabRegs &r) {
-  constexpr int PER = BK * BN / NTH;                 // floats per thread: 16 / 8 / 4
-  constexpr int TPR = BN / PER;                      // threads per k-row
-  const int k = (int)threadIdx.x / TPR, n = ((int)threadIdx.x % TPR) * PER;
-  const bool k_ok = k0 + k < K;
-  const float *p = base + (int64_t)(k0 + (k_ok ? k : 0)) * ld + n0 + n;
+  using M = KnMap<W>;
 #pragma unroll
-  for (int i = 0; i < PER / 4; ++i) {
+  for (int i = 0; i < M::PIECES; ++i) {
+    const int k = k0 + M::row(i), n = n0 + M::col(i);
+    const bool k_ok = k < K;
+    const float *p = base + (int64_t)(k_ok ? k : 0) * ld + n;
     if (VEC) {
-      r.v[i] = (k_ok && n0 + n + i * 4 < N) ? *reinterpret_cast<const f32x4 *>(p + i * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      r.v[i] = (k_ok && n < N) ? *reinterpret_cast<const f32x4 *>(p) : (f32x4){0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r.v[i][e] = (k_ok && n0 + n + i * 4 + e < N) ? p[i * 4 + e] : 0.f;
+      for (int e = 0; e < 4; ++e) r.v[i][e] = (k_ok && n + e < N) ? p[e] : 0.f;
     }
   }
 }
-template <int BN>
+template <int W>
 __device__ __forceinline__ void store_kn(float *slab, int ld, const SlabRegs &r) {
-  constexpr int PER = BK * BN / NTH, TPR = BN / PER;
-  const int k = (int)threadIdx.x / TPR, n = ((int)threadIdx.x % TPR) * PER;
+  using M = KnMap<W>;
 #pragma unroll
-  for (int i = 0; i < PER / 4; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) slab[k * ld + n + i * 4 + e] = r.v[i][e];
+  for (int i = 0; i < M::PIECES; ++i) *reinterpret_cast<f32x4 *>(slab + M::row(i) * ld + M::col(i)) = r.v[i];
 }
+
+// Workgroups are dealt to the eight XCDs round-robin by their linear id, and every XCD has its own L2: with tile = id, the
+// tiles that share an operand slab (one row of tiles shares A, one column B) are spread over all eight L2s. xcd_tile gives
+// XCD x the contiguous tile range [x n / 8, (x + 1) n / 8): what runs side by side on an XCD is a compact patch of C.
+// The grid is rounded up to a multiple of 8; ids whose tile falls outside leave at once.
+#ifndef P2C_GEMM_XCD_SWIZZLE
+#define P2C_GEMM_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ int xcd_tile(int id, int n) {
+#if P2C_GEMM_XCD_SWIZZLE
+  return (id & 7) * ((n + 7) >> 3) + (id >> 3);
+#else
+  return id;
+#endif
+}
+static inline unsigned xcd_grid(int64_t n) { return (unsigned)(((n + 7) >> 3) << 3); }
 
 // TN form (weight gradients of wide layers, dW = dy^T x: A = dy is (K, M) row-major, B = x is (K, N) row-major, K = rows >> M, N):
 // split over K in `slices` (blockIdx.y), every slice writes its own (M, N) slab of the workspace, tn_finish_kernel adds the
@@ -106,15 +129,18 @@ struct TnArgs {
   int32_t bias_accumulate;
 };
 template <int BN, bool VEC>
-__global__ __launch_bounds__(NTH) void gemm_tn_kernel(const TnArgs d) {
+__global__ __launch_bounds__(NTH, 3) void gemm_tn_kernel(const TnArgs d) {
   constexpr int WM = (BN == 128) ? 2 : 4, TM = (BN == 128) ? 2 : 1, TN = (BN == 128) ? 2 : BN / 32;
-  __shared__ float As[BK * (BM + 4)];
-  __shared__ float Bs[BK * (BN + 4)];
-  const int n_tiles = (d.N + BN - 1) / BN;
-  const int tm = (int)blockIdx.x / n_tiles, tn = (int)blockIdx.x % n_tiles;
+  __shared__ __attribute__((aligned(16))) float As[BK * (BM + 4)];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * (BN + 4)];
+  const int n_tiles = (d.N + BN - 1) / BN, tiles = ((d.M + BM - 1) / BM) * n_tiles;
+  const int id = xcd_tile((int)blockIdx.x, tiles * d.slices);
+  if (id >= tiles * d.slices) return;
+  const int slice = id / tiles, tile = id - slice * tiles;
+  const int tm = tile / n_tiles, tn = tile % n_tiles;
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave % WM, wn = wave / WM, li = lane & 31, lk = lane >> 5;
-  const int k_begin = (int)blockIdx.y * d.k_chunk, k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
+  const int k_begin = slice * d.k_chunk, k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -124,16 +150,16 @@ __global__ __launch_bounds__(NTH) void gemm_tn_kernel(const TnArgs d) {
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
   SlabRegs ra, rb;
   const int nk = (k_end - k_begin + BK - 1) / BK;
-  constexpr int A_TPR = BM / (BK * BM / NTH);      // threads per k-row of the A slab (load_kn<BM>)
   const bool sums = d.bias && tn == 0 && (int)threadIdx.x < BM;
   float colsum = 0.f;
   auto fetch = [&](int kt) {
     load_kn<BM, VEC>(d.a, d.lda, k_begin + kt * BK, k_end, m0, d.M, ra);
     if (d.row_scale) {
-      const int k = k_begin + kt * BK + (int)threadIdx.x / A_TPR;
-      const float f = k < k_end ? d.row_scale[k / d.rows_per_scale] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ra.v[i] *= f;
+      for (int i = 0; i < KnMap<BM>::PIECES; ++i) {
+        const int k = k_begin + kt * BK + KnMap<BM>::row(i);
+        ra.v[i] *= k < k_end ? d.row_scale[k / d.rows_per_scale] : 0.f;
+      }
     }
     load_kn<BN, VEC>(d.b, d.ldb, k_begin + kt * BK, k_end, n0, d.N, rb);
   };
@@ -148,18 +174,27 @@ __global__ __launch_bounds__(NTH) void gemm_tn_kernel(const TnArgs d) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) fetch(kt + 1);
+    // operand fragments of k-step ks + 1 are read from LDS BEFORE the MFMAs of k-step ks are issued (two register sets): the
+    // compiler keeps source order here, and with read -> wait -> four MFMAs per step every step exposed an LDS round trip
+    float af[2][TM], bf[2][TN];
+    auto frag = [&](int ks, int buf) {
+      const int k = ks * 2 + lk;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[buf][a] = As[k * (BM + 4) + (wm * TM + a) * 32 + li];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[buf][b] = Bs[k * (BN + 4) + (wn * TN + b) * 32 + li];
+    };
+    frag(0, 0);
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const int k = ks * 2 + lk;
-      float af[TM], bf[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = As[k * (BM + 4) + (wm * TM + a) * 32 + li];
-#pragma unroll
-      for (int b = 0; b < TN; ++b) bf[b] = Bs[k * (BN + 4) + (wn * TN + b) * 32 + li];
+      if (ks + 1 < BK / 2) frag(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);           // (keep the reads of step ks + 1 ahead of the MFMAs of step ks)
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][a], bf[ks & 1][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (sums) {
 #pragma unroll
@@ -171,8 +206,8 @@ __global__ __launch_bounds__(NTH) void gemm_tn_kernel(const TnArgs d) {
       __syncthreads();
     }
   }
-  if (sums && m0 + (int)threadIdx.x < d.M) d.ws_bias[(int64_t)blockIdx.y * d.M + m0 + (int)threadIdx.x] = colsum;
-  float *slab = d.ws + (int64_t)blockIdx.y * d.M * d.N;
+  if (sums && m0 + (int)threadIdx.x < d.M) d.ws_bias[(int64_t)slice * d.M + m0 + (int)threadIdx.x] = colsum;
+  float *slab = d.ws + (int64_t)slice * d.M * d.N;
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
     const int n = n0 + (wn * TN + b) * 32 + li;
@@ -204,15 +239,17 @@ __global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
 }
 
 template <int BN, bool TRANS_B, bool VEC>
-__global__ __launch_bounds__(NTH) void gemm_kernel(const p2c_gemm_desc d) {
+__global__ __launch_bounds__(NTH, 3) void gemm_kernel(const p2c_gemm_desc d) {
   constexpr int WM = (BN == 128) ? 2 : 4;            // waves along m
   constexpr int TM = (BN == 128) ? 2 : 1;            // 32 x 32 MFMA tiles per wave along m ...
   constexpr int TN = (BN == 128) ? 2 : BN / 32;      // ... and along n
   constexpr int LDB = BN + 1;
-  __shared__ float As[BK * LDA];
-  __shared__ float Bs[BK * (BN + 4)];
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * (BN + 4)];
   const int n_tiles = (d.N + BN - 1) / BN;
-  const int tm = (int)blockIdx.x / n_tiles, tn = (int)blockIdx.x % n_tiles;     // neighbours share the A rows (L2)
+  const int id = xcd_tile((int)blockIdx.x, ((d.M + BM - 1) / BM) * n_tiles);
+  if (id >= ((d.M + BM - 1) / BM) * n_tiles) return;
+  const int tm = id / n_tiles, tn = id % n_tiles;                                // neighbours share the A rows (L2)
   const int m0 = tm * BM, n0 = tn * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave % WM, wn = wave / WM;
@@ -247,18 +284,25 @@ __global__ __launch_bounds__(NTH) void gemm_kernel(const p2c_gemm_desc d) {
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) fetch(kt + 1);
+    float af[2][TM], bf[2][TN];          // (fragments of the next k-step are read before this step's MFMAs: see gemm_tn_kernel)
+    auto frag = [&](int ks, int buf) {
+      const int k = ks * 2 + lk;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[buf][a] = As[k * LDA + (wm * TM + a) * 32 + li];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[buf][b] = Bs[k * ldb_s + (wn * TN + b) * 32 + li];
+    };
+    frag(0, 0);
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const int k = ks * 2 + lk;
-      float af[TM], bf[TN];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) af[a] = As[k * LDA + (wm * TM + a) * 32 + li];
-#pragma unroll
-      for (int b = 0; b < TN; ++b) bf[b] = Bs[k * ldb_s + (wn * TN + b) * 32 + li];
+      if (ks + 1 < BK / 2) frag(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);           // (keep the reads of step ks + 1 ahead of the MFMAs of step ks)
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bf[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][a], bf[ks & 1][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
     if (kt + 1 < nk) {
@@ -295,7 +339,7 @@ __global__ __launch_bounds__(NTH) void gemm_kernel(const p2c_gemm_desc d) {
 
 template <int BN, bool TRANS_B>
 static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
-  const unsigned grid = (unsigned)(((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN));
+  const unsigned grid = xcd_grid((int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN));
   if (vec) hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, true>), dim3(grid), dim3(NTH), 0, s, d);
   else hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, false>), dim3(grid), dim3(NTH), 0, s, d);
 }
@@ -341,7 +385,7 @@ extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t 
   auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = al(a) && al(b) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
   const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
-  const dim3 grid((unsigned)(((M + BM - 1) / BM) * ((N + bn - 1) / bn)), (unsigned)d.slices);
+  const dim3 grid(xcd_grid((int64_t)((M + BM - 1) / BM) * ((N + bn - 1) / bn) * d.slices));
 #define P2C_TN(BN_)                                                                         \
   do {                                                                                      \
     if (vec) hipLaunchKernelGGL((gemm_tn_kernel<BN_, true>), grid, dim3(NTH), 0, s, d);     \
