@@ -29,6 +29,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BK = 32, NTH = 256;
+
+#ifdef P2C_GEMM_TRACE   // developer build only (tools/gemmtrace.py): shader-clock stamps of one workgroup of gemm_kernel
+#ifndef P2C_GEMM_TRACE_BLOCK
+#define P2C_GEMM_TRACE_BLOCK 2000
+#endif
+static __device__ unsigned long long g_gemm_trace[64];
+#define GT(i)                                                                                                     \
+  do {                                                                                                            \
+    if ((int)blockIdx.x == P2C_GEMM_TRACE_BLOCK && threadIdx.x == 0 && (i) < 64) g_gemm_trace[i] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define GT(i)
+#endif
 constexpr int LDA = BM + 1;          // pitch of the k-major A slab (floats)
 
 __device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
@@ -36,33 +49,41 @@ __device__ __forceinline__ float gelu_grad(float z) {
   return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.39894228040143268f * __expf(-0.5f * z * z);
 }
 
-// A slab (BM x BK) from a row-major (rows, K) matrix: thread t takes 16 consecutive k of row t >> 1 (two threads = one 128-byte line)
+// row-major slabs (A of the NT / NN forms, B of the NT form): (rows x BK) floats from a row-major (rows, K) matrix. 16-byte piece
+// q = t + 256 i is row q / 8, k-piece q % 8: the eight lanes of a row take one whole 128-byte line per instruction. (The first
+// version gave a thread 16 consecutive k of a row: each of its four load instructions touched 32 lines for 32 bytes each, the
+// same lines four times over -- the timeline of a workgroup, tools/gemmtrace.py, showed the ISSUE of the eight loads of a
+// k-tile taking up to 19 k cycles with three workgroups per CU: the vector-memory path was saturated with line requests.)
 struct SlabRegs {
   f32x4 v[4];
 };
 template <bool VEC>
 __device__ __forceinline__ void load_rows(const float *base, int64_t ld, int row0, int n_rows, int k0, int K, SlabRegs &r, int rows_in_tile) {
-  const int row = (int)threadIdx.x >> 1, kq = ((int)threadIdx.x & 1) * 16;
-  const bool row_ok = row < rows_in_tile && row0 + row < n_rows;
-  const float *p = base + (int64_t)(row0 + (row_ok ? row : 0)) * ld + k0 + kq;
+  const int kp = ((int)threadIdx.x & 7) * 4, k = k0 + kp;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int k = k0 + kq + i * 4;
+    const int row = ((int)threadIdx.x >> 3) + 32 * i;
+    const bool row_ok = row < rows_in_tile && row0 + row < n_rows;
+    const float *p = base + (int64_t)(row0 + (row_ok ? row : 0)) * ld + k;
     if (VEC) {
-      r.v[i] = (row_ok && k < K) ? *reinterpret_cast<const f32x4 *>(p + i * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      r.v[i] = (row_ok && k < K) ? *reinterpret_cast<const f32x4 *>(p) : (f32x4){0.f, 0.f, 0.f, 0.f};
     } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r.v[i][e] = (row_ok && k + e < K) ? p[i * 4 + e] : 0.f;
+      for (int e = 0; e < 4; ++e) r.v[i][e] = (row_ok && k + e < K) ? p[e] : 0.f;
     }
   }
 }
-// ... into the k-major LDS slab [k][row] (pitch `ld`: odd -> the two threads of a row hit banks 16 apart)
-__device__ __forceinline__ void store_rows_transposed(float *slab, int ld, const SlabRegs &r) {
-  const int row = (int)threadIdx.x >> 1, kq = ((int)threadIdx.x & 1) * 16;
+// ... into the k-major LDS slab [k][row] (pitch `ld` odd: the 64 lanes of a store -- 8 rows x 8 k-pieces -- fall two per bank)
+__device__ __forceinline__ void store_rows_transposed(float *slab, int ld, const SlabRegs &r, int rows_in_tile) {
+  const int kp = ((int)threadIdx.x & 7) * 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
+    const int row = ((int)threadIdx.x >> 3) + 32 * i;
+    if (row < rows_in_tile) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) slab[(kq + i * 4 + e) * ld + row] = r.v[i][e];
+      for (int e = 0; e < 4; ++e) slab[(kp + e) * ld + row] = r.v[i][e];
+    }
+  }
 }
 // k-major slabs (B of the NN form, A and B of the TN form): (BK x W) floats from a row-major (K, W') matrix, stored as they are
 // ([k][n], pitch W + 4 floats: 16-byte aligned rows). 16-byte piece q = t + 256 i of the slab is row q / (W / 4), column piece
@@ -238,6 +259,10 @@ __global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
   }
 }
 
+// (An LDS double-buffered main loop -- the wave stores k-tile kt + 1 into the other slab pair and requests kt + 2 in the middle of
+// the MFMAs of kt, one barrier per k-tile -- was measured twice and is slower: 945 vs 846 us at 21 024 x 2 496 x 832. LDS
+// operations of a wave complete in order, so the operand reads behind the 32 stores wait for them anyway, and 66 KB of slabs
+// leave two workgroups per CU instead of three.)
 template <int BN, bool TRANS_B, bool VEC>
 __global__ __launch_bounds__(NTH, 3) void gemm_kernel(const p2c_gemm_desc d) {
   constexpr int WM = (BN == 128) ? 2 : 4;            // waves along m
@@ -272,18 +297,23 @@ __global__ __launch_bounds__(NTH, 3) void gemm_kernel(const p2c_gemm_desc d) {
     else load_kn<BN, VEC>(d.b, d.ldb, kt * BK, d.K, n0, d.N, rb);
   };
   auto commit = [&]() {
-    store_rows_transposed(As, LDA, ra);
+    store_rows_transposed(As, LDA, ra, BM);
     if (TRANS_B) {
-      if ((int)threadIdx.x < BN * 2) store_rows_transposed(Bs, ldb_s, rb);
+      store_rows_transposed(Bs, ldb_s, rb, BN);
     } else {
       store_kn<BN>(Bs, ldb_s, rb);
     }
   };
+  GT(0);
   fetch(0);
+  GT(1);
   commit();
+  GT(2);
   __syncthreads();
+  GT(3);
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) fetch(kt + 1);
+    if (kt < 8) GT(4 + kt * 6);
     float af[2][TM], bf[2][TN];          // (fragments of the next k-step are read before this step's MFMAs: see gemm_tn_kernel)
     auto frag = [&](int ks, int buf) {
       const int k = ks * 2 + lk;
@@ -304,12 +334,21 @@ __global__ __launch_bounds__(NTH, 3) void gemm_kernel(const p2c_gemm_desc d) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][a], bf[ks & 1][b], acc[a][b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (kt < 8) GT(5 + kt * 6);
     __syncthreads();
+    if (kt < 8) GT(6 + kt * 6);
     if (kt + 1 < nk) {
+#ifdef P2C_GEMM_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (kt < 8) GT(7 + kt * 6);
+#endif
       commit();
+      if (kt < 8) GT(8 + kt * 6);
       __syncthreads();
+      if (kt < 8) GT(9 + kt * 6);
     }
   }
+  GT(60);
 
   // ---- epilogue: C/D layout of the 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----
 #pragma unroll
@@ -335,6 +374,7 @@ __global__ __launch_bounds__(NTH, 3) void gemm_kernel(const p2c_gemm_desc d) {
         d.c[(int64_t)m * d.ldc + n] = v;
       }
   }
+  GT(61);
 }
 
 template <int BN, bool TRANS_B>
@@ -400,6 +440,12 @@ extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t 
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+
+#ifdef P2C_GEMM_TRACE
+extern "C" __attribute__((visibility("default"))) int p2c_debug_gemm_trace(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_gemm_impl::g_gemm_trace), sizeof(unsigned long long) * 64);
+}
+#endif
 
 extern "C" int p2c_gemm(const p2c_gemm_desc *desc, void *stream_) {
   using namespace p2c_gemm_impl;
