@@ -20,6 +20,7 @@
 // The weight gradient dW = dy^T x is K12 (p2c_atb.hip: K >> M, N).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/p2c.h"
 
@@ -150,7 +151,7 @@ struct TnArgs {
   int32_t bias_accumulate;
 };
 template <int BN, bool VEC>
-__global__ __launch_bounds__(NTH, 3) void gemm_tn_kernel(const TnArgs d) {
+__global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_tn_kernel(const TnArgs d) {
   constexpr int WM = (BN == 128) ? 2 : 4, TM = (BN == 128) ? 2 : 1, TN = (BN == 128) ? 2 : BN / 32;
   __shared__ __attribute__((aligned(16))) float As[BK * (BM + 4)];
   __shared__ __attribute__((aligned(16))) float Bs[BK * (BN + 4)];
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
 // operations of a wave complete in order, so the operand reads behind the 32 stores wait for them anyway, and 66 KB of slabs
 // leave two workgroups per CU instead of three.)
 template <int BN, bool TRANS_B, bool VEC>
-__global__ __launch_bounds__(NTH, 3) void gemm_kernel(const p2c_gemm_desc d) {
+__global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_kernel(const p2c_gemm_desc d) {
   constexpr int WM = (BN == 128) ? 2 : 4;            // waves along m
   constexpr int TM = (BN == 128) ? 2 : 1;            // 32 x 32 MFMA tiles per wave along m ...
   constexpr int TN = (BN == 128) ? 2 : BN / 32;      // ... and along n
@@ -386,11 +387,19 @@ static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
 
 }  // namespace p2c_gemm_impl
 
+static int tn_bn(int N) {
+  int bn = N > 32 ? 64 : 32;                          // (64: measured ahead of 128 at 832 x 832, equal elsewhere)
+  if (const char *e = getenv("P2C_GEMM_TN_BN")) {     // (experiments)
+    const int v = atoi(e);
+    if (v == 32 || v == 64 || v == 128) bn = v;
+  }
+  return bn;
+}
 static int tn_slices(int M, int N, int K) {
   using namespace p2c_gemm_impl;
   // Every workgroup is MFMA-bound, so the launch takes as long as the busiest CU: pick the slice count whose grid fills the
   // 256 CUs most evenly (tiles * slices close below a multiple of 256), with at least 16 k-steps per slice.
-  const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  const int bn = tn_bn(N);
   const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
   int max_s = K / (16 * BK);
   max_s = max_s < 1 ? 1 : (max_s > 32 ? 32 : max_s);
@@ -424,7 +433,7 @@ extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t 
   hipStream_t s = (hipStream_t)stream_;
   auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = al(a) && al(b) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
-  const int bn = N > 64 ? 128 : (N > 32 ? 64 : 32);
+  const int bn = tn_bn(N);
   const dim3 grid(xcd_grid((int64_t)((M + BM - 1) / BM) * ((N + bn - 1) / bn) * d.slices));
 #define P2C_TN(BN_)                                                                         \
   do {                                                                                      \
@@ -461,11 +470,23 @@ extern "C" int p2c_gemm(const p2c_gemm_desc *desc, void *stream_) {
   // 16-byte loads need 16-byte aligned rows: every leading dimension a multiple of 4 floats, bases aligned, K (NT) / N (NN) too
   auto al = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   const bool vec = al(d.a) && al(d.b) && d.lda % 4 == 0 && d.ldb % 4 == 0 && d.K % 4 == 0 && (d.trans_b || d.N % 4 == 0);
-  // the widest column tile that still gives every CU two workgroups; small problems (the 8 192-row projections around the
-  // Seq2Seq recurrences) take narrower tiles to reach more CUs
-  int bn = d.N > 64 ? 128 : (d.N > 32 ? 64 : 32);
+  // Column tile: 64 (four waves of 32 x 64 side by side) -- measured ahead of the 2 x 2 arrangement of 64 x 64 waves at every
+  // wide shape of cfg5 (NT 832-wide outputs +6..10 %, equal at 2 496; 120 VGPRs -> four workgroups per CU), 32 for the NN form
+  // (another 3..5 %) and for N <= 32. Small problems (the 8 192-row projections around the Seq2Seq recurrences) take the
+  // narrowest tile to reach more CUs. P2C_GEMM_BN forces one (experiments; the 128-column instantiation stays reachable).
+  int bn = d.N > 32 ? 64 : 32;
+  if (!d.trans_b && d.K >= 256) bn = 32;
   const int64_t row_tiles = (d.M + BM - 1) / BM;
   while (bn > 32 && row_tiles * ((d.N + bn - 1) / bn) < 512) bn >>= 1;
+  // shallow products (K <= 128: the spatial blocks' 546 624 x 96 x 32) stream A and C once and are bound by that: the tile that
+  // pads N least wins (N = 96: three 32-column tiles instead of one 128-column tile a quarter empty)
+  if (d.K <= 128)
+    for (int cand = bn >> 1; cand >= 32; cand >>= 1)
+      if ((d.N + cand - 1) / cand * cand < (d.N + bn - 1) / bn * bn) bn = cand;
+  if (const char *e = getenv("P2C_GEMM_BN")) {        // (experiments)
+    const int v = atoi(e);
+    if (v == 32 || v == 64 || v == 128) bn = v;
+  }
   if (d.trans_b) {
     if (bn == 128) launch<128, true>(d, vec, s);
     else if (bn == 64) launch<64, true>(d, vec, s);
