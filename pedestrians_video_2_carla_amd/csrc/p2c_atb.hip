@@ -50,7 +50,10 @@ __device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*r
     return c < limit ? p[off] : ((one_ok && c == limit) ? 1.f : 0.f);
   };
   f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-  constexpr int U = 4;
+#ifndef P2C_ATB_U
+#define P2C_ATB_U 4
+#endif
+  constexpr int U = P2C_ATB_U;
   for (int64_t k = k0; k < kend; k += 4 * U) {
     f32x2 av[U], bv[U];
 #pragma unroll

@@ -243,20 +243,46 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
       }
   }
 }
-__global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
-  const int64_t total = (int64_t)d.M * d.N;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float v = 0.f;
-    for (int s = 0; s < d.slices; ++s) v += d.ws[(int64_t)s * total + i];
-    float *o = d.c + (i / d.N) * d.ldc + (i % d.N);
-    *o = d.accumulate ? *o + v : v;
+// Slabs added in a FIXED order (bitwise reproducible): a workgroup owns 32 outputs, thread (part p, output i) adds slices p,
+// p + 8, ... in that order, eight loads in flight, and the eight parts of an output meet in LDS in part order. (A skinny dW from
+// 546 624 rows has ~1 000 slices: one thread walking them one after the other is ~1 000 dependent round trips, 1.2 ms.)
+__device__ __forceinline__ float tn_slab_sum(const float *ws, int64_t stride, int64_t i, int slices, int part) {
+  float v = 0.f;
+  int s = part;
+  for (; s + 56 < slices; s += 64) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = ws[(int64_t)(s + 8 * u) * stride + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
   }
-  if (d.bias) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.M; i += (int64_t)gridDim.x * blockDim.x) {
-      float v = 0.f;
-      for (int s = 0; s < d.slices; ++s) v += d.ws_bias[(int64_t)s * d.M + i];
-      d.bias[i] = d.bias_accumulate ? d.bias[i] + v : v;
+  for (; s < slices; s += 8) v += ws[(int64_t)s * stride + i];
+  return v;
+}
+__global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
+  __shared__ float red[8][33];
+  const int64_t total = (int64_t)d.M * d.N, n_all = total + (d.bias ? d.M : 0);
+  const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < n_all; base += (int64_t)gridDim.x * 32) {
+    const int64_t i = base + e;
+    float v = 0.f;
+    if (i < total) v = tn_slab_sum(d.ws, total, i, d.slices, part);
+    else if (i < n_all) v = tn_slab_sum(d.ws_bias, d.M, i - total, d.slices, part);
+    red[part][e] = v;
+    __syncthreads();
+    if (part == 0 && i < n_all) {
+      float t = red[0][e];
+#pragma unroll
+      for (int p = 1; p < 8; ++p) t += red[p][e];
+      if (i < total) {
+        float *o = d.c + (i / d.N) * d.ldc + (i % d.N);
+        *o = d.accumulate ? *o + t : t;
+      } else {
+        float *o = d.bias + (i - total);
+        *o = d.bias_accumulate ? *o + t : t;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -397,17 +423,26 @@ static int tn_bn(int N) {
 }
 static int tn_slices(int M, int N, int K) {
   using namespace p2c_gemm_impl;
-  // Every workgroup is MFMA-bound, so the launch takes as long as the busiest CU: pick the slice count whose grid fills the
-  // 256 CUs most evenly (tiles * slices close below a multiple of 256), with at least 16 k-steps per slice.
   const int bn = tn_bn(N);
   const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
-  int max_s = K / (16 * BK);
-  max_s = max_s < 1 ? 1 : (max_s > 32 ? 32 : max_s);
+  int max_s = K / (16 * BK);                             // at least 16 k-tiles per slice
+  max_s = max_s < 1 ? 1 : (max_s > 1024 ? 1024 : max_s);
+  if (tiles < 64) {
+    // a skinny output over very many rows (the spatial blocks' 96 x 32 from 546 624 rows) is a streaming pass over A and B:
+    // what counts is enough workgroups in flight to pull the rows in -- about four per CU
+    const int s = 1024 / tiles;
+    return s < 1 ? 1 : (s > max_s ? max_s : s);
+  }
+  // Otherwise every workgroup is MFMA-bound and the launch takes as long as the busiest CU: the slice count whose grid fills
+  // the 256 CUs most evenly (tiles * slices close below a multiple of 256), minus what a slice costs in workspace traffic
+  // (its slab written and read once: 8 M N bytes at ~6 TB/s against 2 M N K flop at ~100 TFLOP/s = 67 / K of the launch).
+  if (max_s > 64) max_s = 64;
+  const double per_slice = 67.0 / (double)K;
   int best = 1;
   double best_fill = 0.0;
   for (int s = 1; s <= max_s; ++s) {
     const int blocks = tiles * s, rounds = (blocks + 255) / 256;
-    const double fill = (double)blocks / (rounds * 256.0) - 0.004 * s;      // a slab costs a little workspace traffic
+    const double fill = (double)blocks / (rounds * 256.0) - per_slice * s;
     if (fill > best_fill) best_fill = fill, best = s;
   }
   return best;
@@ -445,7 +480,8 @@ extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t 
   else P2C_TN(32);
 #undef P2C_TN
   const int64_t total = (int64_t)M * N;
-  hipLaunchKernelGGL(tn_finish_kernel, dim3((unsigned)((total + 1023) / 1024 < 4096 ? (total + 1023) / 1024 : 4096)), dim3(256), 0, s, d);
+  const int64_t n_all = total + (bias_out ? M : 0);
+  hipLaunchKernelGGL(tn_finish_kernel, dim3((unsigned)((n_all + 31) / 32 < 65536 ? (n_all + 31) / 32 : 65536)), dim3(256), 0, s, d);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

@@ -1224,7 +1224,10 @@ def gemm_tn(a: Tensor, b: Tensor, out: Optional[Tensor] = None, accumulate: bool
     return (out, bias_out) if bias else out
 
 
-WIDE_LAYER = 128      # layers with both feature counts above this take the MFMA TN GEMM for dW; K12 (exact-order VALU) below
+WIDE_LAYER = 128      # layers with both feature counts above this take the MFMA TN GEMM (K16) for dW ...
+LONG_ROWS = 65536     # ... and so do layers with >= 64 outputs over this many rows (PoseTransformer's spatial blocks: 96 x 32 from
+                      # 546 624 rows: 189 -> 68 us, 64 x 32: 117 -> 65; K12's extra column of ones doubles its tiles when the
+                      # input width is a multiple of 32). 32 x 32 and 32 x 64 stay with K12 (68 / 81 us against 64 / 95)
 
 
 def weight_grad(gy: Tensor, x: Tensor, w: Tensor, b: Optional[Tensor], scale: Optional[Tensor] = None, rows_per_scale: int = 1):
@@ -1235,7 +1238,7 @@ def weight_grad(gy: Tensor, x: Tensor, w: Tensor, b: Optional[Tensor], scale: Op
     sb = _sink(b) if (b is not None and sw is not None) else None
     if b is not None and sb is None:
         sw = None                                  # one accumulate flag for both: either both sinks or neither
-    fn = gemm_tn if (gy.shape[0] > 0 and gy.shape[1] > WIDE_LAYER and x.shape[1] > WIDE_LAYER) else atb
+    fn = gemm_tn if (gy.shape[0] > 0 and ((gy.shape[1] > WIDE_LAYER and x.shape[1] > WIDE_LAYER) or (gy.shape[0] >= LONG_ROWS and gy.shape[1] >= 64))) else atb
     res = fn(gy, x, bias=b is not None, out=sw, bias_out=sb, accumulate=sw is not None, a_scale=scale,
              rows_per_scale=rows_per_scale)
     gw, gb = res if isinstance(res, tuple) else (res, None)
