@@ -693,8 +693,11 @@ def main():
 
     if rank != 0:
         if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+            dist.barrier()                    # rank 0's last barrier; then out without RCCL's teardown (see the end of main)
+            torch.cuda.synchronize()
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         return
 
     global_batch = args.batch_size * world
@@ -786,8 +789,14 @@ def main():
         result['cpu_baseline'] = cpu_baseline(args.batch_size, args.cpu_seconds)
     print(json.dumps(result), flush=True)
     if world > 1:
+        # every rank has finished; leave WITHOUT tearing the communicator down: destroy_process_group with a captured graph that
+        # holds the collective aborted the interpreter once in a while inside RCCL's teardown (tests/test_ddp_gpu.py), and a rank
+        # that dies after the line is printed would still fail the launcher
         dist.barrier()
-        dist.destroy_process_group()
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':
