@@ -59,11 +59,12 @@ struct SlabRegs {
   f32x4 v[4];
 };
 template <bool VEC>
-__device__ __forceinline__ void load_rows(const float *base, int64_t ld, int row0, int n_rows, int k0, int K, SlabRegs &r, int rows_in_tile) {
-  const int kp = ((int)threadIdx.x & 7) * 4, k = k0 + kp;
+__device__ __forceinline__ void load_rows(const float *base, int64_t ld, int row0, int n_rows, int k0, int K, SlabRegs &r, int rows_in_tile,
+                                          int tid) {
+  const int kp = (tid & 7) * 4, k = k0 + kp;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = ((int)threadIdx.x >> 3) + 32 * i;
+    const int row = (tid >> 3) + 32 * i;
     const bool row_ok = row < rows_in_tile && row0 + row < n_rows;
     const float *p = base + (int64_t)(row0 + (row_ok ? row : 0)) * ld + k;
     if (VEC) {
@@ -75,11 +76,11 @@ __device__ __forceinline__ void load_rows(const float *base, int64_t ld, int row
   }
 }
 // ... into the k-major LDS slab [k][row] (pitch `ld` odd: the 64 lanes of a store -- 8 rows x 8 k-pieces -- fall two per bank)
-__device__ __forceinline__ void store_rows_transposed(float *slab, int ld, const SlabRegs &r, int rows_in_tile) {
-  const int kp = ((int)threadIdx.x & 7) * 4;
+__device__ __forceinline__ void store_rows_transposed(float *slab, int ld, const SlabRegs &r, int rows_in_tile, int tid) {
+  const int kp = (tid & 7) * 4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int row = ((int)threadIdx.x >> 3) + 32 * i;
+    const int row = (tid >> 3) + 32 * i;
     if (row < rows_in_tile) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) slab[(kp + e) * ld + row] = r.v[i][e];
@@ -95,15 +96,15 @@ template <int W>
 struct KnMap {
   static constexpr int PIECES = BK * W / 4 / NTH;        // pieces per thread: 4 / 2 / 1
   static constexpr int PPR = W / 4;                      // pieces per k-row
-  __device__ static __forceinline__ int row(int i) { return ((int)threadIdx.x + i * NTH) / PPR; }
-  __device__ static __forceinline__ int col(int i) { return (((int)threadIdx.x + i * NTH) % PPR) * 4; }
+  __device__ static __forceinline__ int row(int i, int tid) { return (tid + i * NTH) / PPR; }
+  __device__ static __forceinline__ int col(int i, int tid) { return ((tid + i * NTH) % PPR) * 4; }
 };
 template <int W, bool VEC>
-__device__ __forceinline__ void load_kn(const float *base, int64_t ld, int k0, int K, int n0, int N, SlabRegs &r) {
+__device__ __forceinline__ void load_kn(const float *base, int64_t ld, int k0, int K, int n0, int N, SlabRegs &r, int tid) {
   using M = KnMap<W>;
 #pragma unroll
   for (int i = 0; i < M::PIECES; ++i) {
-    const int k = k0 + M::row(i), n = n0 + M::col(i);
+    const int k = k0 + M::row(i, tid), n = n0 + M::col(i, tid);
     const bool k_ok = k < K;
     const float *p = base + (int64_t)(k_ok ? k : 0) * ld + n;
     if (VEC) {
@@ -115,10 +116,10 @@ __device__ __forceinline__ void load_kn(const float *base, int64_t ld, int k0, i
   }
 }
 template <int W>
-__device__ __forceinline__ void store_kn(float *slab, int ld, const SlabRegs &r) {
+__device__ __forceinline__ void store_kn(float *slab, int ld, const SlabRegs &r, int tid) {
   using M = KnMap<W>;
 #pragma unroll
-  for (int i = 0; i < M::PIECES; ++i) *reinterpret_cast<f32x4 *>(slab + M::row(i) * ld + M::col(i)) = r.v[i];
+  for (int i = 0; i < M::PIECES; ++i) *reinterpret_cast<f32x4 *>(slab + M::row(i, tid) * ld + M::col(i, tid)) = r.v[i];
 }
 
 // Workgroups are dealt to the eight XCDs round-robin by their linear id, and every XCD has its own L2: with tile = id, the
@@ -175,19 +176,19 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
   const bool sums = d.bias && tn == 0 && (int)threadIdx.x < BM;
   float colsum = 0.f;
   auto fetch = [&](int kt) {
-    load_kn<BM, VEC>(d.a, d.lda, k_begin + kt * BK, k_end, m0, d.M, ra);
+    load_kn<BM, VEC>(d.a, d.lda, k_begin + kt * BK, k_end, m0, d.M, ra, (int)threadIdx.x);
     if (d.row_scale) {
 #pragma unroll
       for (int i = 0; i < KnMap<BM>::PIECES; ++i) {
-        const int k = k_begin + kt * BK + KnMap<BM>::row(i);
+        const int k = k_begin + kt * BK + KnMap<BM>::row(i, (int)threadIdx.x);
         ra.v[i] *= k < k_end ? d.row_scale[k / d.rows_per_scale] : 0.f;
       }
     }
-    load_kn<BN, VEC>(d.b, d.ldb, k_begin + kt * BK, k_end, n0, d.N, rb);
+    load_kn<BN, VEC>(d.b, d.ldb, k_begin + kt * BK, k_end, n0, d.N, rb, (int)threadIdx.x);
   };
   auto commit = [&]() {
-    store_kn<BM>(As, BM + 4, ra);
-    store_kn<BN>(Bs, BN + 4, rb);
+    store_kn<BM>(As, BM + 4, ra, (int)threadIdx.x);
+    store_kn<BN>(Bs, BN + 4, rb, (int)threadIdx.x);
   };
   if (nk > 0) {
     fetch(0);
@@ -286,6 +287,35 @@ __global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
   }
 }
 
+// ---- epilogue of one wave's TM x TN accumulator tiles: C/D layout of the 32 x 32 tile: column = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const p2c_gemm_desc &d, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int li, int lk) {
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    const int n = n0 + (wn * TN + b) * 32 + li;
+    if (n >= d.N) continue;
+    const float bias = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (m >= d.M) continue;
+        float v = acc[a][b][r] + bias;
+        if (d.act == 1) {
+          if (d.aux_out) d.aux_out[(int64_t)m * d.ldaux + n] = v;
+          v = gelu(v);
+        } else if (d.act == 2) {
+          v *= gelu_grad(d.aux[(int64_t)m * d.ldaux + n]);
+        }
+        if (d.row_scale) v *= d.row_scale[m / d.rows_per_scale];
+        if (d.residual) v += d.residual[(int64_t)m * d.ldr + n];
+        d.c[(int64_t)m * d.ldc + n] = v;
+      }
+  }
+}
+
 // (An LDS double-buffered main loop -- the wave stores k-tile kt + 1 into the other slab pair and requests kt + 2 in the middle of
 // the MFMAs of kt, one barrier per k-tile -- was measured twice and is slower: 945 vs 846 us at 21 024 x 2 496 x 832. LDS
 // operations of a wave complete in order, so the operand reads behind the 32 stores wait for them anyway, and 66 KB of slabs
@@ -319,16 +349,16 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
   SlabRegs ra, rb;
   const int nk = (d.K + BK - 1) / BK;
   auto fetch = [&](int kt) {
-    load_rows<VEC>(d.a, d.lda, m0, d.M, kt * BK, d.K, ra, BM);
-    if (TRANS_B) load_rows<VEC>(d.b, d.ldb, n0, d.N, kt * BK, d.K, rb, BN);
-    else load_kn<BN, VEC>(d.b, d.ldb, kt * BK, d.K, n0, d.N, rb);
+    load_rows<VEC>(d.a, d.lda, m0, d.M, kt * BK, d.K, ra, BM, (int)threadIdx.x);
+    if (TRANS_B) load_rows<VEC>(d.b, d.ldb, n0, d.N, kt * BK, d.K, rb, BN, (int)threadIdx.x);
+    else load_kn<BN, VEC>(d.b, d.ldb, kt * BK, d.K, n0, d.N, rb, (int)threadIdx.x);
   };
   auto commit = [&]() {
-    store_rows_transposed(As, LDA, ra, BM);
+    store_rows_transposed(As, LDA, ra, BM, (int)threadIdx.x);
     if (TRANS_B) {
-      store_rows_transposed(Bs, ldb_s, rb, BN);
+      store_rows_transposed(Bs, ldb_s, rb, BN, (int)threadIdx.x);
     } else {
-      store_kn<BN>(Bs, ldb_s, rb);
+      store_kn<BN>(Bs, ldb_s, rb, (int)threadIdx.x);
     }
   };
   GT(0);
@@ -377,36 +407,115 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
   }
   GT(60);
 
-  // ---- epilogue: C/D layout of the 32 x 32 tile: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----
-#pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int n = n0 + (wn * TN + b) * 32 + li;
-    if (n >= d.N) continue;
-    const float bias = d.bias ? d.bias[n] : 0.f;
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m >= d.M) continue;
-        float v = acc[a][b][r] + bias;
-        if (d.act == 1) {
-          if (d.aux_out) d.aux_out[(int64_t)m * d.ldaux + n] = v;
-          v = gelu(v);
-        } else if (d.act == 2) {
-          v *= gelu_grad(d.aux[(int64_t)m * d.ldaux + n]);
-        }
-        if (d.row_scale) v *= d.row_scale[m / d.rows_per_scale];
-        if (d.residual) v += d.residual[(int64_t)m * d.ldr + n];
-        d.c[(int64_t)m * d.ldc + n] = v;
-      }
-  }
+  epilogue<TM, TN>(d, acc, m0, n0, wm, wn, li, lk);
   GT(61);
+}
+
+// ---- producer / consumer form (round 3 experiment, OFF by default: P2C_GEMM_WS=1): eight waves per workgroup. Waves 4..7 only move data -- global loads of k-tile kt + 2
+// into registers, the registers of kt + 1 into the OTHER slab pair -- and waves 0..3 only multiply out of the current pair; one
+// workgroup barrier per k-tile hands a pair over. In the four-wave kernel above every wave does both jobs in turn and the
+// workgroup spends more than half of a k-tile outside its MFMA phase (tools/gemmtrace.py), which co-resident workgroups do not
+// cover for each other; a wave's own LDS stores cannot overlap its own operand reads either (in-order LDS queue: the measured
+// double-buffered variant). Here the stores and the operand reads belong to different waves.
+// Measured: correct (tests/test_gemm_gpu.py under P2C_GEMM_WS=1) and NOT faster -- 21 024 x 2 496 x 832 NT 888 vs 868 us, NN 832 x
+// 2 496: 826..851 vs 759 us, cfg5 38.1..38.8 vs 37.0 ms -- with one or with three k-tiles of load look-ahead: neither the load
+// latency nor the store / barrier phases of the four-wave kernel are what holds the MFMA rate at ~65 % of peak.
+template <int BN, bool TRANS_B, bool VEC>
+__global__ __launch_bounds__(2 * NTH, 2) void gemm_ws_kernel(const p2c_gemm_desc d) {
+  constexpr int WM = (BN == 128) ? 2 : 4, TM = (BN == 128) ? 2 : 1, TN = (BN == 128) ? 2 : BN / 32;
+  constexpr int LDB = BN + 1, ldb_s = TRANS_B ? LDB : BN + 4;
+  constexpr int A_SZ = (BK * LDA + 3) & ~3, B_SZ = BK * (BN + 4);
+  __shared__ __attribute__((aligned(16))) float As2[2 * A_SZ];
+  __shared__ __attribute__((aligned(16))) float Bs2[2 * B_SZ];
+  const int n_tiles = (d.N + BN - 1) / BN;
+  const int id = xcd_tile((int)blockIdx.x, ((d.M + BM - 1) / BM) * n_tiles);
+  if (id >= ((d.M + BM - 1) / BM) * n_tiles) return;
+  const int tm = id / n_tiles, tn = id % n_tiles;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = (d.K + BK - 1) / BK;
+  const bool producer = threadIdx.x >= NTH;                 // (wave-uniform)
+  if (producer) {
+    const int tid = (int)threadIdx.x - NTH;
+    // k-tile j travels through register set j % D: its loads are issued D k-tiles before it is stored to LDS (a k-tile of the
+    // consumers is only ~2-4 k cycles: one k-tile of look-ahead is less than a loaded memory round trip)
+    constexpr int D = 3;
+    SlabRegs ra[D], rb[D];
+    auto fetch = [&](int kt, int slot) {
+      load_rows<VEC>(d.a, d.lda, m0, d.M, kt * BK, d.K, ra[slot], BM, tid);
+      if (TRANS_B) load_rows<VEC>(d.b, d.ldb, n0, d.N, kt * BK, d.K, rb[slot], BN, tid);
+      else load_kn<BN, VEC>(d.b, d.ldb, kt * BK, d.K, n0, d.N, rb[slot], tid);
+    };
+    auto commit = [&](int buf, int slot) {
+      store_rows_transposed(As2 + buf * A_SZ, LDA, ra[slot], BM, tid);
+      if (TRANS_B) store_rows_transposed(Bs2 + buf * B_SZ, ldb_s, rb[slot], BN, tid);
+      else store_kn<BN>(Bs2 + buf * B_SZ, ldb_s, rb[slot], tid);
+    };
+    fetch(0, 0);
+    commit(0, 0);
+#pragma unroll
+    for (int j = 1; j <= D; ++j)
+      if (j < nk) fetch(j, j % D);
+    __syncthreads();                                        // slab pair 0 is ready
+    for (int kt0 = 0; kt0 < nk; kt0 += D) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {                         // (unrolled: the register set of a k-tile is a compile-time index)
+        const int kt = kt0 + u;
+        if (kt < nk) {
+          if (kt + 1 < nk) {
+            commit((kt + 1) & 1, (u + 1) % D);              // (the consumers left this pair at the previous barrier)
+            if (kt + 1 + D < nk) fetch(kt + 1 + D, (u + 1) % D);
+          }
+          __syncthreads();
+        }
+      }
+    }
+    return;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave % WM, wn = wave / WM, li = lane & 31, lk = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const float *As = As2 + (kt & 1) * A_SZ, *Bs = Bs2 + (kt & 1) * B_SZ;
+    float af[2][TM], bf[2][TN];
+    auto frag = [&](int ks, int buf) {
+      const int k = ks * 2 + lk;
+#pragma unroll
+      for (int a = 0; a < TM; ++a) af[buf][a] = As[k * LDA + (wm * TM + a) * 32 + li];
+#pragma unroll
+      for (int b = 0; b < TN; ++b) bf[buf][b] = Bs[k * ldb_s + (wn * TN + b) * 32 + li];
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < BK / 2; ++ks) {
+      if (ks + 1 < BK / 2) frag(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][a], bf[ks & 1][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  epilogue<TM, TN>(d, acc, m0, n0, wm, wn, li, lk);
 }
 
 template <int BN, bool TRANS_B>
 static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
   const unsigned grid = xcd_grid((int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN));
+  static const int ws_mode = getenv("P2C_GEMM_WS") ? atoi(getenv("P2C_GEMM_WS")) : 0;
+  if (ws_mode && vec && d.K >= 256) {           // producer / consumer form: deep products
+    hipLaunchKernelGGL((gemm_ws_kernel<BN, TRANS_B, true>), dim3(grid), dim3(2 * NTH), 0, s, d);
+    return;
+  }
   if (vec) hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, true>), dim3(grid), dim3(NTH), 0, s, d);
   else hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, false>), dim3(grid), dim3(NTH), 0, s, d);
 }
