@@ -411,6 +411,95 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
   GT(61);
 }
 
+// ---- the same 128 x 64 tile on v_mfma_f32_16x16x4_f32 (round 3 experiment: P2C_GEMM_MI16=1): a wave's 32 x 64 block as 2 x 4
+// tiles of 16 x 16 (eight f32x4 accumulators), k advances by 4 per step: six LDS dwords feed eight MFMAs of 32 cycles. Same
+// FLOP per cycle as 32 x 32 x 2; what it tests is whether the instruction shape matters for the sustained rate (the library's
+// kernels at these shapes are built on 16 x 16 x 4). Measured: it does not -- NT 21 024 x 2 496 x 832: 904 vs 868 us, 832-wide
+// outputs 296 vs 274 us, cfg5 37.6 vs 37.0 ms. Kept as the opt-in it was measured as.
+template <bool TRANS_B, bool VEC>
+__global__ __launch_bounds__(NTH, 5) void gemm16_kernel(const p2c_gemm_desc d) {
+  constexpr int BN = 64, LDB = BN + 1, ldb_s = TRANS_B ? LDB : BN + 4;
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * (BN + 4)];
+  const int n_tiles = (d.N + BN - 1) / BN;
+  const int id = xcd_tile((int)blockIdx.x, ((d.M + BM - 1) / BM) * n_tiles);
+  if (id >= ((d.M + BM - 1) / BM) * n_tiles) return;
+  const int tm = id / n_tiles, tn = id % n_tiles, m0 = tm * BM, n0 = tn * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kg = lane >> 4;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  SlabRegs ra, rb;
+  const int nk = (d.K + BK - 1) / BK;
+  auto fetch = [&](int kt) {
+    load_rows<VEC>(d.a, d.lda, m0, d.M, kt * BK, d.K, ra, BM, (int)threadIdx.x);
+    if (TRANS_B) load_rows<VEC>(d.b, d.ldb, n0, d.N, kt * BK, d.K, rb, BN, (int)threadIdx.x);
+    else load_kn<BN, VEC>(d.b, d.ldb, kt * BK, d.K, n0, d.N, rb, (int)threadIdx.x);
+  };
+  auto commit = [&]() {
+    store_rows_transposed(As, LDA, ra, BM, (int)threadIdx.x);
+    if (TRANS_B) store_rows_transposed(Bs, ldb_s, rb, BN, (int)threadIdx.x);
+    else store_kn<BN>(Bs, ldb_s, rb, (int)threadIdx.x);
+  };
+  fetch(0);
+  commit();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) fetch(kt + 1);
+    float af[2][2], bf[2][4];
+    auto frag = [&](int ks, int buf) {
+      const int k = ks * 4 + kg;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[buf][a] = As[k * LDA + wave * 32 + a * 16 + li];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[buf][b] = Bs[k * ldb_s + b * 16 + li];
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      if (ks + 1 < BK / 4) frag(ks + 1, (ks + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][a], bf[ks & 1][b], acc[a][b], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (kt + 1 < nk) {
+      commit();
+      __syncthreads();
+    }
+  }
+  // C/D layout of the 16 x 16 tile: column = lane & 15, row = 4 (lane >> 4) + reg
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int n = n0 + b * 16 + li;
+    if (n >= d.N) continue;
+    const float bias = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wave * 32 + a * 16 + 4 * kg + r;
+        if (m >= d.M) continue;
+        float v = acc[a][b][r] + bias;
+        if (d.act == 1) {
+          if (d.aux_out) d.aux_out[(int64_t)m * d.ldaux + n] = v;
+          v = gelu(v);
+        } else if (d.act == 2) {
+          v *= gelu_grad(d.aux[(int64_t)m * d.ldaux + n]);
+        }
+        if (d.row_scale) v *= d.row_scale[m / d.rows_per_scale];
+        if (d.residual) v += d.residual[(int64_t)m * d.ldr + n];
+        d.c[(int64_t)m * d.ldc + n] = v;
+      }
+  }
+}
+
 // ---- producer / consumer form (round 3 experiment, OFF by default: P2C_GEMM_WS=1): eight waves per workgroup. Waves 4..7 only move data -- global loads of k-tile kt + 2
 // into registers, the registers of kt + 1 into the OTHER slab pair -- and waves 0..3 only multiply out of the current pair; one
 // workgroup barrier per k-tile hands a pair over. In the four-wave kernel above every wave does both jobs in turn and the
@@ -512,6 +601,11 @@ template <int BN, bool TRANS_B>
 static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
   const unsigned grid = xcd_grid((int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN));
   static const int ws_mode = getenv("P2C_GEMM_WS") ? atoi(getenv("P2C_GEMM_WS")) : 0;
+  static const int mi16 = getenv("P2C_GEMM_MI16") ? atoi(getenv("P2C_GEMM_MI16")) : 0;
+  if (mi16 && vec && BN == 64) {
+    hipLaunchKernelGGL((gemm16_kernel<TRANS_B, true>), dim3(grid), dim3(NTH), 0, s, d);
+    return;
+  }
   if (ws_mode && vec && d.K >= 256) {           // producer / consumer form: deep products
     hipLaunchKernelGGL((gemm_ws_kernel<BN, TRANS_B, true>), dim3(grid), dim3(2 * NTH), 0, s, d);
     return;
