@@ -60,7 +60,8 @@ def test_gemm_tn_matches_fp64_is_reproducible_and_accumulates(K, M, N):
     assert rel(c2, wide_a[:, 1:M + 1].double().t() @ wide_b[:, 2:N + 2].double()) < 2e-6 * math.sqrt(K) + 1e-7
 
 
-@pytest.mark.parametrize('K,M,N,per', [(9 * 500, 832, 256, 9), (26 * 300, 140, 200, 26), (26 * 300, 32, 96, 26), (64, 5, 3, 1)])
+@pytest.mark.parametrize('K,M,N,per', [(9 * 500, 832, 256, 9), (26 * 300, 140, 200, 26), (26 * 300, 32, 96, 26), (64, 5, 3, 1),
+                                       (26 * 3000, 96, 32, 26)])       # (the last: a skinny dW over many rows -> ~150 K slices)
 def test_weight_gradient_with_row_factor_and_bias_in_one_pass(K, M, N, per):
     """dW = (dy * f)^T x and db = column sums of dy * f, f per sample (K12 below 128 features, the K16 TN form above), written
     and accumulated; same bits on every call."""

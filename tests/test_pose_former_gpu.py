@@ -187,7 +187,8 @@ def test_spatial_half_once_per_frame_equals_the_per_window_model():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('S,N,C,heads,p_drop,sinks', [(40, 26, 32, 8, 0.3, False), (12, 9, 832, 8, 0.25, True), (7, 9, 160, 8, 0.0, False)])
+@pytest.mark.parametrize('S,N,C,heads,p_drop,sinks', [(40, 26, 32, 8, 0.3, False), (12, 9, 832, 8, 0.25, True), (7, 9, 160, 8, 0.0, False),
+                                                      (2600, 26, 32, 8, 0.2, True)])     # (67 600 rows: the long-row dW routing)
 def test_block_as_one_autograd_node_matches_the_same_block_in_fp64(S, N, C, heads, p_drop, sinks):
     """pose_transformer._Block through ops.transformer_block (one node: LayerNorm / GEMM / attention launches with the factor,
     residual, GELU and bias work in their epilogues, LayerNorm backward adding the residual gradient, parameter gradients added
