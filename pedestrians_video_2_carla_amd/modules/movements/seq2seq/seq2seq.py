@@ -97,8 +97,9 @@ class Decoder(nn.Module):
 
     def forward(self, x, hidden, cell):
         if _fused_ok(self.rnn, x):
+            from pedestrians_video_2_carla_amd import ops
             output, hidden, cell = _run_stack(self.rnn, x.unsqueeze(0), hidden, cell)
-            return self.fc_out(output.squeeze(0)), hidden, cell
+            return ops.dense(output.squeeze(0), self.fc_out.weight, self.fc_out.bias), hidden, cell      # (K16 / K12)
         output, (hidden, cell) = self.rnn(x.unsqueeze(0), (hidden, cell))
         return self.fc_out(output.squeeze(0)), hidden, cell
 
