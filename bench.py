@@ -295,12 +295,19 @@ def recurrence_times(device, B, T=T_FRAMES, H=64, O=52):
     keep.append(ten)
     dd = _lib.DecoderDesc()
     dd.T, dd.B, dd.H, dd.O = T, B, H, O
-    ten2 = {k: rnd(*s) for k, s in dict(k0=(B, 4 * H), c0=(B, H), k1=(B, 4 * H), c1=(B, H), w_ih0=(4 * H, O), w_ih1=(4 * H, H),
+    # the launches the step itself issues (ops.DecoderStackFunction): the frame-invariant terms k_l = b + hid_l W_hh_l^T and their
+    # gradients formed inside, the output written batch-first as well, the loss gradient read batch-first, dropout mask on
+    ten2 = {k: rnd(*s) for k, s in dict(c0=(B, H), c1=(B, H), w_ih0=(4 * H, O), w_ih1=(4 * H, H),
                                         w_fc=(O, H), b_fc=(O,), out=(T, B, O), acts0=(T, B, 4 * H), acts1=(T, B, 4 * H),
-                                        h0d=(T, B, H), h1=(T, B, H), g_out=(T, B, O), g_gates0=(T, B, 4 * H),
-                                        g_gates1=(T, B, 4 * H), g_outtot=(T, B, O), g_c0=(B, H), g_c1=(B, H)).items()}
+                                        h0d=(T, B, H), h1=(T, B, H), g_out=(B, T, O), g_gates0=(T, B, 4 * H),
+                                        g_gates1=(T, B, 4 * H), g_outtot=(T, B, O), g_c0=(B, H), g_c1=(B, H),
+                                        hid0=(B, H), hid1=(B, H), w_hh0=(4 * H, H), w_hh1=(4 * H, H), b0a=(4 * H,), b0b=(4 * H,),
+                                        b1a=(4 * H,), b1b=(4 * H,), kw0=(B, 4 * H), kw1=(B, 4 * H), out_bt=(B, T, O),
+                                        g_k0=(B, 4 * H), g_k1=(B, 4 * H), g_hid0=(B, H), g_hid1=(B, H)).items()}
+    ten2['drop'] = (torch.rand(T, B, H, generator=g, **f32) > 0.2).float() / 0.8
     for k, v in ten2.items():
         setattr(dd, k, v.data_ptr())
+    dd.g_out_bt = 1
     keep.append(ten2)
     out = {}
     stream = torch.cuda.Stream(device=device)
@@ -311,7 +318,7 @@ def recurrence_times(device, B, T=T_FRAMES, H=64, O=52):
         out['decoder_loop_fwd (K7c)'] = _graph_us(lambda: _lib.check(lib.p2c_decoder_fwd(ctypes.byref(dd), s), 'dec fwd'), stream)
         out['decoder_loop_bwd (K7c)'] = _graph_us(lambda: _lib.check(lib.p2c_decoder_bwd(ctypes.byref(dd), s), 'dec bwd'), stream)
     rec = 2 * T * B * H * 4 * H                                        # h_{t-1} W_hh^T for all t
-    dec = 2 * T * B * (O * 4 * H + H * 4 * H + H * O)                  # W_ih0 x_t, W_ih1 h0_t, fc_out h1_t
+    dec = 2 * T * B * (O * 4 * H + H * 4 * H + H * O) + 2 * 2 * B * H * 4 * H     # W_ih0 x_t, W_ih1 h0_t, fc_out h1_t; the two k_l
     flops = {'lstm_rec_fwd (K7b, one layer)': rec, 'lstm_rec_bwd (K7b, one layer)': rec,
              'decoder_loop_fwd (K7c)': dec, 'decoder_loop_bwd (K7c)': dec}
     return out, flops
