@@ -523,6 +523,10 @@ P2C_API int p2c_layernorm_bwd(const float *x, const float *gamma, const float *m
                       const float *gx_add, float *gx, float *g_gamma, float *g_beta, int32_t accumulate, float *partials,
                       int64_t rows, int32_t D, void *stream);
 
+/* Testing aid (no counterpart in the reference): fills the LDS of every CU with NaN bit patterns, so that a kernel reading LDS it
+ * never wrote fails deterministically instead of by what the previous workgroup left behind. One launch on `stream`. */
+P2C_API int p2c_debug_poison_lds(void *stream);
+
 /* ---- dense layers on fp32 MFMA with a fused epilogue (K16, csrc/p2c_gemm.hip) -----------------------------------------------------
  * C (M, N) = epilogue(A (M, K) * op(B)): trans_b = 1: B is (N, K) row-major -- y = x W^T, the forward of torch.nn.Linear as the
  * reference's model plugins use it (PoseTransformer qkv / proj / fc1 / fc2: modules/movements/pose_former/pose_former.py:62-76;

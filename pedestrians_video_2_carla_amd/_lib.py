@@ -118,6 +118,7 @@ SYMBOLS = {
     'p2c_pose_head_fwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp]),
     'p2c_pose_head_fwd_launch': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.c_int32, _vp]),
     'p2c_gemm': (ctypes.c_int, [ctypes.POINTER(GemmDesc), _vp]),
+    'p2c_debug_poison_lds': (ctypes.c_int, [_vp]),
     'p2c_gemm_tn_workspace_floats': (_i64, [_i32, _i32, _i32]),
     'p2c_gemm_tn': (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     'p2c_pose_head_bwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.POINTER(_vp * 3), _vp, _vp, _vp, _vp, _vp]),
@@ -213,8 +214,33 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args
+        if os.environ.get('P2C_POISON_LDS') == '1':
+            handle = _PoisonedLib(handle)
         _lib = handle
     return _lib
+
+
+class _PoisonedLib:
+    """Test audit (P2C_POISON_LDS=1): every launching entry point -- int result, stream as its last argument -- is preceded by
+    p2c_debug_poison_lds on that stream, so a kernel that reads LDS it never wrote returns NaN instead of whatever the previous
+    workgroup left behind. Run the GPU suite once under it after touching a kernel's LDS layout."""
+
+    def __init__(self, handle):
+        self._h = handle
+        self._wrap = {n for n, (res, args) in SYMBOLS.items()
+                      if res is ctypes.c_int and args and args[-1] is _vp and not n.startswith('p2c_debug')
+                      and n not in ('p2c_graph_node_counts',)}
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        if name not in self._wrap:
+            return fn
+        poison = self._h.p2c_debug_poison_lds
+
+        def call(*a):
+            poison(a[-1])
+            return fn(*a)
+        return call
 
 
 def check(rc: int, what: str):

@@ -501,3 +501,26 @@ extern "C" int p2c_graph_node_counts(void *graph, int32_t *n_total, int32_t *n_k
   delete[] nodes;
   return e == hipSuccess ? 0 : (int)e;
 }
+
+
+// ---- testing aid: fill the LDS of every CU with NaN bit patterns ----------------------------------------------------------------
+// LDS keeps what the last workgroup on the CU left in it. A kernel that reads LDS it never wrote works or fails by that
+// accident (tests/test_pose_head_gpu.py: a stale NaN behind the chain-lane backward's rotation image surfaced as an intermittent
+// NaN in grad_y). After this launch every uninitialised LDS read returns NaN.
+namespace p2c_aux {
+__global__ __launch_bounds__(1024) void poison_lds_kernel(int n_floats) {
+  extern __shared__ float poison[];
+  for (int i = threadIdx.x; i < n_floats; i += blockDim.x) poison[i] = __builtin_nanf("");
+  __syncthreads();
+  if (poison[(threadIdx.x * 37) % n_floats] == 0.f) __builtin_trap();      // (keeps the stores alive)
+}
+}  // namespace p2c_aux
+
+extern "C" int p2c_debug_poison_lds(void *stream) {
+  const int bytes = 160 * 1024;
+  hipError_t e = hipFuncSetAttribute((const void *)p2c_aux::poison_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(p2c_aux::poison_lds_kernel, dim3(256 * 8), dim3(1024), bytes, (hipStream_t)stream, bytes / 4);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

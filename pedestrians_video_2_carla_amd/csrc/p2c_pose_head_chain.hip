@@ -544,8 +544,13 @@ __device__ __forceinline__ void load_rotations(const p2c_pose_head_desc &d, cons
 #pragma unroll
   for (int k = 0; k < NS; ++k)
 #pragma unroll
-    for (int i = 0; i < 9; ++i) R[k].m[i] = img[at + k * 9 + i];       // (steps a lane does not own: the next bones' values, unused)
+    for (int i = 0; i < 9; ++i) R[k].m[i] = img[at + k * 9 + i];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // Steps a lane does not own read the next bones' values -- and, for the left toe end of a wave's last clip, LDS BEHIND the 7 488
+  // bytes that were fetched: whatever an earlier kernel left there. Those steps carry no force, but 0 x NaN is NaN: a stale NaN
+  // travelled through the chain-local FK into F x x of the lane's OWN bone (intermittent NaN in grad_y of bone 25). Identity there.
+#pragma unroll
+  for (int k = 0; k < NS; ++k) R[k] = sel(L.valid[k], R[k], identity());
 }
 
 // =====================================================================================================================
@@ -680,7 +685,7 @@ __global__ __launch_bounds__(256, P2C_CHAIN_BWD_WAVES) void pose_head_chain_bwd(
     fk_base(L, Al, xl, BA, BX);
     V3 x[NS], F[NS];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) x[k] = vmul(xl[k], BA) + BX;
+    for (int k = 0; k < NS; ++k) x[k] = sel(L.valid[k], vmul(xl[k], BA) + BX, v3(0.f, 0.f, 0.f));   // (unowned steps: a finite point)
     head4<true>(d, L, t, x, in, acc, coef2, coef3, F);
 
     // ---- subtree sums of F and F x x: suffix sums inside the chain, chain totals to the trunk, toe ends to their legs ----

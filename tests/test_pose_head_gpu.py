@@ -342,6 +342,38 @@ def test_gradient_through_absolute_rotations(kind):
     close(yd.grad, y64.grad, 'grad through rotations')
 
 
+@pytest.mark.parametrize('B,T,upstream', [(64, 16, (1.0, 0.0, 0.0)), (8, 5, (0.0, 0.0, 1.0)), (21, 16, (0.0, 1.0, 0.0))])
+def test_kernels_do_not_depend_on_stale_lds(B, T, upstream):
+    """Every CU's LDS is filled with NaN patterns right before the launches (p2c_debug_poison_lds): a kernel that reads LDS it
+    never wrote then produces NaN deterministically. Regression for the chain-lane backward: the left toe end of a wavefront's
+    last clip read its unowned steps' rotations from behind the fetched image, and 0 x NaN reached the gradient of its own bone --
+    an intermittent NaN that depended on what the previous workgroup on the CU had left. All kernel variants (autouse fixture)."""
+    import ctypes
+    from pedestrians_video_2_carla_amd import _lib
+    from pedestrians_video_2_carla_amd.ops import PoseHeadSpec
+    from pedestrians_video_2_carla_amd import ops
+    y, st, gt2, gt3, _ = _random_case(B, T, seed=B * 100 + T)
+    lib, d = _lib.lib(), dev()
+
+    def poison():
+        _lib.check(lib.p2c_debug_poison_lds(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'poison')
+    which = [i for i, u in enumerate(upstream) if u != 0][0]
+    for gt2d, gt3d in ((gt2, gt3), (None, gt3), (gt2, None)):
+        if (gt2d is None and which != 1) or (gt3d is None and which != 0):
+            continue
+        yd = y.float().to(d).requires_grad_(True)
+        mv = lambda t: None if t is None else t.float().to(d)          # noqa: E731
+        poison()                                                       # ... before the forward launches
+        losses, _ = ops.pose_head(yd, PoseHeadSpec(kind='pose_changes_6d'), st.to(d).int(), None, None, mv(gt2d), mv(gt3d), ())
+        poison()                                                       # ... and again before the backward launch
+        losses[which].backward()
+        o, gref = run_oracle(y, 'pose_changes_6d', st, gt2d=gt2d, gt3d=gt3d, upstream=upstream)
+        _, g32 = run_oracle(y, 'pose_changes_6d', st, gt2d=gt2d, gt3d=gt3d, upstream=upstream, dtype=torch.float32)
+        assert torch.isfinite(yd.grad).all(), 'NaN / Inf in grad_y: a kernel read LDS it had not written'
+        close(losses[which], o[('loc_2d', 'loc_3d', 'loc_2d_3d')[which]], 'loss')
+        close(yd.grad, gref, f'grad {upstream}', fp32_ref=g32)
+
+
 @pytest.mark.parametrize('kind', ['pose_changes_6d', 'relative_rot_6d'])
 @pytest.mark.parametrize('body25,sl', [(False, (None, None)), (True, (2, 6))])
 def test_rot_3d_fused_into_the_lean_pose_head(kind, body25, sl, kernel_variant):
