@@ -80,12 +80,26 @@ class PoseFormer(MovementsModel):
             windows = x.unfold(1, self.__receptive, 1)[:, :n_windows].permute(0, 1, 4, 2, 3)
             centre = inner(windows.reshape(B * n_windows, self.__receptive, *x.shape[2:]))
         centre = centre.reshape(B, n_windows, self.__n_out, self.__out_features)
-        # frame f receives the prediction of the LAST window i with i+shift <= f < i+shift+receptive (overwrite order)
-        frames = torch.arange(T, device=x.device)
-        last = torch.clamp(frames - self.__shift, max=n_windows - 1)
-        outputs = centre[:, last.clamp(min=0)]
-        valid = (frames >= self.__shift) & (frames - self.__shift - (self.__receptive - 1) <= n_windows - 1)
-        return outputs * valid.view(1, T, 1, 1).to(outputs.dtype)
+        # frame f receives the prediction of the LAST window i with i+shift <= f < i+shift+receptive (overwrite order): window
+        # f - shift for the frames up to the last window's centre, the last window for the (receptive - 1) frames behind it, zero
+        # before the first centre and beyond the last window's reach (reference pose_former.py:117-127). Written as a
+        # concatenation of slices: the gather ``centre[:, index]`` of the first version has an index_put with a device sort and
+        # scratch buffers in its backward, the kind of framework op a captured step cannot rely on here (ops.py, "broadcast
+        # parameters"); slices and concatenation are element-wise both ways.
+        shift, W = self.__shift, n_windows
+        n_head = min(shift, T)
+        n_body = max(0, min(W, T - shift))
+        n_tail = max(0, min(T - shift - W, self.__receptive - 1))
+        n_rest = T - n_head - n_body - n_tail
+        parts = []
+        if n_head:
+            parts.append(centre.new_zeros(B, n_head, self.__n_out, self.__out_features))
+        if n_body:
+            parts.append(centre[:, :n_body])
+        parts.extend([centre[:, W - 1:W]] * n_tail)
+        if n_rest:
+            parts.append(centre.new_zeros(B, n_rest, self.__n_out, self.__out_features))
+        return torch.cat(parts, dim=1)
 
     def configure_optimizers(self):
         optimizer = torch.optim.AdamW(self.parameters(), lr=0.0004, weight_decay=0.1)

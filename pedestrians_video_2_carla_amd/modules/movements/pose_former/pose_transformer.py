@@ -35,13 +35,6 @@ def _linear(layer: nn.Linear, x, scale=None, residual=None):
     gradient, K12 (p2c_atb) for the weight + bias gradient. The spatial blocks contract 546 624 rows (cfg5: 2 336 windows x 9
     frames x 26 joints) into 32..96 x 32..64 outputs -- pure streaming; the temporal blocks (21 024 rows, 832 x 2 496 outputs)
     are the step's 2.8 TFLOP."""
-    if layer.in_features <= 4 and x.is_cuda:
-        # Linear(2, E) over 546 624 keypoints: as a GEMM with K = 2 the library took 3.0 ms; as E-wide multiply-adds it is one
-        # streaming pass (and its weight gradient two row reductions)
-        y = layer.bias if layer.bias is not None else 0.0
-        for c in range(layer.in_features):
-            y = y + x[..., c:c + 1] * layer.weight[:, c]
-        return y
     if _fused(x):
         from pedestrians_video_2_carla_amd import ops
         shp = x.shape
@@ -53,6 +46,15 @@ def _linear(layer: nn.Linear, x, scale=None, residual=None):
     if scale is not None:
         y = y * scale.view(-1, *([1] * (y.ndim - 1)))
     return y if residual is None else y + residual
+
+
+def _add_param(x, p):
+    """``x + p`` for a learned p broadcast over the batch; fp32 on the GPU through ``ops.add_row_parameter`` (its gradient is a
+    K12 column sum: a framework reduction in a captured backward replays wrong on this stack, see ops.py)."""
+    if _fused(x):
+        from pedestrians_video_2_carla_amd import ops
+        return ops.add_row_parameter(x, p)
+    return x + p
 
 
 def _norm(layer: nn.LayerNorm, x):
@@ -226,7 +228,7 @@ class PoseTransformer(nn.Module):
         return self._forward_clip(x, n_windows)
 
     def _spatial(self, frames):
-        t = _linear(self.Spatial_patch_to_embedding, frames) + self.Spatial_pos_embed
+        t = _add_param(_linear(self.Spatial_patch_to_embedding, frames), self.Spatial_pos_embed)
         t = self.pos_drop(t)
         for blk in self.Spatial_blocks:
             t = blk(t)
@@ -236,12 +238,12 @@ class PoseTransformer(nn.Module):
         B, T, J, C = x.shape
         feats = self._spatial(x.reshape(B * T, J, C)).reshape(B, T, -1)                     # (B, T, J*E), once per frame
         t = feats.unfold(1, self.num_frame, 1)[:, :n_windows].permute(0, 1, 3, 2)            # (B, W, F, J*E) view
-        t = t.reshape(B * n_windows, self.num_frame, -1) + self.Temporal_pos_embed
+        t = _add_param(t.reshape(B * n_windows, self.num_frame, -1), self.Temporal_pos_embed)
         return self._temporal(t, J)
 
     def _forward(self, x):
         B, Fr, J, C = x.shape
-        t = self._spatial(x.reshape(B * Fr, J, C)).reshape(B, Fr, -1) + self.Temporal_pos_embed
+        t = _add_param(self._spatial(x.reshape(B * Fr, J, C)).reshape(B, Fr, -1), self.Temporal_pos_embed)
         return self._temporal(t, J)
 
     def _temporal(self, t, J):
@@ -250,8 +252,13 @@ class PoseTransformer(nn.Module):
         for blk in self.blocks:
             t = blk(t)
         # the learned mean over the frames, Conv1d(F, 1, kernel 1), written as the weighted sum it is (the convolution library
-        # spends seconds searching kernels for this shape at the first step and then runs four launches for it)
+        # spends seconds searching kernels for this shape at the first step and then runs four launches for it); fp32 on the GPU its
+        # backward runs through K12 (ops.frame_mean), not through framework reductions
         wm = self.weighted_mean
-        # (multiply + sum, not einsum: its weight gradient would be a 9 x 1 GEMM over 1.9 M rows -- 3.0 ms in the library)
-        t = ((_norm(self.Temporal_norm, t) * wm.weight.view(1, -1, 1)).sum(1) + wm.bias).unsqueeze(1)           # (B, 1, J*E)
+        n = _norm(self.Temporal_norm, t)
+        if _fused(n):
+            from pedestrians_video_2_carla_amd import ops
+            t = ops.frame_mean(n, wm.weight, wm.bias).unsqueeze(1)                                              # (B, 1, J*E)
+        else:
+            t = ((n * wm.weight.view(1, -1, 1)).sum(1) + wm.bias).unsqueeze(1)
         return _linear(self.head[1], _norm(self.head[0], t)).view(B, 1, J, 3)

@@ -1725,6 +1725,93 @@ def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# broadcast parameters without framework reductions in the backward
+# ----------------------------------------------------------------------------------------------------------------------
+# Why these exist: on this stack (PyTorch 2.10 / ROCm 7.0) a captured step whose backward holds one of ATen's multi-block
+# reductions -- the gradient of any parameter that is broadcast over the batch: position embeddings, a frame-mean weight, a bias
+# added outside a GEMM -- replays WRONG once the allocator has handed out other memory in between: the reduction's scratch
+# buffers come from the raw allocator API and do not stay with the graph's private pool (tools/graph_reduce_repro.py: pure
+# torch, errors of 1e3..1e7 from the second replay on; found because the NaN-filled-torch.empty audit of tests/conftest.py made
+# cfg5's replayed step diverge from the eager one). Inside a trainer's captured step every reduction over rows therefore runs
+# through the build's own kernels (K12: fixed-order column sums).
+def column_sums(a: Tensor) -> Tensor:
+    """Sum of the rows of a 2-D device tensor (K12's bias column: fixed summation order, no framework reduction)."""
+    a = _require_device(a, 'rows')
+    return atb(a, a[:, :1], bias=True)[1]
+
+
+class AddRowParameterFunction(torch.autograd.Function):
+    """x (rows..., F) + p (broadcast over the leading dimensions, F = p.numel()): the gradient of p is the column sum of the
+    upstream gradient through K12, added straight into p.grad inside ``grad_sinks``."""
+
+    @staticmethod
+    def forward(ctx, x, p):                 # x (rows, F), p (F)
+        ctx.p = p
+        return x + p
+
+    @staticmethod
+    def backward(ctx, g):
+        p = ctx.p
+        g = g.contiguous()
+        gp = None
+        if ctx.needs_input_grad[1]:
+            sums = column_sums(g)
+            sink = _sink(p)
+            if sink is not None:
+                sink.view(-1).add_(sums)
+            else:
+                gp = sums.view_as(p)
+        return (g if ctx.needs_input_grad[0] else None), gp
+
+
+def add_row_parameter(x: Tensor, p: Tensor) -> Tensor:
+    """``x + p`` for a learned p of shape (1, ...) that spans the trailing dimensions of x (position embeddings, a bias outside
+    a GEMM)."""
+    tail = tuple(p.shape[1:]) if (p.ndim > 1 and p.shape[0] == 1) else tuple(p.shape)
+    if (x.is_cuda and x.dtype == torch.float32 and p.dtype == torch.float32 and x.numel() > 0 and len(tail) >= 1
+            and x.ndim > len(tail) and tuple(x.shape[x.ndim - len(tail):]) == tail):
+        F = p.numel()
+        return AddRowParameterFunction.apply(x.reshape(-1, F), p.view(F)).view_as(x)
+    return x + p
+
+
+class FrameMeanFunction(torch.autograd.Function):
+    """out (B, C) = sum_f w[f] x[b, f, c] + bias: the learned weighted mean over the F frame tokens (PoseTransformer's
+    ``weighted_mean`` = Conv1d(F, 1, kernel 1)). Backward: d x = g (x) w element-wise; d w[f] = <g, x[:, f, :]> and d bias = sum g as
+    K12 contractions over the B * C (row, channel) pairs."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.b = b
+        return (x * w.view(1, -1, 1)).sum(1) + b.view(1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        b = ctx.b
+        g = g.contiguous()
+        B, F, C = x.shape
+        gx = g.unsqueeze(1) * w.view(1, -1, 1) if ctx.needs_input_grad[0] else None
+        rows = x.permute(0, 2, 1).reshape(B * C, F)                       # (b, c) pairs x frames
+        gcol = g.reshape(B * C, 1)
+        gw, _ = atb(rows, gcol)                                            # (F, 1)
+        gb = column_sums(gcol)                                             # (1,)
+        out_w, out_b = gw.view_as(w), gb.view_as(b)
+        sw, sb = _sink(w), _sink(b)
+        if sw is not None and sb is not None:
+            sw.view(-1).add_(gw.view(-1)), sb.view(-1).add_(gb.view(-1))
+            out_w = out_b = None
+        return gx, out_w, out_b
+
+
+def frame_mean(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    if x.is_cuda and x.dtype == torch.float32 and x.ndim == 3 and w.numel() == x.shape[1] and b.numel() == 1:
+        return FrameMeanFunction.apply(x.contiguous(), w.reshape(-1), b.reshape(-1))
+    return (x * w.view(1, -1, 1)).sum(1) + b
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # one pre-norm transformer block as ONE autograd node (K15 + K16 + K14 + K12 launches only)
 # ----------------------------------------------------------------------------------------------------------------------
 def _ln_fwd(x2d: Tensor, w: Tensor, b: Tensor, eps: float):

@@ -386,7 +386,13 @@ class Trainer:
         # the warm-up iterations below are real optimisation steps: snapshot parameters + optimizer state and restore
         # them IN PLACE afterwards (the graphs hold the addresses), so that replay #1 is training step #1
         snapshot = self._snapshot(flow)
-        side = torch.cuda.Stream()
+        # ONE side stream for the warm-up steps and for every capture below: autograd's AccumulateGrad nodes remember the stream
+        # they were created on and outlive a step whenever anything still references its graph; a node from the warm-up that
+        # runs on another stream than the capture's put the gradients of the parameters that reach the flat buffer through
+        # AccumulateGrad (PoseFormer's position embeddings, patch embedding, frame-mean bias) one step late in the replayed
+        # graph -- found with NaN-filled torch.empty (tests/conftest.py P2C_POISON_EMPTY), visible without it as parameters that
+        # drift from the eager trainer by ~lr per step
+        side = self._capture_stream = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                 # warm-up outside capture (allocator, lazy inits, autotuning)
             for _ in range(3):
@@ -406,7 +412,7 @@ class Trainer:
                 return
             g_fb = self._new_graph(keep=True)
         if distributed:
-            with torch.cuda.graph(g_fb):
+            with torch.cuda.graph(g_fb, stream=side):
                 self._static_loss = self._forward_backward(flow, batch, batch_idx, batch_start=False)
             if self._kept_graph:
                 self._graph_nodes = self._count_nodes(g_fb)      # stage A alone: forward + backward
@@ -415,7 +421,7 @@ class Trainer:
                 g_opt = 'eager'          # FlatAdamW is a single kernel: a direct launch has less latency than a 1-node graph
             else:
                 g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_opt):
+                with torch.cuda.graph(g_opt, stream=side):
                     self._optimizer_step()
         else:
             g_opt = None
@@ -432,7 +438,7 @@ class Trainer:
                 rec = rec if try_direct else None
             ops.TRAIN_STEP_RECORDER = rec
             try:
-                with torch.cuda.graph(g_fb):
+                with torch.cuda.graph(g_fb, stream=side):
                     self._static_loss = self._forward_backward(flow, batch, batch_idx, batch_start=False)
                     self._optimizer_step()
             finally:
@@ -496,7 +502,7 @@ class Trainer:
         verification replay run, followed by a second agreement on bit-identical parameters."""
         ok, err = True, None
         try:
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=self._capture_stream):
                 self._static_loss = self._forward_backward(flow, batch, batch_idx, batch_start=False)
                 self.exchange.all_reduce_gradients()
                 self._optimizer_step()

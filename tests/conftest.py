@@ -15,6 +15,11 @@ def pytest_configure(config):
     # with 256 threads against 0.45 s with 8).
     import torch
     torch.set_num_threads(min(os.cpu_count() or 1, 8))
+    if os.environ.get('P2C_POISON_EMPTY') == '1':
+        # test audit: torch.empty / empty_like return NaN-filled memory, so that a kernel (or host code) reading a workspace or
+        # output buffer it never wrote shows up as NaN instead of depending on what the allocator handed back
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
 
 
 @pytest.fixture(scope='session')

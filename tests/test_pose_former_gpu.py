@@ -4,6 +4,8 @@ The transformer's arithmetic is parity-unpinned (third-party source absent from 
 what the reference owns -- the window wrapper (pose_former.py:117-127), eval_slice (:114-115), the optimizer / scheduler
 (:129-138) -- plus properties of the build's restatement (shapes, centre-frame dependence, permutation of the batch) and
 one captured train step of cfg5's per-GPU share."""
+import os
+
 import pytest
 import torch
 
@@ -81,6 +83,8 @@ def test_cfg5_train_steps_through_the_flow_with_lr_schedule():
         curves[graph] = torch.stack(losses).cpu()
         lr = trainer.optimizers[0].param_groups[0]['lr']
         assert abs(lr - 4e-4 * 0.99 ** 2) < 1e-12, lr               # two epoch ends
+    if os.environ.get('P2C_PRINT_CURVES'):
+        print('curves', curves)
     assert torch.isfinite(curves[False]).all() and curves[False][-1] < curves[False][0]
     assert torch.allclose(curves[True], curves[False], rtol=2e-3), (curves[True], curves[False])
 
