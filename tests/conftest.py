@@ -31,3 +31,19 @@ def golden():
         d = np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'))
         return {k: torch.from_numpy(d[k]) for k in d.files}
     return load
+
+
+# The two audit modes add launches to every step (an LDS-poisoning launch before each entry point / a fill behind each torch.empty):
+# tests that assert the STRUCTURE of the captured step -- exactly two launches, replayed as the one recorded call -- cannot hold
+# under them and are skipped there; everything numerical runs.
+_STRUCTURAL = ('test_cfg4_per_gpu_step_with_the_exchange_on', 'test_loss_curve_at_the_benchmark_configuration_conditioned_init_strict',
+               'test_captured_step_replayed_as_its_recorded_call', 'test_direct_replay_takes_new_batches_by_address')
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get('P2C_POISON_LDS') != '1' and os.environ.get('P2C_POISON_EMPTY') != '1':
+        return
+    skip = pytest.mark.skip(reason='asserts the launch structure of the captured step; the audit modes add launches')
+    for item in items:
+        if any(name in item.nodeid for name in _STRUCTURAL):
+            item.add_marker(skip)
