@@ -523,6 +523,12 @@ P2C_API int p2c_layernorm_bwd(const float *x, const float *gamma, const float *m
                       const float *gx_add, float *gx, float *g_gamma, float *g_beta, int32_t accumulate, float *partials,
                       int64_t rows, int32_t D, void *stream);
 
+/* Learned weighted mean over F frame tokens: out (B, C) = sum_f w[f] x[b, f, c] + bias[0] (bias may be NULL) -- the forward of
+ * PoseTransformer's weighted_mean = Conv1d(F, 1, kernel 1), bound at modules/movements/pose_former/pose_former.py:62-76. x (B, F, C)
+ * and out (B, C) dense and 16-byte aligned, C % 4 == 0. One launch. */
+P2C_API int p2c_frame_mean_fwd(const float *x, const float *w, const float *bias, float *out, int64_t B, int32_t F, int32_t C,
+                       void *stream);
+
 /* Testing aid (no counterpart in the reference): fills the LDS of every CU with NaN bit patterns, so that a kernel reading LDS it
  * never wrote fails deterministically instead of by what the previous workgroup left behind. One launch on `stream`. */
 P2C_API int p2c_debug_poison_lds(void *stream);

@@ -119,6 +119,7 @@ SYMBOLS = {
     'p2c_pose_head_fwd_launch': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.c_int32, _vp]),
     'p2c_gemm': (ctypes.c_int, [ctypes.POINTER(GemmDesc), _vp]),
     'p2c_debug_poison_lds': (ctypes.c_int, [_vp]),
+    'p2c_frame_mean_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'p2c_gemm_tn_workspace_floats': (_i64, [_i32, _i32, _i32]),
     'p2c_gemm_tn': (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     'p2c_pose_head_bwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.POINTER(_vp * 3), _vp, _vp, _vp, _vp, _vp]),

@@ -524,3 +524,37 @@ extern "C" int p2c_debug_poison_lds(void *stream) {
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
+
+
+// ---- learned weighted mean over F frame tokens: out (B, C) = sum_f w[f] x[b, f, c] + bias ---------------------------------------
+// PoseTransformer's weighted_mean = Conv1d(F, 1, kernel 1) (bound at modules/movements/pose_former/pose_former.py:62-76) as the
+// streaming pass it is: a thread owns four channels of one sample and walks the F rows (16-byte loads, F <= 64 weights in
+// registers). Its backward is element-wise (d x) plus two K12 contractions (d w, d bias): ops.FrameMeanFunction.
+namespace p2c_aux {
+__global__ __launch_bounds__(256) void frame_mean_kernel(const float *x, const float *w, const float *bias, float *out, int64_t B, int F,
+                                                         int C) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int c4 = C >> 2;
+  const float b0 = bias ? bias[0] : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B * c4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / c4;
+    const int c = (int)(i - b * c4) * 4;
+    const float *p = x + (b * F) * C + c;
+    f4 acc = {b0, b0, b0, b0};
+    for (int f = 0; f < F; ++f) acc += *reinterpret_cast<const f4 *>(p + (int64_t)f * C) * w[f];
+    *reinterpret_cast<f4 *>(out + b * C + c) = acc;
+  }
+}
+}  // namespace p2c_aux
+
+extern "C" int p2c_frame_mean_fwd(const float *x, const float *w, const float *bias, float *out, int64_t B, int32_t F, int32_t C,
+                                  void *stream) {
+  if (!x || !w || !out) return P2C_E_NULL;
+  if (B < 0 || F < 1 || C < 4 || (C & 3) || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15)) return P2C_E_SHAPE;
+  if (B == 0) return 0;
+  const int64_t n = B * (C >> 2);
+  const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+  hipLaunchKernelGGL(p2c_aux::frame_mean_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, out, B, F, C);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

@@ -250,3 +250,28 @@ def test_block_as_one_autograd_node_matches_the_same_block_in_fp64(S, N, C, head
     for i, ((name, pg), (_, pr)) in enumerate(zip(blk.named_parameters(), ref.named_parameters())):
         want = pr.grad + (seeds[i].double() if sinks else 0.0)
         assert rel(pg.grad, want) < 1e-4, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,F,C', [(2336, 9, 832), (5, 3, 8), (1, 1, 4), (100, 64, 36)])
+def test_frame_mean_and_row_parameter_ops_match_fp64(B, F, C):
+    """ops.frame_mean (p2c_frame_mean_fwd + K12 contractions behind it) and ops.add_row_parameter (K12 column sum behind it)
+    against the written-out formulas in fp64: values and all gradients."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    torch.manual_seed(B + F)
+    x = torch.randn(B, F, C, device=d, requires_grad=True)
+    w, b = torch.randn(F, 1, device=d, requires_grad=True), torch.randn(1, device=d, requires_grad=True)
+    p = torch.randn(1, F, C, device=d, requires_grad=True)
+    up = torch.randn(B, C, device=d)
+    y = ops.frame_mean(ops.add_row_parameter(x, p), w.view(1, F, 1), b)
+    (y * up).sum().backward()
+    x64, w64, b64, p64 = (t.detach().double().requires_grad_(True) for t in (x, w, b, p))
+    y64 = ((x64 + p64) * w64.view(1, F, 1)).sum(1) + b64
+    (y64 * up.double()).sum().backward()
+
+    def rel(a, r):
+        return float((a.detach().double() - r).abs().max() / (r.abs().max() + 1e-30))
+    assert rel(y, y64) < 1e-5
+    for name, a, r in (('x', x, x64), ('w', w, w64), ('b', b, b64), ('p', p, p64)):
+        assert rel(a.grad, r.grad) < 5e-5, name
