@@ -33,12 +33,32 @@ struct Args {
 // A and of B as one 8-byte access each (a whole 128-byte line per row and operand), so tile (h, g) of the block is the
 // interleaved set of rows m0 + 2i + h and columns n0 + 2j + g: two loads feed four MFMAs.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*red)[4][64]) {
+// Workgroup numbering: the grid is launch_blocks() = (launched blocks of C) x (slices rounded up to 8). Workgroups are handed to
+// the eight XCDs round-robin, so id & 7 is the XCD: it picks the slice within a run of eight, and all blocks of C of one slice
+// follow each other on ONE XCD -- the 128-byte row segments of A and B they share (a row of A feeds every column block, a row
+// of B every row block) are fetched into that XCD's L2 once instead of once per XCD.
+// The bias gradient (A^T times a column of ones) of a problem with N % 32 == 0 would open a column block of its own for one
+// useful column: instead the workgroups of column block 0 carry two more accumulators (A pairs against a [1 0 .. 0] operand)
+// and publish them in the place of that virtual block, which only the finish pass knows about.
+__device__ __forceinline__ bool bias_in_block(const Args &a) { return a.ones != 0 && (a.N & 31) == 0; }
+__host__ __device__ __forceinline__ int launched_tiles(int tiles, int N, int ones) {
+  const int nb_count = (N + ones + 31) >> 5;
+  return (ones != 0 && (N & 31) == 0) ? tiles / nb_count * (nb_count - 1) : tiles;
+}
+static inline int launch_blocks(const Args &a) { return launched_tiles(a.tiles, a.N, a.ones) * ((a.ks + 7) & ~7); }
+
+__device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*red)[4][64], f32x4 (*redb)[2][4]) {
   const int lane = threadIdx.x & 63, r = lane & 15, kk = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nb_count = (a.N + a.ones + 31) >> 5;
-  const int blk = bid % a.tiles, slice = bid / a.tiles;
-  const int mb = blk / nb_count, nb = blk - mb * nb_count;
+  const int nb_count = (a.N + a.ones + 31) >> 5;              // column blocks the finish pass walks (a.tiles = row blocks x this)
+  const int nb_real = bias_in_block(a) ? nb_count - 1 : nb_count;
+  const int tiles_real = a.tiles / nb_count * nb_real;
+  const int slice = ((bid >> 3) / tiles_real) * 8 + (bid & 7), blk_r = (bid >> 3) % tiles_real;
+  if (slice >= a.ks) return;
+  const int mb = blk_r / nb_real, nb = blk_r - mb * nb_real;
+  const int blk = mb * nb_count + nb;
+  const bool with_bias = bias_in_block(a) && nb == 0;
+  const float onev = r == 0 ? 1.f : 0.f;
   const int m = mb * 32 + 2 * r, n = nb * 32 + 2 * r;          // first column of this lane's pair
   const bool vec_a = (m + 1 < a.M) && ((a.lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 7) == 0);
   const bool vec_b = (n + 1 < a.N) && ((a.ldb & 1) == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 7) == 0);
@@ -50,6 +70,7 @@ __device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*r
     return c < limit ? p[off] : ((one_ok && c == limit) ? 1.f : 0.f);
   };
   f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+  f32x4 accb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #ifndef P2C_ATB_U
 #define P2C_ATB_U 4
 #endif
@@ -76,15 +97,29 @@ __device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*r
 #pragma unroll
         for (int g = 0; g < 2; ++g)
           acc[h][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][h], bv[u][g], acc[h][g], 0, 0, 0);
+      if (with_bias) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) accb[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][h], onev, accb[h], 0, 0, 0);
+      }
     }
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int g = 0; g < 2; ++g) red[wave][h * 2 + g][lane] = acc[h][g];
+  if (with_bias && r == 0) redb[wave][0][kk] = accb[0], redb[wave][1][kk] = accb[1];     // column 0 of the two bias tiles
   __syncthreads();
-  // waves 0..3 each finish one of the four tiles (slices of K added in wave order)
-  if (wave >= 4) return;
+  // waves 0..3 each finish one of the four tiles (slices of K added in wave order); waves 4, 5 the two bias tiles
+  if (wave >= 4) {
+    if (with_bias && wave < 6 && lane < 4) {
+      f32x4 s = redb[0][wave - 4][lane];
+#pragma unroll
+      for (int w = 1; w < WAVES; ++w) s += redb[w][wave - 4][lane];
+      // tile (h = wave - 4, g = 0) of the virtual column block nb_real, lane (r = 0, kk = lane)
+      reinterpret_cast<f32x4 *>(a.ws)[(((size_t)slice * a.tiles + blk + nb_real) * 4 + (wave - 4) * 2) * 64 + 16 * lane] = s;
+    }
+    return;
+  }
   f32x4 s = red[0][wave][lane];
 #pragma unroll
   for (int w = 1; w < WAVES; ++w) s += red[w][wave][lane];
@@ -93,7 +128,8 @@ __device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*r
 
 __global__ __launch_bounds__(64 * WAVES) void atb_kernel(const Args a) {
   __shared__ f32x4 red[WAVES][4][64];
-  atb_body(a, blockIdx.x, red);
+  __shared__ f32x4 redb[WAVES][2][4];
+  atb_body(a, blockIdx.x, red, redb);
 }
 
 // slices added in order, one thread per (block, tile, lane)
@@ -142,9 +178,10 @@ struct Group {
 };
 __global__ __launch_bounds__(64 * WAVES) void atb_group_kernel(const Group g) {
   __shared__ f32x4 red[WAVES][4][64];
+  __shared__ f32x4 redb[WAVES][2][4];
   int i = 0;
   while (i + 1 < g.n && (int)blockIdx.x >= g.first[i + 1]) ++i;
-  atb_body(g.p[i], blockIdx.x - g.first[i], red);
+  atb_body(g.p[i], blockIdx.x - g.first[i], red, redb);
 }
 __global__ __launch_bounds__(256) void atb_group_finish_kernel(const Group g) {
   int i = 0;
@@ -177,7 +214,7 @@ extern "C" int p2c_atb_scaled(const float *A, int64_t lda, const float *B, int64
          rows_per_scale};
   a.tiles = ((M + 31) / 32) * ((N + a.ones + 31) / 32);      // 32x32 blocks of C
   a.ks = slices_for(a.tiles, K);
-  hipLaunchKernelGGL(atb_kernel, dim3((unsigned)(a.tiles * a.ks)), dim3(64 * WAVES), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(atb_kernel, dim3((unsigned)launch_blocks(a)), dim3(64 * WAVES), 0, (hipStream_t)stream, a);
   hipLaunchKernelGGL(atb_finish_kernel, dim3((unsigned)a.tiles), dim3(256), 0, (hipStream_t)stream, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
@@ -204,7 +241,7 @@ static int group_fill(const p2c_atb_problem *p, int32_t n, float *workspace, p2c
              q.M, q.N, q.bias_out ? 1 : 0, q.flags & 3, 1, 0, q.bias_out2, nullptr, 1};
     a.tiles = ((q.M + 31) / 32) * ((q.N + a.ones + 31) / 32);
     a.ks = slices_for(a.tiles, q.K);
-    g.first[i + 1] = g.first[i] + a.tiles * a.ks;
+    g.first[i + 1] = g.first[i] + launch_blocks(a);        // (a multiple of 8: every problem starts on XCD 0)
     g.ffirst[i + 1] = g.ffirst[i] + a.tiles;
     off += (int64_t)a.ks * a.tiles * 1024;
   }

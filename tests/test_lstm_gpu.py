@@ -411,7 +411,8 @@ def test_residual_seq2seq_variants_on_the_gpu_match_cpu(variant):
         close(pg.grad, pc.grad, 'grad ' + n, rtol=5e-4)
 
 
-@pytest.mark.parametrize('K,M,N', [(8192, 256, 64), (8192, 256, 52), (8001, 52, 64), (5, 7, 3), (1, 16, 16), (300, 159, 100)])
+@pytest.mark.parametrize('K,M,N', [(8192, 256, 64), (8192, 256, 52), (8001, 52, 64), (5, 7, 3), (1, 16, 16), (300, 159, 100),
+                                   (70000, 96, 32), (100, 33, 96), (15360, 256, 128)])
 def test_atb_matches_fp64(K, M, N):
     """p2c_atb: C = A^T B and the column sums of A (weight + bias gradient of a dense layer), overwrite and accumulate,
     contiguous and row-strided operands, vs fp64."""
