@@ -38,7 +38,10 @@ constexpr int BM = 128, BK = 32, NTH = 256;
 static __device__ unsigned long long g_gemm_trace[64];
 #define GT(i)                                                                                                     \
   do {                                                                                                            \
-    if ((int)blockIdx.x == P2C_GEMM_TRACE_BLOCK && threadIdx.x == 0 && (i) < 64) g_gemm_trace[i] = __builtin_readcyclecounter(); \
+    if ((int)blockIdx.x == P2C_GEMM_TRACE_BLOCK && threadIdx.x == 0 && (i) < 62) {                                 \
+      g_gemm_trace[i] = __builtin_readcyclecounter();                                                             \
+      if ((i) == 0 || (i) == 61) g_gemm_trace[(i) == 0 ? 62 : 63] = wall_clock64();   /* 100 MHz: the shader clock under load */ \
+    }                                                                                                             \
   } while (0)
 #else
 #define GT(i)
@@ -288,31 +291,72 @@ __global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
 }
 
 // ---- epilogue of one wave's TM x TN accumulator tiles: C/D layout of the 32 x 32 tile: column = lane & 31,
-// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue(const p2c_gemm_desc &d, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int li, int lk) {
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// Which terms exist (activation, row scale, residual) and whether the wave's block lies inside the matrix are uniform over the
+// launch / the wave: they pick ONE straight-line instantiation. Written as one loop with the tests inside, every element was
+// its own basic block of ~150 instructions (the tests, a 64-bit row product per pointer, an integer division for the row
+// scale): 5 000 instructions per wave, 50 k cycles = 15 % of a workgroup's life at 21 024 x 2 496 x 832 (tools/gemmtrace.py).
+// Here a row's pointers and its scale are formed once and serve the TN columns.
+template <int ACT, bool SCALE, bool RES, bool FULL, int TM, int TN>
+__device__ __forceinline__ void epilogue_rows(const p2c_gemm_desc &d, const f32x16 (&acc)[TM][TN], int mw, int nw, int li, int lk) {
+  int n[TN];
+  bool nok[TN];
+  float bias[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
-    const int n = n0 + (wn * TN + b) * 32 + li;
-    if (n >= d.N) continue;
-    const float bias = d.bias ? d.bias[n] : 0.f;
+    n[b] = nw + b * 32 + li;
+    nok[b] = FULL || n[b] < d.N;
+    bias[b] = (d.bias && nok[b]) ? d.bias[n[b]] : 0.f;
+  }
+  float *const zbase = (ACT == 1) ? d.aux_out : nullptr;
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * TM + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (m >= d.M) continue;
-        float v = acc[a][b][r] + bias;
-        if (d.act == 1) {
-          if (d.aux_out) d.aux_out[(int64_t)m * d.ldaux + n] = v;
+    for (int r = 0; r < 16; ++r) {
+      const int m = mw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      if (!FULL && m >= d.M) continue;
+      float *const crow = d.c + (int64_t)m * d.ldc;
+      const float *const rrow = RES ? d.residual + (int64_t)m * d.ldr : nullptr;
+      const float *const xrow = (ACT == 2) ? d.aux + (int64_t)m * d.ldaux : nullptr;
+      float *const zrow = (ACT == 1 && zbase) ? zbase + (int64_t)m * d.ldaux : nullptr;
+      const float rs = SCALE ? d.row_scale[(unsigned)m / (unsigned)d.rows_per_scale] : 1.f;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        if (!nok[b]) continue;
+        float v = acc[a][b][r] + bias[b];
+        if (ACT == 1) {
+          if (zrow) zrow[n[b]] = v;
           v = gelu(v);
-        } else if (d.act == 2) {
-          v *= gelu_grad(d.aux[(int64_t)m * d.ldaux + n]);
+        } else if (ACT == 2) {
+          v *= gelu_grad(xrow[n[b]]);
         }
-        if (d.row_scale) v *= d.row_scale[m / d.rows_per_scale];
-        if (d.residual) v += d.residual[(int64_t)m * d.ldr + n];
-        d.c[(int64_t)m * d.ldc + n] = v;
+        if (SCALE) v *= rs;
+        if (RES) v += rrow[n[b]];
+        crow[n[b]] = v;
       }
+    }
+}
+template <int ACT, bool FULL, int TM, int TN>
+__device__ __forceinline__ void epilogue_terms(const p2c_gemm_desc &d, const f32x16 (&acc)[TM][TN], int mw, int nw, int li, int lk) {
+  const bool scale = d.row_scale != nullptr, res = d.residual != nullptr;
+  if (scale && res) epilogue_rows<ACT, true, true, FULL>(d, acc, mw, nw, li, lk);
+  else if (scale) epilogue_rows<ACT, true, false, FULL>(d, acc, mw, nw, li, lk);
+  else if (res) epilogue_rows<ACT, false, true, FULL>(d, acc, mw, nw, li, lk);
+  else epilogue_rows<ACT, false, false, FULL>(d, acc, mw, nw, li, lk);
+}
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const p2c_gemm_desc &d, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int li, int lk) {
+  const int mw = m0 + wm * TM * 32, nw = n0 + wn * TN * 32;
+  const bool full = mw + TM * 32 <= d.M && nw + TN * 32 <= d.N;
+  if (d.act == 1) {
+    if (full) epilogue_terms<1, true>(d, acc, mw, nw, li, lk);
+    else epilogue_terms<1, false>(d, acc, mw, nw, li, lk);
+  } else if (d.act == 2) {
+    if (full) epilogue_terms<2, true>(d, acc, mw, nw, li, lk);
+    else epilogue_terms<2, false>(d, acc, mw, nw, li, lk);
+  } else {
+    if (full) epilogue_terms<0, true>(d, acc, mw, nw, li, lk);
+    else epilogue_terms<0, false>(d, acc, mw, nw, li, lk);
   }
 }
 
