@@ -35,10 +35,12 @@ constexpr int BM = 128, BK = 32, NTH = 256;
 #ifndef P2C_GEMM_TRACE_BLOCK
 #define P2C_GEMM_TRACE_BLOCK 2000
 #endif
-static __device__ unsigned long long g_gemm_trace[64];
+static __device__ unsigned long long g_gemm_trace[65];      // [62], [63]: wall clock at stamps 0 and 61; [64]: at stamp 0 of workgroup 0
+static __device__ int g_gemm_trace_block = P2C_GEMM_TRACE_BLOCK;
 #define GT(i)                                                                                                     \
   do {                                                                                                            \
-    if ((int)blockIdx.x == P2C_GEMM_TRACE_BLOCK && threadIdx.x == 0 && (i) < 62) {                                 \
+    if ((i) == 0 && blockIdx.x == 0 && threadIdx.x == 0) g_gemm_trace[64] = wall_clock64();                      \
+    if ((int)blockIdx.x == g_gemm_trace_block && threadIdx.x == 0 && (i) < 62) {                                 \
       g_gemm_trace[i] = __builtin_readcyclecounter();                                                             \
       if ((i) == 0 || (i) == 61) g_gemm_trace[(i) == 0 ? 62 : 63] = wall_clock64();   /* 100 MHz: the shader clock under load */ \
     }                                                                                                             \
@@ -125,6 +127,48 @@ __device__ __forceinline__ void store_kn(float *slab, int ld, const SlabRegs &r,
   for (int i = 0; i < M::PIECES; ++i) *reinterpret_cast<f32x4 *>(slab + M::row(i, tid) * ld + M::col(i, tid)) = r.v[i];
 }
 
+// ---- the same slabs through buffer loads (FAST forms: 16-byte-aligned operands, K a multiple of BK, every operand below 2 GB).
+// A thread's four (two, one) pieces sit at the same place of every k-tile: their byte offsets are formed ONCE, with pieces outside
+// the matrix (rows past M or N, columns past N) parked beyond the buffer's records -- the range check of a raw buffer looks at
+// the lane offset only and returns zeros there -- and the k-tile is the scalar offset of the instruction. A k-tile's fetch is
+// its 6 load instructions and one scalar add; with pointers, every piece carried a 64-bit row product, two compares and a
+// branch around the load, and the timeline (tools/gemmtrace.py) showed the ISSUE of a k-tile's loads taking 2 000 - 3 900 cycles
+// -- the largest part of what a wave spends outside its MFMA phase.
+constexpr int OOB_OFF = 0x7fffff00;
+struct SlabOff {
+  int v[4];
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const float *base, int64_t rows, int64_t ld, int64_t cols) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)(((rows - 1) * ld + cols) * 4), 0x00020000);
+}
+__device__ __forceinline__ SlabOff rows_offsets(int64_t ld, int row0, int n_rows, int rows_in_tile, int tid) {
+  SlabOff o;
+  const int kp = (tid & 7) * 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (tid >> 3) + 32 * i;
+    o.v[i] = (row < rows_in_tile && row0 + row < n_rows) ? (int)(((int64_t)(row0 + row) * ld + kp) * 4) : OOB_OFF;
+  }
+  return o;
+}
+template <int W>
+__device__ __forceinline__ SlabOff kn_offsets(int64_t ld, int n0, int N, int tid) {
+  using M = KnMap<W>;
+  SlabOff o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i >= M::PIECES) { o.v[i] = OOB_OFF; continue; }
+    const int n = n0 + M::col(i, tid);
+    o.v[i] = n < N ? (int)(((int64_t)M::row(i, tid) * ld + n) * 4) : OOB_OFF;
+  }
+  return o;
+}
+template <int PIECES>
+__device__ __forceinline__ void load_pieces(__amdgpu_buffer_rsrc_t rs, const SlabOff &o, int soff, SlabRegs &r) {
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) r.v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o.v[i], soff, 0));
+}
+
 // Workgroups are dealt to the eight XCDs round-robin by their linear id, and every XCD has its own L2: with tile = id, the
 // tiles that share an operand slab (one row of tiles shares A, one column B) are spread over all eight L2s. xcd_tile gives
 // XCD x the contiguous tile range [x n / 8, (x + 1) n / 8): what runs side by side on an XCD is a compact patch of C.
@@ -154,7 +198,7 @@ struct TnArgs {
   float *bias, *ws_bias;        // column sums of the (scaled) A = the bias gradient, or NULL; (slices, M) slabs
   int32_t bias_accumulate;
 };
-template <int BN, bool VEC>
+template <int BN, bool VEC, bool FAST = false>
 __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_tn_kernel(const TnArgs d) {
   constexpr int WM = (BN == 128) ? 2 : 4, TM = (BN == 128) ? 2 : 1, TN = (BN == 128) ? 2 : BN / 32;
   __shared__ __attribute__((aligned(16))) float As[BK * (BM + 4)];
@@ -178,8 +222,15 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
   const int nk = (k_end - k_begin + BK - 1) / BK;
   const bool sums = d.bias && tn == 0 && (int)threadIdx.x < BM;
   float colsum = 0.f;
+  SlabOff oa, ob;
+  __amdgpu_buffer_rsrc_t rsa, rsb;
+  if (FAST) {
+    rsa = operand_rsrc(d.a, d.K, d.lda, d.M), rsb = operand_rsrc(d.b, d.K, d.ldb, d.N);
+    oa = kn_offsets<BM>(d.lda, m0, d.M, (int)threadIdx.x), ob = kn_offsets<BN>(d.ldb, n0, d.N, (int)threadIdx.x);
+  }
   auto fetch = [&](int kt) {
-    load_kn<BM, VEC>(d.a, d.lda, k_begin + kt * BK, k_end, m0, d.M, ra, (int)threadIdx.x);
+    if (FAST) load_pieces<KnMap<BM>::PIECES>(rsa, oa, (int)((k_begin + kt * BK) * d.lda * 4), ra);
+    else load_kn<BM, VEC>(d.a, d.lda, k_begin + kt * BK, k_end, m0, d.M, ra, (int)threadIdx.x);
     if (d.row_scale) {
 #pragma unroll
       for (int i = 0; i < KnMap<BM>::PIECES; ++i) {
@@ -187,7 +238,8 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
         ra.v[i] *= k < k_end ? d.row_scale[k / d.rows_per_scale] : 0.f;
       }
     }
-    load_kn<BN, VEC>(d.b, d.ldb, k_begin + kt * BK, k_end, n0, d.N, rb, (int)threadIdx.x);
+    if (FAST) load_pieces<KnMap<BN>::PIECES>(rsb, ob, (int)((k_begin + kt * BK) * d.ldb * 4), rb);
+    else load_kn<BN, VEC>(d.b, d.ldb, k_begin + kt * BK, k_end, n0, d.N, rb, (int)threadIdx.x);
   };
   auto commit = [&]() {
     store_kn<BM>(As, BM + 4, ra, (int)threadIdx.x);
@@ -364,7 +416,7 @@ __device__ __forceinline__ void epilogue(const p2c_gemm_desc &d, const f32x16 (&
 // the MFMAs of kt, one barrier per k-tile -- was measured twice and is slower: 945 vs 846 us at 21 024 x 2 496 x 832. LDS
 // operations of a wave complete in order, so the operand reads behind the 32 stores wait for them anyway, and 66 KB of slabs
 // leave two workgroups per CU instead of three.)
-template <int BN, bool TRANS_B, bool VEC>
+template <int BN, bool TRANS_B, bool VEC, bool FAST = false>
 __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_kernel(const p2c_gemm_desc d) {
   constexpr int WM = (BN == 128) ? 2 : 4;            // waves along m
   constexpr int TM = (BN == 128) ? 2 : 1;            // 32 x 32 MFMA tiles per wave along m ...
@@ -392,7 +444,28 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
 
   SlabRegs ra, rb;
   const int nk = (d.K + BK - 1) / BK;
+  SlabOff oa, ob;
+  __amdgpu_buffer_rsrc_t rsa, rsb;
+  int b_step = 0;
+  if (FAST) {
+    rsa = operand_rsrc(d.a, d.M, d.lda, d.K);
+    oa = rows_offsets(d.lda, m0, d.M, BM, (int)threadIdx.x);
+    if (TRANS_B) {
+      rsb = operand_rsrc(d.b, d.N, d.ldb, d.K);
+      ob = rows_offsets(d.ldb, n0, d.N, BN, (int)threadIdx.x);
+      b_step = BK * 4;
+    } else {
+      rsb = operand_rsrc(d.b, d.K, d.ldb, d.N);
+      ob = kn_offsets<BN>(d.ldb, n0, d.N, (int)threadIdx.x);
+      b_step = (int)(BK * d.ldb * 4);
+    }
+  }
   auto fetch = [&](int kt) {
+    if (FAST) {
+      load_pieces<4>(rsa, oa, kt * (BK * 4), ra);
+      load_pieces<TRANS_B ? BN / 32 : KnMap<BN>::PIECES>(rsb, ob, kt * b_step, rb);
+      return;
+    }
     load_rows<VEC>(d.a, d.lda, m0, d.M, kt * BK, d.K, ra, BM, (int)threadIdx.x);
     if (TRANS_B) load_rows<VEC>(d.b, d.ldb, n0, d.N, kt * BK, d.K, rb, BN, (int)threadIdx.x);
     else load_kn<BN, VEC>(d.b, d.ldb, kt * BK, d.K, n0, d.N, rb, (int)threadIdx.x);
@@ -463,6 +536,7 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
 template <bool TRANS_B, bool VEC>
 __global__ __launch_bounds__(NTH, 5) void gemm16_kernel(const p2c_gemm_desc d) {
   constexpr int BN = 64, LDB = BN + 1, ldb_s = TRANS_B ? LDB : BN + 4;
+  constexpr bool FAST = false;
   __shared__ __attribute__((aligned(16))) float As[BK * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * (BN + 4)];
   const int n_tiles = (d.N + BN - 1) / BN;
@@ -477,7 +551,28 @@ __global__ __launch_bounds__(NTH, 5) void gemm16_kernel(const p2c_gemm_desc d) {
     for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   SlabRegs ra, rb;
   const int nk = (d.K + BK - 1) / BK;
+  SlabOff oa, ob;
+  __amdgpu_buffer_rsrc_t rsa, rsb;
+  int b_step = 0;
+  if (FAST) {
+    rsa = operand_rsrc(d.a, d.M, d.lda, d.K);
+    oa = rows_offsets(d.lda, m0, d.M, BM, (int)threadIdx.x);
+    if (TRANS_B) {
+      rsb = operand_rsrc(d.b, d.N, d.ldb, d.K);
+      ob = rows_offsets(d.ldb, n0, d.N, BN, (int)threadIdx.x);
+      b_step = BK * 4;
+    } else {
+      rsb = operand_rsrc(d.b, d.K, d.ldb, d.N);
+      ob = kn_offsets<BN>(d.ldb, n0, d.N, (int)threadIdx.x);
+      b_step = (int)(BK * d.ldb * 4);
+    }
+  }
   auto fetch = [&](int kt) {
+    if (FAST) {
+      load_pieces<4>(rsa, oa, kt * (BK * 4), ra);
+      load_pieces<TRANS_B ? BN / 32 : KnMap<BN>::PIECES>(rsb, ob, kt * b_step, rb);
+      return;
+    }
     load_rows<VEC>(d.a, d.lda, m0, d.M, kt * BK, d.K, ra, BM, (int)threadIdx.x);
     if (TRANS_B) load_rows<VEC>(d.b, d.ldb, n0, d.N, kt * BK, d.K, rb, BN, (int)threadIdx.x);
     else load_kn<BN, VEC>(d.b, d.ldb, kt * BK, d.K, n0, d.N, rb, (int)threadIdx.x);
@@ -654,7 +749,12 @@ static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
     hipLaunchKernelGGL((gemm_ws_kernel<BN, TRANS_B, true>), dim3(grid), dim3(2 * NTH), 0, s, d);
     return;
   }
-  if (vec) hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, true>), dim3(grid), dim3(NTH), 0, s, d);
+  static const int no_fast = getenv("P2C_GEMM_NO_FAST") ? atoi(getenv("P2C_GEMM_NO_FAST")) : 0;      // (A/B timing)
+  const int64_t a_bytes = ((int64_t)(d.M - 1) * d.lda + d.K) * 4;
+  const int64_t b_bytes = (TRANS_B ? (int64_t)(d.N - 1) * d.ldb + d.K : (int64_t)(d.K - 1) * d.ldb + d.N) * 4;
+  const bool fast = vec && !no_fast && d.K % BK == 0 && a_bytes < OOB_OFF && b_bytes < OOB_OFF;
+  if (fast) hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, true, true>), dim3(grid), dim3(NTH), 0, s, d);
+  else if (vec) hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, true>), dim3(grid), dim3(NTH), 0, s, d);
   else hipLaunchKernelGGL((gemm_kernel<BN, TRANS_B, false>), dim3(grid), dim3(NTH), 0, s, d);
 }
 
@@ -717,9 +817,12 @@ extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t 
   const bool vec = al(a) && al(b) && lda % 4 == 0 && ldb % 4 == 0 && M % 4 == 0 && N % 4 == 0;
   const int bn = tn_bn(N);
   const dim3 grid(xcd_grid((int64_t)((M + BM - 1) / BM) * ((N + bn - 1) / bn) * d.slices));
+  static const int no_fast = getenv("P2C_GEMM_NO_FAST") ? atoi(getenv("P2C_GEMM_NO_FAST")) : 0;      // (A/B timing)
+  const bool fast = vec && !no_fast && K % BK == 0 && ((int64_t)(K - 1) * lda + M) * 4 < OOB_OFF && ((int64_t)(K - 1) * ldb + N) * 4 < OOB_OFF;
 #define P2C_TN(BN_)                                                                         \
   do {                                                                                      \
-    if (vec) hipLaunchKernelGGL((gemm_tn_kernel<BN_, true>), grid, dim3(NTH), 0, s, d);     \
+    if (fast) hipLaunchKernelGGL((gemm_tn_kernel<BN_, true, true>), grid, dim3(NTH), 0, s, d);   \
+    else if (vec) hipLaunchKernelGGL((gemm_tn_kernel<BN_, true>), grid, dim3(NTH), 0, s, d);     \
     else hipLaunchKernelGGL((gemm_tn_kernel<BN_, false>), grid, dim3(NTH), 0, s, d);        \
   } while (0)
   if (bn == 128) P2C_TN(128);
@@ -734,8 +837,11 @@ extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t 
 }
 
 #ifdef P2C_GEMM_TRACE
+extern "C" __attribute__((visibility("default"))) int p2c_debug_gemm_trace_block(int block) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(p2c_gemm_impl::g_gemm_trace_block), &block, sizeof(int));
+}
 extern "C" __attribute__((visibility("default"))) int p2c_debug_gemm_trace(unsigned long long *out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_gemm_impl::g_gemm_trace), sizeof(unsigned long long) * 64);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_gemm_impl::g_gemm_trace), sizeof(unsigned long long) * 65);
 }
 #endif
 

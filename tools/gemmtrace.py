@@ -11,7 +11,7 @@ for _ in range(int(os.environ.get('GEMMTRACE_WARM', '60'))):       # long enough
 torch.cuda.synchronize()
 lib = _lib.lib()
 lib.p2c_debug_gemm_trace.argtypes = [ctypes.c_void_p]
-buf = (ctypes.c_ulonglong * 64)()
+buf = (ctypes.c_ulonglong * 65)()
 assert lib.p2c_debug_gemm_trace(buf) == 0
 t = list(buf)
 print('first fetch issue', t[1] - t[0], '| wait + commit', t[2] - t[1], '| barrier', t[3] - t[2])
@@ -21,3 +21,16 @@ for kt in range(8):
           f'LDS stores {t[b + 4] - t[b + 3]:5d} | barrier {t[b + 5] - t[b + 4]:5d} | next fetch issue {t[b + 6] - t[b + 5] if kt < 7 else 0:5d}')
 print('main loop', t[60] - t[3], 'epilogue', t[61] - t[60], 'workgroup total', t[61] - t[0])
 print('shader clock over this workgroup\'s life: %.0f MHz (%.1f us)' % ((t[61] - t[0]) / ((t[63] - t[62]) / 100.0), (t[63] - t[62]) / 100.0))
+
+# the same launch seen from workgroups that start in later rounds: life in cycles, wall-clock start / end relative to the first
+lib.p2c_debug_gemm_trace_block.argtypes = [ctypes.c_int]
+rows = []
+for blk in (0, 640, 1279, 1280, 2000, 3000, 4000, 5000, 6000, 6300, 6434):
+    assert lib.p2c_debug_gemm_trace_block(blk) == 0
+    ops.gemm(a, w, True)
+    torch.cuda.synchronize()
+    assert lib.p2c_debug_gemm_trace(buf) == 0
+    t = list(buf)
+    rows.append((blk, t[61] - t[0], t[3] - t[0], t[60] - t[3], t[61] - t[60], (t[62] - t[64]) / 100.0, (t[63] - t[64]) / 100.0))
+for blk, life, pro, main, epi, w0, w1 in rows:
+    print(f'block {blk:5d}: life {life:7d} cycles (prologue {pro:6d}, main {main:7d}, epilogue {epi:6d}), from {w0:7.1f} to {w1:7.1f} us after workgroup 0 started')
