@@ -341,6 +341,33 @@ __global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
     __syncthreads();
   }
 }
+// Few slices (the wide layers: 2 .. 8 slabs of up to 2 M outputs each): a thread owns FOUR neighbouring outputs and adds their
+// slabs in slice order from 16-byte loads, all of them in flight at once -- the same sums, bit for bit, as the eight-part form
+// above gives for <= 8 slices (each part holds one slab), at the rate of a streaming pass instead of 4-byte loads by a
+// quarter of the threads (35 us -> see DESIGN.md for 5 slabs of 2 496 x 832).
+__global__ __launch_bounds__(256) void tn_finish_vec_kernel(const TnArgs d) {
+  const int64_t total = (int64_t)d.M * d.N, nv = total >> 2, n_all = nv + (d.bias ? d.M : 0);
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n_all; j += (int64_t)gridDim.x * 256) {
+    if (j < nv) {
+      const int64_t i = j * 4;
+      f32x4 t[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        t[s] = s < d.slices ? *reinterpret_cast<const f32x4 *>(d.ws + (int64_t)s * total + i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 8; ++s)
+        if (s < d.slices) v += t[s];
+      f32x4 *o = reinterpret_cast<f32x4 *>(d.c + (i / d.N) * d.ldc + (i % d.N));
+      *o = d.accumulate ? *o + v : v;
+    } else {
+      const int64_t b = j - nv;
+      float v = 0.f;
+      for (int s = 0; s < d.slices; ++s) v += d.ws_bias[(int64_t)s * d.M + b];
+      d.bias[b] = d.bias_accumulate ? d.bias[b] + v : v;
+    }
+  }
+}
 
 // ---- epilogue of one wave's TM x TN accumulator tiles: C/D layout of the 32 x 32 tile: column = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
@@ -774,23 +801,32 @@ static int tn_slices(int M, int N, int K) {
   const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
   int max_s = K / (16 * BK);                             // at least 16 k-tiles per slice
   max_s = max_s < 1 ? 1 : (max_s > 1024 ? 1024 : max_s);
+  if (const char *e = getenv("P2C_GEMM_TN_SLICES")) {     // (experiments: tools/tn_bench.py sweeps it)
+    const int v = atoi(e);
+    if (v >= 1) return v > max_s ? max_s : v;
+  }
   if (tiles < 64) {
     // a skinny output over very many rows (the spatial blocks' 96 x 32 from 546 624 rows) is a streaming pass over A and B:
     // what counts is enough workgroups in flight to pull the rows in -- about four per CU
     const int s = 1024 / tiles;
     return s < 1 ? 1 : (s > max_s ? max_s : s);
   }
-  // Otherwise every workgroup is MFMA-bound and the launch takes as long as the busiest CU: the slice count whose grid fills
-  // the 256 CUs most evenly (tiles * slices close below a multiple of 256), minus what a slice costs in workspace traffic
-  // (its slab written and read once: 8 M N bytes at ~6 TB/s against 2 M N K flop at ~100 TFLOP/s = 67 / K of the launch).
+  // Otherwise the launch takes as long as the busiest CU. A CU runs its workgroups five at a time (launch bounds), and what a
+  // k-tile step costs depends on how many share the MFMA pipes (timeline of a workgroup, tools/gemmtrace.py: alone a wave
+  // spends ~5.7 k cycles per k-tile, 2 k of them in MFMAs; five together take ~11.6 k per step and keep the pipes ~88 % busy):
+  // equal workgroups started together stay in step, so n of them on a CU cost floor(n / 5) full steps and one step of the
+  // remainder -- a remainder of one is the worst buy (half a full step for a fifth of its work). On top of that every slice
+  // writes and re-reads its slab (8 M N bytes at ~4 TB/s through the second launch). The slice count minimises the sum.
   if (max_s > 64) max_s = 64;
-  const double per_slice = 67.0 / (double)K;
+  static const double step_cost[6] = {0.0, 5.7e3, 5.7e3, 7.2e3, 9.4e3, 11.6e3};      // cycles per k-tile step, by co-resident count
+  const double finish_cycles_per_slice = 8.0 * M * N / 4.0e12 * 2.35e9;
   int best = 1;
-  double best_fill = 0.0;
+  double best_cost = 1e300;
   for (int s = 1; s <= max_s; ++s) {
-    const int blocks = tiles * s, rounds = (blocks + 255) / 256;
-    const double fill = (double)blocks / (rounds * 256.0) - per_slice * s;
-    if (fill > best_fill) best_fill = fill, best = s;
+    const int n_max = (tiles * s + 255) / 256;
+    const double kt = (double)((K + (int64_t)s * BK - 1) / ((int64_t)s * BK));
+    const double cost = kt * ((n_max / 5) * step_cost[5] + step_cost[n_max % 5]) + finish_cycles_per_slice * s;
+    if (cost < best_cost) best_cost = cost, best = s;
   }
   return best;
 }
@@ -831,7 +867,12 @@ extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t 
 #undef P2C_TN
   const int64_t total = (int64_t)M * N;
   const int64_t n_all = total + (bias_out ? M : 0);
-  hipLaunchKernelGGL(tn_finish_kernel, dim3((unsigned)((n_all + 31) / 32 < 65536 ? (n_all + 31) / 32 : 65536)), dim3(256), 0, s, d);
+  if (d.slices <= 8 && N % 4 == 0 && ldc % 4 == 0 && al(c) && al(workspace)) {
+    const int64_t n_thr = total / 4 + (bias_out ? M : 0);
+    hipLaunchKernelGGL(tn_finish_vec_kernel, dim3((unsigned)((n_thr + 255) / 256 < 65536 ? (n_thr + 255) / 256 : 65536)), dim3(256), 0, s, d);
+  } else {
+    hipLaunchKernelGGL(tn_finish_kernel, dim3((unsigned)((n_all + 31) / 32 < 65536 ? (n_all + 31) / 32 : 65536)), dim3(256), 0, s, d);
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
