@@ -27,7 +27,9 @@ def gelu64(z):
 
 
 @pytest.mark.parametrize('M,N,K', [(21024, 2496, 832), (4099, 96, 32), (1000, 32, 96), (777, 52, 64), (130, 64, 52), (8192, 256, 52),
-                                   (5, 3, 7), (1, 1, 1), (257, 129, 33), (300, 70, 1664)])
+                                   (5, 3, 7), (1, 1, 1), (257, 129, 33), (300, 70, 1664),
+                                   # K % 32 == 0 and aligned (the buffer-load forms) with ragged M and N tiles
+                                   (300, 100, 64), (129, 36, 96), (1000, 68, 32), (131, 260, 128)])
 @pytest.mark.parametrize('trans_b', [True, False])
 def test_gemm_plain_matches_fp64(M, N, K, trans_b):
     from pedestrians_video_2_carla_amd import ops
@@ -40,7 +42,7 @@ def test_gemm_plain_matches_fp64(M, N, K, trans_b):
 
 
 @pytest.mark.parametrize('K,M,N', [(21024, 2496, 832), (21024, 832, 1664), (4000, 130, 200), (31, 129, 140), (1, 5, 3), (9000, 64, 33),
-                                   (2050, 257, 129)])
+                                   (2050, 257, 129), (4096, 132, 100), (640, 36, 260)])    # (the last two: buffer-load forms, ragged tiles)
 def test_gemm_tn_matches_fp64_is_reproducible_and_accumulates(K, M, N):
     """dW = dy^T x for wide layers: split-K slabs added in a fixed order -- same bits on every call; accumulate adds to the sink;
     strided operands (column slices) take the dword loads."""

@@ -300,3 +300,32 @@ def test_static_batch_owns_an_int32_skeleton_type_index():
     keep = torch.tensor([3, 1, 0], dtype=torch.int32)
     batch = (frames, {}, {'skel_type': keep})
     assert tr._with_skel_type(batch) is batch
+
+
+def test_stochastic_depth_factors_of_a_stack_come_from_one_draw():
+    """PoseTransformer draws the survivor factors of a whole stack of blocks at once (``_stack_factors``): block i's two rows
+    are Bernoulli(keep_i) / keep_i like the per-block draw of the reference's DropPath (the third-party PoseTransformer bound at
+    modules/movements/pose_former/pose_former.py:62-76), blocks that drop nothing get none, eval mode draws nothing."""
+    import torch
+    from pedestrians_video_2_carla_amd.modules.movements.pose_former import pose_transformer as PT
+    m = PT.PoseTransformer(num_frame=9, num_joints=26, in_chans=2, embed_dim_ratio=8, depth=4, num_heads=2, mlp_ratio=2.,
+                           drop_path_rate=0.3)
+    x = torch.zeros(200000, 1)
+    m.train()
+    torch.manual_seed(3)
+    keep = m._keep_of(m.blocks, x)
+    factors = PT._stack_factors(m.blocks, keep, x)
+    assert keep.shape == (6, 1) and factors[0] == (None, None)
+    for blk, (f1, f2) in list(zip(m.blocks, factors))[1:]:
+        k = 1.0 - blk.drop_path.p
+        for f in (f1, f2):
+            assert f.shape == (200000,)
+            vals = torch.unique(f)
+            assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1.0 / k) < 1e-6
+            assert abs(float((f != 0).float().mean()) - k) < 5e-3
+        assert not torch.equal(f1, f2)
+    m.eval()
+    assert PT._stack_factors(m.blocks, keep, x) == [None] * 4
+    m.train()
+    y = m(torch.randn(3, 9, 26, 2))
+    assert y.shape == (3, 1, 26, 3) and torch.isfinite(y).all()
