@@ -11,6 +11,7 @@
 // they are (no transpose copy).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/p2c.h"
 
@@ -75,19 +76,35 @@ __device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*r
 #define P2C_ATB_U 4
 #endif
   constexpr int U = P2C_ATB_U;
-  for (int64_t k = k0; k < kend; k += 4 * U) {
+  // The lane's rows are k0 + kk, + 4, + 8, ...: its two operand pointers and the index of its row's scale factor are CARRIED
+  // from row to row (one division per wave, then add / compare), and whole steps of 4 U rows run without per-row tests. (With
+  // the row product, the 64-bit division `row / rows_per_scale` and a branch per row inside the loop, a step of the scaled form
+  // was ~660 scalar + vector instructions around its 16 MFMAs.)
+  const bool scaled = a.a_scale != nullptr;
+  const int64_t rps = scaled ? a.rows_per_scale : 1;
+  int64_t sidx = (k0 + kk) / rps, srem = (k0 + kk) % rps;
+  const int64_t sq4 = 4 / rps, sr4 = 4 % rps;
+  const float *pa = ap + (k0 + kk) * a.lda, *pb = bp + (k0 + kk) * a.ldb;
+  const int64_t sa = 4 * a.lda, sb = 4 * a.ldb;
+  // (whole: every lane of the workgroup takes the 8-byte loads -- the block lies inside both matrices -- so nothing in the
+  // step depends on the lane but the addresses)
+  auto step = [&](auto guarded, auto whole, int64_t k) {
     f32x2 av[U], bv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t row = k + 4 * u + kk;
-      const bool ok = row < kend;
+      const bool ok = !decltype(guarded)::value || k + 4 * u + kk < kend;
       av[u] = (f32x2){0.f, 0.f}, bv[u] = (f32x2){0.f, 0.f};
       if (ok) {
-        if (vec_a) av[u] = *reinterpret_cast<const f32x2 *>(ap + row * a.lda);
-        else av[u] = (f32x2){col(ap, row * a.lda, m, a.M, false), col(ap, row * a.lda + 1, m + 1, a.M, false)};
-        if (a.a_scale) av[u] *= a.a_scale[row / a.rows_per_scale];
-        if (vec_b) bv[u] = *reinterpret_cast<const f32x2 *>(bp + row * a.ldb);
-        else bv[u] = (f32x2){col(bp, row * a.ldb, n, a.N, a.ones != 0), col(bp, row * a.ldb + 1, n + 1, a.N, a.ones != 0)};
+        if (decltype(whole)::value || vec_a) av[u] = *reinterpret_cast<const f32x2 *>(pa);
+        else av[u] = (f32x2){col(pa, 0, m, a.M, false), col(pa, 1, m + 1, a.M, false)};
+        if (scaled) av[u] *= a.a_scale[sidx];
+        if (decltype(whole)::value || vec_b) bv[u] = *reinterpret_cast<const f32x2 *>(pb);
+        else bv[u] = (f32x2){col(pb, 0, n, a.N, a.ones != 0), col(pb, 1, n + 1, a.N, a.ones != 0)};
+      }
+      pa += sa, pb += sb;
+      if (scaled) {
+        sidx += sq4, srem += sr4;
+        if (srem >= rps) srem -= rps, ++sidx;
       }
     }
 #pragma unroll
@@ -102,6 +119,16 @@ __device__ __forceinline__ void atb_body(const Args &a, const int bid, f32x4 (*r
         for (int h = 0; h < 2; ++h) accb[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][h], onev, accb[h], 0, 0, 0);
       }
     }
+  };
+  const bool whole = mb * 32 + 32 <= a.M && nb * 32 + 32 <= a.N && ((a.lda | a.ldb) & 1) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 7) == 0;
+  int64_t k = k0;
+  if (whole) {
+    for (; k + 4 * U <= kend; k += 4 * U) step(std::false_type{}, std::true_type{}, k);
+    if (k < kend) step(std::true_type{}, std::true_type{}, k);
+  } else {
+    for (; k + 4 * U <= kend; k += 4 * U) step(std::false_type{}, std::false_type{}, k);
+    if (k < kend) step(std::true_type{}, std::false_type{}, k);
   }
 #pragma unroll
   for (int h = 0; h < 2; ++h)
