@@ -228,6 +228,11 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
     rsa = operand_rsrc(d.a, d.K, d.lda, d.M), rsb = operand_rsrc(d.b, d.K, d.ldb, d.N);
     oa = kn_offsets<BM>(d.lda, m0, d.M, (int)threadIdx.x), ob = kn_offsets<BN>(d.ldb, n0, d.N, (int)threadIdx.x);
   }
+  // index of a row's factor: below 2^21 rows floor((k + 0.5) / rows_per_scale) in fp32 is exact (the quotient's rounding error,
+  // q * 2^-22, stays below the 0.5 / rows_per_scale that separates it from the next integer): three instructions instead of the
+  // ~35 of an integer division, four times per k-tile and thread
+  const bool fdiv = d.K <= (1 << 21);
+  const float inv_rps = d.row_scale ? 1.f / (float)d.rows_per_scale : 0.f;
   auto fetch = [&](int kt) {
     if (FAST) load_pieces<KnMap<BM>::PIECES>(rsa, oa, (int)((k_begin + kt * BK) * d.lda * 4), ra);
     else load_kn<BM, VEC>(d.a, d.lda, k_begin + kt * BK, k_end, m0, d.M, ra, (int)threadIdx.x);
@@ -235,7 +240,8 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
 #pragma unroll
       for (int i = 0; i < KnMap<BM>::PIECES; ++i) {
         const int k = k_begin + kt * BK + KnMap<BM>::row(i, (int)threadIdx.x);
-        ra.v[i] *= k < k_end ? d.row_scale[k / d.rows_per_scale] : 0.f;
+        const int idx = fdiv ? (int)(((float)k + 0.5f) * inv_rps) : k / d.rows_per_scale;
+        ra.v[i] *= (FAST || k < k_end) ? d.row_scale[idx] : 0.f;
       }
     }
     if (FAST) load_pieces<KnMap<BN>::PIECES>(rsb, ob, (int)((k_begin + kt * BK) * d.ldb * 4), rb);
