@@ -24,4 +24,9 @@ done
 echo "head pmc done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg5_trace" -- python3 tools/bench_poseformer.py 32 5 > "$OUT/cfg5_trace.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/cfg3_trace" -- python3 tools/bench_seq2seq.py 512 30 graph > "$OUT/cfg3_trace.log" 2>&1 || exit 1
+
+# K16 at 21 024 x 2 496 x 832 (NT, NN, TN) beside the library: MFMA-busy cycles and the instruction mix, two separate passes
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_gemm_MFMA" -- python3 tools/gemm_pmc.py > "$OUT/pmc_gemm_MFMA.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_MFMA --output-format csv -d "$OUT/pmc_gemm_INSTS" -- python3 tools/gemm_pmc.py > "$OUT/pmc_gemm_INSTS.log" 2>&1 || exit 1
+echo "gemm pmc done"
 echo "all done"
