@@ -347,6 +347,48 @@ __global__ __launch_bounds__(256) void tn_finish_kernel(const TnArgs d) {
     __syncthreads();
   }
 }
+// More than eight slabs with 16-byte-aligned outputs: the eight-part scheme of tn_finish_kernel on FOUR neighbouring outputs per
+// thread (same order of additions per output, so the same bits; a quarter of the load instructions).
+__device__ __forceinline__ f32x4 tn_slab_sum4(const float *ws, int64_t stride, int64_t i, int slices, int part) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int s = part;
+  for (; s + 56 < slices; s += 64) {
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const f32x4 *>(ws + (int64_t)(s + 8 * u) * stride + i);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; s < slices; s += 8) v += *reinterpret_cast<const f32x4 *>(ws + (int64_t)s * stride + i);
+  return v;
+}
+__global__ __launch_bounds__(256) void tn_finish_vec8_kernel(const TnArgs d) {
+  __shared__ f32x4 red[8][33];
+  const int64_t total = (int64_t)d.M * d.N, nv = total >> 2, n_all = nv + (d.bias ? d.M : 0);
+  const int e = threadIdx.x & 31, part = threadIdx.x >> 5;
+  for (int64_t base = (int64_t)blockIdx.x * 32; base < n_all; base += (int64_t)gridDim.x * 32) {
+    const int64_t j = base + e;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (j < nv) v = tn_slab_sum4(d.ws, total, j * 4, d.slices, part);
+    else if (j < n_all) v[0] = tn_slab_sum(d.ws_bias, d.M, j - nv, d.slices, part);
+    red[part][e] = v;
+    __syncthreads();
+    if (part == 0 && j < n_all) {
+      f32x4 t = red[0][e];
+#pragma unroll
+      for (int p = 1; p < 8; ++p) t += red[p][e];
+      if (j < nv) {
+        const int64_t i = j * 4;
+        f32x4 *o = reinterpret_cast<f32x4 *>(d.c + (i / d.N) * d.ldc + (i % d.N));
+        *o = d.accumulate ? *o + t : t;
+      } else {
+        float *o = d.bias + (j - nv);
+        *o = d.bias_accumulate ? *o + t[0] : t[0];
+      }
+    }
+    __syncthreads();
+  }
+}
 // Few slices (the wide layers: 2 .. 8 slabs of up to 2 M outputs each): a thread owns FOUR neighbouring outputs and adds their
 // slabs in slice order from 16-byte loads, all of them in flight at once -- the same sums, bit for bit, as the eight-part form
 // above gives for <= 8 slices (each part holds one slab), at the rate of a streaming pass instead of 4-byte loads by a
@@ -873,9 +915,12 @@ extern "C" int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t 
 #undef P2C_TN
   const int64_t total = (int64_t)M * N;
   const int64_t n_all = total + (bias_out ? M : 0);
-  if (d.slices <= 8 && N % 4 == 0 && ldc % 4 == 0 && al(c) && al(workspace)) {
+  if (N % 4 == 0 && ldc % 4 == 0 && al(c) && al(workspace)) {
     const int64_t n_thr = total / 4 + (bias_out ? M : 0);
-    hipLaunchKernelGGL(tn_finish_vec_kernel, dim3((unsigned)((n_thr + 255) / 256 < 65536 ? (n_thr + 255) / 256 : 65536)), dim3(256), 0, s, d);
+    if (d.slices <= 8)
+      hipLaunchKernelGGL(tn_finish_vec_kernel, dim3((unsigned)((n_thr + 255) / 256 < 65536 ? (n_thr + 255) / 256 : 65536)), dim3(256), 0, s, d);
+    else
+      hipLaunchKernelGGL(tn_finish_vec8_kernel, dim3((unsigned)((n_thr + 31) / 32 < 65536 ? (n_thr + 31) / 32 : 65536)), dim3(256), 0, s, d);
   } else {
     hipLaunchKernelGGL(tn_finish_kernel, dim3((unsigned)((n_all + 31) / 32 < 65536 ? (n_all + 31) / 32 : 65536)), dim3(256), 0, s, d);
   }
