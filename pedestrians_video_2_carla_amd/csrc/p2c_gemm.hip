@@ -956,7 +956,7 @@ extern "C" int p2c_gemm(const p2c_gemm_desc *desc, void *stream_) {
   // (another 3..5 %) and for N <= 32. Small problems (the 8 192-row projections around the Seq2Seq recurrences) take the
   // narrowest tile to reach more CUs. P2C_GEMM_BN forces one (experiments; the 128-column instantiation stays reachable).
   int bn = d.N > 32 ? 64 : 32;
-  if (!d.trans_b && d.K >= 256) bn = 32;
+  if (!d.trans_b && d.K >= 256 && d.K < 2048) bn = 32;      // (with the buffer-load fetch the 64-column tile is ahead again from K ~ 2 000: 687 vs 714 us at 832 x 2 496)
   const int64_t row_tiles = (d.M + BM - 1) / BM;
   while (bn > 32 && row_tiles * ((d.N + bn - 1) / bn) < 512) bn >>= 1;
   // shallow products (K <= 128: the spatial blocks' 546 624 x 96 x 32) stream A and C once and are bound by that: the tile that
