@@ -424,7 +424,9 @@ __global__ __launch_bounds__(256) void tn_finish_vec_kernel(const TnArgs d) {
 // its own basic block of ~150 instructions (the tests, a 64-bit row product per pointer, an integer division for the row
 // scale): 5 000 instructions per wave, 50 k cycles = 15 % of a workgroup's life at 21 024 x 2 496 x 832 (tools/gemmtrace.py).
 // Here a row's pointers and its scale are formed once and serve the TN columns.
-template <int ACT, bool SCALE, bool RES, bool FULL, int TM, int TN>
+// SCALE / RES: 0 = absent, 1 = present, 2 = looked up at run time (the activation forms: their erf dominates the code anyway, and
+// sixteen copies of it per kernel were most of this file's compile time)
+template <int ACT, int SCALE, int RES, bool FULL, int TM, int TN>
 __device__ __forceinline__ void epilogue_rows(const p2c_gemm_desc &d, const f32x16 (&acc)[TM][TN], int mw, int nw, int li, int lk) {
   int n[TN];
   bool nok[TN];
@@ -436,6 +438,7 @@ __device__ __forceinline__ void epilogue_rows(const p2c_gemm_desc &d, const f32x
     bias[b] = (d.bias && nok[b]) ? d.bias[n[b]] : 0.f;
   }
   float *const zbase = (ACT == 1) ? d.aux_out : nullptr;
+  const bool scale = SCALE == 1 || (SCALE == 2 && d.row_scale != nullptr), res = RES == 1 || (RES == 2 && d.residual != nullptr);
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -443,10 +446,10 @@ __device__ __forceinline__ void epilogue_rows(const p2c_gemm_desc &d, const f32x
       const int m = mw + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
       if (!FULL && m >= d.M) continue;
       float *const crow = d.c + (int64_t)m * d.ldc;
-      const float *const rrow = RES ? d.residual + (int64_t)m * d.ldr : nullptr;
+      const float *const rrow = res ? d.residual + (int64_t)m * d.ldr : nullptr;
       const float *const xrow = (ACT == 2) ? d.aux + (int64_t)m * d.ldaux : nullptr;
       float *const zrow = (ACT == 1 && zbase) ? zbase + (int64_t)m * d.ldaux : nullptr;
-      const float rs = SCALE ? d.row_scale[(unsigned)m / (unsigned)d.rows_per_scale] : 1.f;
+      const float rs = scale ? d.row_scale[(unsigned)m / (unsigned)d.rows_per_scale] : 1.f;
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
         if (!nok[b]) continue;
@@ -457,19 +460,23 @@ __device__ __forceinline__ void epilogue_rows(const p2c_gemm_desc &d, const f32x
         } else if (ACT == 2) {
           v *= gelu_grad(xrow[n[b]]);
         }
-        if (SCALE) v *= rs;
-        if (RES) v += rrow[n[b]];
+        if (scale) v *= rs;
+        if (res) v += rrow[n[b]];
         crow[n[b]] = v;
       }
     }
 }
 template <int ACT, bool FULL, int TM, int TN>
 __device__ __forceinline__ void epilogue_terms(const p2c_gemm_desc &d, const f32x16 (&acc)[TM][TN], int mw, int nw, int li, int lk) {
+  if (ACT != 0) {
+    epilogue_rows<ACT, 2, 2, FULL>(d, acc, mw, nw, li, lk);
+    return;
+  }
   const bool scale = d.row_scale != nullptr, res = d.residual != nullptr;
-  if (scale && res) epilogue_rows<ACT, true, true, FULL>(d, acc, mw, nw, li, lk);
-  else if (scale) epilogue_rows<ACT, true, false, FULL>(d, acc, mw, nw, li, lk);
-  else if (res) epilogue_rows<ACT, false, true, FULL>(d, acc, mw, nw, li, lk);
-  else epilogue_rows<ACT, false, false, FULL>(d, acc, mw, nw, li, lk);
+  if (scale && res) epilogue_rows<ACT, 1, 1, FULL>(d, acc, mw, nw, li, lk);
+  else if (scale) epilogue_rows<ACT, 1, 0, FULL>(d, acc, mw, nw, li, lk);
+  else if (res) epilogue_rows<ACT, 0, 1, FULL>(d, acc, mw, nw, li, lk);
+  else epilogue_rows<ACT, 0, 0, FULL>(d, acc, mw, nw, li, lk);
 }
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue(const p2c_gemm_desc &d, const f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn, int li, int lk) {
@@ -603,6 +610,7 @@ __global__ __launch_bounds__(NTH, BN == 128 ? 3 : (BN == 64 ? 5 : 6)) void gemm_
   GT(61);
 }
 
+#ifdef P2C_GEMM_EXPERIMENTS   // the two measured-and-shelved variants below: make EXTRA=-DP2C_GEMM_EXPERIMENTS (a third of this file's compile time)
 // ---- the same 128 x 64 tile on v_mfma_f32_16x16x4_f32 (round 3 experiment: P2C_GEMM_MI16=1): a wave's 32 x 64 block as 2 x 4
 // tiles of 16 x 16 (eight f32x4 accumulators), k advances by 4 per step: six LDS dwords feed eight MFMAs of 32 cycles. Same
 // FLOP per cycle as 32 x 32 x 2; what it tests is whether the instruction shape matters for the sustained rate (the library's
@@ -811,9 +819,12 @@ __global__ __launch_bounds__(2 * NTH, 2) void gemm_ws_kernel(const p2c_gemm_desc
   epilogue<TM, TN>(d, acc, m0, n0, wm, wn, li, lk);
 }
 
+#endif  // P2C_GEMM_EXPERIMENTS
+
 template <int BN, bool TRANS_B>
 static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
   const unsigned grid = xcd_grid((int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN));
+#ifdef P2C_GEMM_EXPERIMENTS
   static const int ws_mode = getenv("P2C_GEMM_WS") ? atoi(getenv("P2C_GEMM_WS")) : 0;
   static const int mi16 = getenv("P2C_GEMM_MI16") ? atoi(getenv("P2C_GEMM_MI16")) : 0;
   if (mi16 && vec && BN == 64) {
@@ -824,6 +835,7 @@ static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
     hipLaunchKernelGGL((gemm_ws_kernel<BN, TRANS_B, true>), dim3(grid), dim3(2 * NTH), 0, s, d);
     return;
   }
+#endif
   static const int no_fast = getenv("P2C_GEMM_NO_FAST") ? atoi(getenv("P2C_GEMM_NO_FAST")) : 0;      // (A/B timing)
   const int64_t a_bytes = ((int64_t)(d.M - 1) * d.lda + d.K) * 4;
   const int64_t b_bytes = (TRANS_B ? (int64_t)(d.N - 1) * d.ldb + d.K : (int64_t)(d.K - 1) * d.ldb + d.N) * 4;
