@@ -580,7 +580,7 @@ def extra_config(device, name, steps=100, warmup=10):
         out['shared_spatial_bf16'] = arm(share_spatial=True, compute_dtype=torch.bfloat16)
         out['note'] = ('transformer arithmetic parity-unpinned (third-party source absent); attention = K14 (p2c_attn_small), LayerNorm = '
                        'K15 (p2c_layernorm), every dense layer = K16 (p2c_gemm / p2c_gemm_tn: fp32 MFMA with bias / GELU / '
-                       'stochastic-depth factor / residual in the epilogue; no library GEMM in the step), narrow weight gradients = K12; '
+                       'stochastic-depth factor / residual in the epilogue, 110-130 TFLOP/s at the temporal shapes; no library GEMM in the step), narrow weight gradients = K12; '
                        'a block is one autograd node. The four temporal blocks are 2.8 TFLOP per step = 17.8 ms at the fp32 MFMA '
                        'peak; the pose head is the HIP absolute_loc kernel; stochastic depth (0.2) on')
         out['windows_per_step'] = B * (81 - 9 + 1)
