@@ -324,6 +324,26 @@ def recurrence_times(device, B, T=T_FRAMES, H=64, O=52):
     return out, flops
 
 
+def gemm_times(device, rows=2336 * 9, width=832):
+    """Device time of K16 at the shapes of one temporal PoseTransformer block (cfg5: 2 336 windows x 9 frame tokens, 832
+    features), graph-timed through ops.gemm / ops.gemm_tn: the qkv layer forward (NT), its input gradient (NN) and its weight
+    gradient (TN, both launches), each with its 2 M N K flop."""
+    from pedestrians_video_2_carla_amd import ops
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x = torch.randn(rows, width, generator=g).to(device)
+    w = torch.randn(3 * width, width, generator=g).to(device)
+    gy = torch.randn(rows, 3 * width, generator=g).to(device)
+    y, gx, gw = torch.empty(rows, 3 * width, device=device), torch.empty(rows, width, device=device), torch.empty(3 * width, width, device=device)
+    out = {}
+    stream = torch.cuda.Stream(device=device)
+    with torch.cuda.stream(stream):
+        out['K16 NT qkv forward (21024 x 2496 x 832)'] = _graph_us(lambda: ops.gemm(x, w, True, out=y), stream, reps=5, rounds=3)
+        out['K16 NN qkv input gradient (21024 x 832 x 2496)'] = _graph_us(lambda: ops.gemm(gy, w, False, out=gx), stream, reps=5, rounds=3)
+        out['K16 TN qkv weight gradient (2496 x 832 from 21024 rows; slabs + sum)'] = _graph_us(lambda: ops.gemm_tn(gy, x, out=gw), stream, reps=5, rounds=3)
+    flops = {k: 2.0 * rows * width * 3 * width for k in out}
+    return out, flops
+
+
 def mfma_entry(name, B, us, flops):
     achieved = flops / (us * 1e-6) / 1e12
     return {'kernel': name, 'B': B, 'us_per_launch': round(us, 2), 'bound': 'mfma', 'achieved': round(achieved, 3),
@@ -584,6 +604,11 @@ def extra_config(device, name, steps=100, warmup=10):
                        'a block is one autograd node. The four temporal blocks are 2.8 TFLOP per step = 17.8 ms at the fp32 MFMA '
                        'peak; the pose head is the HIP absolute_loc kernel; stochastic depth (0.2) on')
         out['windows_per_step'] = B * (81 - 9 + 1)
+        try:
+            gt, gflops = gemm_times(device)
+            out['roofline'] = [mfma_entry(k, B, gt[k], fl) for k, fl in gflops.items()]
+        except Exception as e:                                      # noqa: BLE001 -- evidence beside the step time, not the step
+            out['roofline'] = {'error': repr(e)[:200]}
     else:
         # the recurrences (K7b encoder layers, K7c decoder loop) priced against the fp32 MFMA peak: 2*T*B*H*4H flop per
         # LSTM layer and direction of the data flow (forward; the backward kernels do the same again with W^T)
