@@ -266,6 +266,16 @@ P2C_API int p2c_train_step(const p2c_train_step_desc *desc, const float *const g
  * step), 3: both (= p2c_train_step). bench.py times the launches one by one with it. */
 P2C_API int p2c_train_step_launch(const p2c_train_step_desc *desc, const float *const grad_losses[3], int32_t which,
                                   void *stream);
+/* The first launch has two forms: one workgroup of eight wavefronts per clip (latency form, about one clip per CU) and one
+ * wavefront per clip with the weight image shared by four (throughput form, csrc/p2c_train_stream.hip), taken from min_b clips
+ * on when the descriptor allows it (identity joint maps, CARLA targets, no world motion). Returns the previous threshold;
+ * min_b < 0 only queries. Default 512 (env P2C_STREAM_MIN_B). Both leave the same factor blocks for the second launch. */
+P2C_API int p2c_train_step_set_stream_min_batch(int32_t min_b);
+/* The second launch has two forms as well: a workgroup per dW tile and clip slice with the combine, the optimizer and the loss
+ * reduction in the same launch (few hundred clips), and -- from min_b clips on (default 2048, env P2C_WGRAD_STREAM_MIN_B) -- a
+ * persistent workgroup per clip slice that reads every factor block once and holds all 79 tiles, followed by a third launch
+ * that adds the per-workgroup partials in a fixed order (+ optimizer + losses). Returns the previous threshold. */
+P2C_API int p2c_train_step_set_wgrad_stream_min_batch(int32_t min_b);
 /* counts[b] = number of (frame, joint) pairs of clip b inside [t0, t1) whose 2-D target the loss does not mask
  * (utils/tensors.py:29-40 via loss/base_pose_loss.py:36-66): reads only the target-side fields of desc (gt2d, gmap2d,
  * hips_lane, mask_missing_joints, t0, t1); y / partials / losses may be NULL. One launch. */

@@ -175,6 +175,8 @@ SYMBOLS = {
     'p2c_train_step': (ctypes.c_int, [ctypes.POINTER(TrainStepDesc), ctypes.POINTER(_vp * 3), _vp]),
     'p2c_train_step_launch': (ctypes.c_int, [ctypes.POINTER(TrainStepDesc), ctypes.POINTER(_vp * 3), _i32, _vp]),
     'p2c_count_target_pairs': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), _vp, _vp]),
+    'p2c_train_step_set_stream_min_batch': (ctypes.c_int, [ctypes.c_int32]),
+    'p2c_train_step_set_wgrad_stream_min_batch': (ctypes.c_int, [ctypes.c_int32]),
 }
 
 _lib = None

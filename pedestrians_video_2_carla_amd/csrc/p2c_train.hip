@@ -33,13 +33,23 @@
 #include "p2c_adam_math.h"
 #include "p2c_mlp_dev.h"
 #include "p2c_pose_head_dev.h"
+#include "p2c_train_dev.h"
 
 int p2c_internal_validate_pose_head(const p2c_pose_head_desc *d);   // p2c_pose_head.hip
 
 namespace p2c_train {
 
-using namespace p2c_mlp;
-namespace ph = p2c;
+constexpr int T_MAX = TS;                    // one clip = one sample tile
+constexpr int PLANE = T_MAX * ph::GROUP * 9; // one plane of the cumulative-rotation scan (floats)
+constexpr int H_ROWS = S::h_off(NLAY);       // rows of H_0 .. H_{L-1}
+constexpr int G_ROWS = S::act_rows() - S::h_off(1);   // rows of G_1 .. G_L
+constexpr int ACT_FLOATS = (H_ROWS + G_ROWS) * TP;
+static_assert((S::h_off(NLAY) - S::h_off(1)) * TP >= PLANE, "scan plane 1 aliases the rows of G_1 .. G_{L-1}");
+static_assert(S::dim_at(NLAY) == ph::J * 6, "the last layer is the (26, 6) rotation output");
+constexpr int SCRATCH = 64;
+constexpr int LDS_FLOATS = S::w_total() + ACT_FLOATS + PLANE + SCRATCH;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
 
 #ifdef P2C_TRAIN_TRACE   // developer build only (tools/traintrace.py): shader-clock stamps of one workgroup per kernel
 static __device__ unsigned long long g_ttrace[2][40];
@@ -72,33 +82,6 @@ static __device__ unsigned long long g_ttrace[2][40];
 #define TB(i)
 #define TB_DUMP(cond)
 #endif
-
-using S = LinearAE156;                       // 52 -> 26 -> 13 -> 6 -> 39 -> 78 -> 156 (linear_ae.py:25-40, 6-D output)
-constexpr int NLAY = S::NLAY;
-constexpr int T_MAX = TS;                    // one clip = one sample tile
-constexpr int PLANE = T_MAX * ph::GROUP * 9; // one plane of the cumulative-rotation scan (floats)
-constexpr int H_ROWS = S::h_off(NLAY);       // rows of H_0 .. H_{L-1}
-constexpr int G_ROWS = S::act_rows() - S::h_off(1);   // rows of G_1 .. G_L
-constexpr int ACT_FLOATS = (H_ROWS + G_ROWS) * TP;
-static_assert((S::h_off(NLAY) - S::h_off(1)) * TP >= PLANE, "scan plane 1 aliases the rows of G_1 .. G_{L-1}");
-static_assert(S::dim_at(NLAY) == ph::J * 6, "the last layer is the (26, 6) rotation output");
-constexpr int SCRATCH = 64;
-constexpr int LDS_FLOATS = S::w_total() + ACT_FLOATS + PLANE + SCRATCH;
-static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
-
-// factor block of one clip: rows [H_0 .. H_{L-1} | G_1 .. G_L], 16 samples (64 B) per row
-__host__ __device__ constexpr int f_h_off(int l) {
-  int r = 0;
-  for (int i = 0; i < l; ++i) r += S::dim_at(i);
-  return r;
-}
-constexpr int F_HALF = f_h_off(NLAY);
-__host__ __device__ constexpr int f_g_off(int l) {
-  int r = F_HALF;
-  for (int i = 1; i < l; ++i) r += S::dim_at(i);
-  return r;
-}
-constexpr int F_ROWS = f_g_off(NLAY) + S::dim_at(NLAY);
 
 // geometry of the packed weight image for a layer index known only at run time
 __device__ __forceinline__ int image_w_off(int l) {
@@ -137,15 +120,6 @@ __device__ __forceinline__ ph::M3 scan_time2(ph::M3 P, int t, int j, int T, floa
   return P;
 }
 
-struct ClipArgs {
-  const float *x;          // (B*T, 52) model input
-  const float *w_image;    // packed weight image (p2c_mlp_pack layout), current
-  const float *counts;     // (B) unmasked 2-D target pairs per clip
-  float *factors;          // (B, F_ROWS, 16)
-  int32_t *counters;       // arrival tickets of the second launch: zeroed here
-  int32_t n_counters;
-  int32_t identity_maps;   // gmap2d[j] == gmap3d[j] == j for every joint (host-checked)
-};
 
 // ---- the weight image by LDS-DMA (round 3 experiment, OFF: build with EXTRA=-DP2C_TRAIN_DMA_IMAGE=1) ------------------------
 // The 70 KB image is a straight copy HBM -> LDS; staged through registers (stage_issue / stage_commit, K8) it arrives at
@@ -616,6 +590,219 @@ __global__ __launch_bounds__(64 * WG_WAVES) void train_wgrad_kernel(const WgradA
   TB_DUMP(t == P2C_TRAIN_TRACE_TILE);
 }
 
+// ---- second launch, throughput form (large batches): stream every clip's factor block ONCE ------------------------------------
+// train_wgrad_kernel gives every dW tile its own workgroups: each reads the two 1 KB operand blocks of its tile from every
+// clip -- 158 KB per clip in all for a 34 KB factor block. That is the right trade at a few hundred clips (632 workgroups,
+// every CU busy, one launch incl. the optimizer); at thousands of clips the launch is bound by that redundant operand
+// traffic (B = 8192: 114 us for 8.7 GFLOP). Here a persistent workgroup owns ALL 79 tiles for a strided slice of the clips:
+// its eight waves split the tiles in dense blocks of (G row-tiles) x (H row-tiles) -- waves 0-4 two of layer 5's ten
+// n-tiles against its five m-tiles each (ten accumulators from seven 16-byte loads per lane and clip), wave 5 / 6 layer 4
+// (+ layer 3), wave 7 layers 0-2 -- so a clip's factors cross HBM once, the accumulators stay in registers over the whole
+// slice, and a workgroup leaves one 79 KB partial. wgrad_reduce_kernel adds the partials in workgroup order (fixed: bitwise
+// reproducible), applies AdamW, refreshes the weight image and finishes the losses.
+constexpr int WS_BLOCKS_MAX = 256;
+struct RowBlock {          // one dense block: n-tiles [n0, n0 + NA) x m-tiles [0, NB) of layer l; its first dW tile index
+  int l, n0, na, nb, tile0;
+};
+template <int NA, int NB>
+__device__ __forceinline__ void wgrad_block(const WgradArgs &a, const RowBlock rb, const int first, const int step, const int lane,
+                                            f32x4 (&acc)[NA * NB]) {
+  const int r = lane & 15, k = lane >> 4;
+  int32_t dd[NLAY + 1];
+#pragma unroll
+  for (int i = 0; i <= NLAY; ++i) dd[i] = S::dim_at(i);
+  const int n_in = dd[rb.l], n_out = dd[rb.l + 1];
+  int g_row = F_HALF, h_row = 0;                               // first factor row of G_{l+1} / H_l
+  for (int i = 1; i <= rb.l; ++i) g_row += dd[i];
+  for (int i = 0; i < rb.l; ++i) h_row += dd[i];
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, ones = {1.f, 1.f, 1.f, 1.f};
+  size_t a_off[NA], b_off[NB];
+  bool a_ok[NA], b_ok[NB], b_one[NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int n = (rb.n0 + i) * 16 + r;
+    a_ok[i] = n < n_out, a_off[i] = (size_t)(g_row + (a_ok[i] ? n : 0)) * 16 + 4 * k;
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int mm = j * 16 + r;
+    b_ok[j] = mm < n_in, b_one[j] = mm == n_in, b_off[j] = (size_t)(h_row + (b_ok[j] ? mm : 0)) * 16 + 4 * k;
+  }
+#pragma unroll
+  for (int i = 0; i < NA * NB; ++i) acc[i] = zero;
+  const size_t f_tile = (size_t)F_ROWS * 16;
+  auto load = [&](int st, f32x4 (&av)[NA], f32x4 (&bv)[NB]) {      // unconditional loads from clamped rows, selected afterwards
+    const float *f = a.factors + (size_t)st * f_tile;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) av[i] = *reinterpret_cast<const f32x4 *>(f + a_off[i]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[j] = *reinterpret_cast<const f32x4 *>(f + b_off[j]);
+  };
+  auto fma = [&](const f32x4 (&av_)[NA], const f32x4 (&bv_)[NB]) {
+    f32x4 av[NA], bv[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) av[i] = a_ok[i] ? av_[i] : zero;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[j] = b_one[j] ? ones : (b_ok[j] ? bv_[j] : zero);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i * NB + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u], bv[j][u], acc[i * NB + j], 0, 0, 0);
+  };
+  // DEPTH clips in flight per wave (a ring of register sets): behind every clip's MFMAs the loads of the clip DEPTH steps ahead
+  // go out -- with one clip of look-ahead the loop ran at one HBM round trip per clip (B = 8192: 93 us for 35 us of MFMA)
+  constexpr int DEPTH = (NA + NB) * 4 * 6 <= 176 ? 6 : 5;
+  f32x4 ar[DEPTH][NA], br[DEPTH][NB];
+  const int last = a.n_stiles - 1;
+  // (every load is unconditional, from a clamped clip: a load inside a branch makes the compiler drain the queue at the join;
+  // what a set holds beyond the slice is never multiplied)
+#pragma unroll
+  for (int dth = 0; dth < DEPTH; ++dth) {
+    const int cl = first + dth * step;
+    load(cl < last ? cl : last, ar[dth], br[dth]);
+  }
+  int st = first;
+  for (; st + (2 * DEPTH - 1) * step < a.n_stiles; st += DEPTH * step) {      // steady state: no tests inside
+#pragma unroll
+    for (int dth = 0; dth < DEPTH; ++dth) {
+      fma(ar[dth], br[dth]);
+      load(st + (dth + DEPTH) * step, ar[dth], br[dth]);
+    }
+  }
+  for (; st < a.n_stiles; st += DEPTH * step) {                               // the last one or two rounds
+#pragma unroll
+    for (int dth = 0; dth < DEPTH; ++dth) {
+      const int cur = st + dth * step, nxt = cur + DEPTH * step;
+      if (cur < a.n_stiles) fma(ar[dth], br[dth]);
+      load(nxt < last ? nxt : last, ar[dth], br[dth]);
+    }
+  }
+  // the block's partial tiles, in MFMA C layout (one 16-byte store per lane and tile)
+  f32x4 *out = reinterpret_cast<f32x4 *>(a.slices) + ((size_t)blockIdx.x * a.n_tiles_w + rb.tile0) * 64 + lane;
+  const int mtiles = (n_in + 1 + 15) >> 4;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) out[(size_t)(i * mtiles + j) * 64] = acc[i * NB + j];
+}
+
+__global__ __launch_bounds__(64 * WG_WAVES) void wgrad_stream_kernel(const WgradArgs a) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int first = blockIdx.x, step = gridDim.x;      // clips b, b + grid, ...: those written on this XCD (grid = 0 mod 8)
+  // tile index of (layer l, n-tile n, m-tile 0): layers 0..5 hold 8, 2, 1, 3, 15, 50 tiles
+  constexpr int T0 = 0, T1 = 8, T2 = 10, T3 = 11, T4 = 14, T5 = 29;
+  if (wave < 5) {
+    f32x4 acc[10];
+    wgrad_block<2, 5>(a, RowBlock{5, 2 * wave, 2, 5, T5 + 2 * wave * 5}, first, step, lane, acc);
+  } else if (wave == 5) {
+    f32x4 acc[9];
+    wgrad_block<3, 3>(a, RowBlock{4, 0, 3, 3, T4}, first, step, lane, acc);
+  } else if (wave == 6) {
+    {
+      f32x4 acc[6];
+      wgrad_block<2, 3>(a, RowBlock{4, 3, 2, 3, T4 + 9}, first, step, lane, acc);
+    }
+    {
+      f32x4 acc[3];
+      wgrad_block<3, 1>(a, RowBlock{3, 0, 3, 1, T3}, first, step, lane, acc);
+    }
+  } else {
+    {
+      f32x4 acc[8];
+      wgrad_block<2, 4>(a, RowBlock{0, 0, 2, 4, T0}, first, step, lane, acc);
+    }
+    {
+      f32x4 acc[2];
+      wgrad_block<1, 2>(a, RowBlock{1, 0, 1, 2, T1}, first, step, lane, acc);
+    }
+    {
+      f32x4 acc[1];
+      wgrad_block<1, 1>(a, RowBlock{2, 0, 1, 1, T2}, first, step, lane, acc);
+    }
+  }
+}
+
+// grad = sum over the stream kernel's workgroups of their partial tiles, in workgroup order; the optimizer step and the packed
+// image ride on it (= mlp_reduce_kernel of p2c_mlp.hip on this launch's arguments); the extra workgroup finishes the losses
+constexpr int RED_G = 32, RED_L = 8;     // groups of partials added in parallel (256 partials: one round of eight loads per thread); lanes of a tile per workgroup
+template <bool ADAM>
+__global__ __launch_bounds__(RED_L * RED_G) void wgrad_reduce_kernel(const WgradArgs a, const int n_blocks, const p2c_adamw_desc o) {
+  __shared__ f32x4 red[RED_G][RED_L];
+  __shared__ p2c_optim::Coefs sc;
+  if ((int)blockIdx.x == a.n_tiles_w * (64 / RED_L)) {
+    __shared__ double fin[3][256];
+    finalize_losses(a, fin);
+    return;
+  }
+  const int t = blockIdx.x / (64 / RED_L), li = threadIdx.x % RED_L, q = threadIdx.x / RED_L;
+  const int lane = (blockIdx.x % (64 / RED_L)) * RED_L + li;
+  float step = 0.f;
+  if (ADAM) {
+    step = *o.step + 1.f;
+    if (threadIdx.x == RED_L * RED_G - 1) sc = p2c_optim::coefs(o, step);
+  }
+  int32_t dd[NLAY + 1];
+#pragma unroll
+  for (int i = 0; i <= NLAY; ++i) dd[i] = S::dim_at(i);
+  const TileRef tr = locate_tile(dd, t);
+  const int n_in = dd[tr.l], n_out = dd[tr.l + 1];
+  const int m = tr.mtile * 16 + (lane & 15);
+  float *gp[4];
+  float pv[4], mv[4], vv[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = tr.ntile * 16 + 4 * (lane >> 4) + r;
+    gp[r] = (q == 0 && n < n_out && m <= n_in) ? ((m < n_in) ? a.gW[tr.l] + n * n_in + m : a.gb[tr.l] + n) : nullptr;
+    pv[r] = mv[r] = vv[r] = 0.f;
+    if (ADAM && gp[r]) {
+      const ptrdiff_t off = gp[r] - o.grad;
+      pv[r] = o.param[off], mv[r] = o.exp_avg[off], vv[r] = o.exp_avg_sq[off];
+    }
+  }
+  const size_t stride = (size_t)a.n_tiles_w * 64;
+  const f32x4 *p = reinterpret_cast<const f32x4 *>(a.slices) + (size_t)t * 64 + lane;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int w = q;
+  for (; w + 7 * RED_G < n_blocks; w += 8 * RED_G) {     // eight loads in flight, added in workgroup order
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(&p[(size_t)(w + u * RED_G) * stride]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; w < n_blocks; w += RED_G) s += __builtin_nontemporal_load(&p[(size_t)w * stride]);
+  red[q][li] = s;
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int i = 1; i < RED_G; ++i) s += red[i][li];
+    p2c_optim::Coefs cf;
+    if (ADAM) cf = sc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (!gp[r]) continue;
+      *gp[r] = (ADAM && o.zero_grad) ? 0.f : s[r];
+      if (ADAM) {
+        const ptrdiff_t off = gp[r] - o.grad;
+        if (o.adamw) p2c_optim::update<true>(cf, pv[r], s[r], mv[r], vv[r]);
+        else p2c_optim::update<false>(cf, pv[r], s[r], mv[r], vv[r]);
+        o.param[off] = pv[r], o.exp_avg[off] = mv[r], o.exp_avg_sq[off] = vv[r];
+        const int n = tr.ntile * 16 + 4 * (lane >> 4) + r;
+        if (a.w_image) a.w_image[image_w_off(tr.l) + n * image_ld(tr.l) + m] = pv[r];
+      }
+    }
+  }
+  if (ADAM) {
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(o.ticket, 1) == a.n_tiles_w * (64 / RED_L) - 1) {
+      *o.step = step;
+      *o.ticket = 0;
+    }
+  }
+}
+
 // per-clip count of the 2-D target pairs the loss will not mask (utils/tensors.py:29-40, loss/loc_2d.py:69-89): a property
 // of the targets alone, computed once per batch
 __global__ __launch_bounds__(256) void count_pairs_kernel(const p2c_pose_head_desc d, float *counts) {
@@ -661,12 +848,41 @@ extern "C" int p2c_train_step_supported(const p2c_train_step_desc *d) {
   return 1;
 }
 
+// batches from which the first launch takes its throughput form (P2C_STREAM_MIN_B; p2c_train_step_set_stream_min_batch)
+static int g_stream_min_b = -1;
+static int stream_min_b() {
+  if (g_stream_min_b < 0) {
+    const char *e = getenv("P2C_STREAM_MIN_B");
+    g_stream_min_b = e ? atoi(e) : 512;
+  }
+  return g_stream_min_b;
+}
+// batches from which the second launch streams the factors once (P2C_WGRAD_STREAM_MIN_B)
+static int g_wgrad_stream_min_b = -1;
+static int wgrad_stream_min_b() {
+  if (g_wgrad_stream_min_b < 0) {
+    const char *e = getenv("P2C_WGRAD_STREAM_MIN_B");
+    g_wgrad_stream_min_b = e ? atoi(e) : 2048;
+  }
+  return g_wgrad_stream_min_b;
+}
+extern "C" P2C_API int p2c_train_step_set_wgrad_stream_min_batch(int32_t min_b) {
+  const int prev = wgrad_stream_min_b();
+  if (min_b >= 0) g_wgrad_stream_min_b = min_b;
+  return prev;
+}
+extern "C" P2C_API int p2c_train_step_set_stream_min_batch(int32_t min_b) {
+  const int prev = stream_min_b();
+  if (min_b >= 0) g_stream_min_b = min_b;
+  return prev;
+}
+
 static constexpr int kClipBlocks = 256;   // CUs of an MI355X: one 156 KB-LDS workgroup each
 static constexpr int kTilesW = 79;    // 16x16 tiles of the augmented weight gradients of LinearAE156 (checked below)
 // workspace: [factors (B, F_ROWS, 16) | slices (KS, tiles, 256) | counters (tiles, padded to 128 ints)]
 extern "C" int64_t p2c_train_step_workspace_floats(const p2c_train_step_desc *d) {
   if (!p2c_train_step_supported(d)) return 0;
-  return (int64_t)d->head.B * F_ROWS * 16 + (int64_t)KS * kTilesW * 256 + 128;
+  return (int64_t)d->head.B * F_ROWS * 16 + (int64_t)WS_BLOCKS_MAX * kTilesW * 256 + 128;   // [factors | partial tiles | tickets]
 }
 
 extern "C" int p2c_count_target_pairs(const p2c_pose_head_desc *desc, float *counts, void *stream_) {
@@ -741,14 +957,18 @@ extern "C" int p2c_train_step_launch(const p2c_train_step_desc *desc, const floa
   for (int l = 0; l < NLAY; ++l) tiles += ((m.dims[l + 1] + 15) / 16) * ((m.dims[l] + 1 + 15) / 16);
   if (tiles != kTilesW) return P2C_E_SHAPE;
   float *slices = m.partials + (size_t)d.B * F_ROWS * 16;
-  int32_t *counters = reinterpret_cast<int32_t *>(slices + (size_t)KS * kTilesW * 256);
+  int32_t *counters = reinterpret_cast<int32_t *>(slices + (size_t)WS_BLOCKS_MAX * kTilesW * 256);
   int identity = 1;
   for (int j = 0; j < P2C_JOINTS; ++j) identity &= (d.gmap2d[j] == j) && (d.gmap3d[j] == j);
   ClipArgs ca{m.x, m.w_image, desc->pair_counts, m.partials, counters, tiles, identity};
   const size_t lds_a = (size_t)LDS_FLOATS * sizeof(float);
   hipError_t e = hipSuccess;
   const dim3 grid_a((unsigned)(d.B < kClipBlocks ? d.B : kClipBlocks));   // persistent: one workgroup per CU walks its clips
-  if (which & 1) {
+  if ((which & 1) && d.B >= stream_min_b() && p2c_internal_train_stream_supported(d)) {
+    // several clips per CU: the throughput form (one wavefront per clip, p2c_train_stream.hip)
+    rc = p2c_internal_train_stream_launch(d, gl, ca, stream);
+    if (rc) return rc;
+  } else if (which & 1) {
     if (d.kind == P2C_KIND_POSE_CHANGES_6D)
       hipLaunchKernelGGL(train_clip_kernel<P2C_KIND_POSE_CHANGES_6D>, grid_a, dim3(64 * WAVES), lds_a, stream, d, gl, ca);
     else
@@ -767,6 +987,20 @@ extern "C" int p2c_train_step_launch(const p2c_train_step_desc *desc, const floa
   wa.n3_elems = (float)((double)d.B * (double)(d.t1 - d.t0) * (double)d.n_common3d * 3.0);
   wa.has2d = d.gt2d ? 1 : 0, wa.has3d = d.gt3d ? 1 : 0;
   wa.loss_sums = d.loss_sums, wa.losses = d.losses;
+  if (d.B >= wgrad_stream_min_b()) {
+    // thousands of clips: every factor block crosses HBM once (wgrad_stream_kernel), the per-workgroup partials are added by a third launch
+    int blocks = d.B / 8;                                         // at least eight clips per workgroup; a multiple of 8 (XCD affinity)
+    blocks = blocks > WS_BLOCKS_MAX ? WS_BLOCKS_MAX : (blocks & ~7);
+    if (blocks < 8) blocks = 8;
+    hipLaunchKernelGGL(wgrad_stream_kernel, dim3((unsigned)blocks), dim3(64 * WG_WAVES), 0, stream, wa);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid_r((unsigned)(tiles * (64 / RED_L) + 1));
+    if (adam) hipLaunchKernelGGL(wgrad_reduce_kernel<true>, grid_r, dim3(RED_L * RED_G), 0, stream, wa, blocks, o);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<false>, grid_r, dim3(RED_L * RED_G), 0, stream, wa, blocks, o);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+  }
   const dim3 grid_b((unsigned)(tiles * KS + 1));
   if (adam) hipLaunchKernelGGL(train_wgrad_kernel<true>, grid_b, dim3(64 * WG_WAVES), 0, stream, wa, o);
   else hipLaunchKernelGGL(train_wgrad_kernel<false>, grid_b, dim3(64 * WG_WAVES), 0, stream, wa, o);

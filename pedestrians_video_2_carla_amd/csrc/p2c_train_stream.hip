@@ -1,0 +1,806 @@
+// p2c_train_stream.hip -- the THROUGHPUT form of the fused train step's first launch (gfx950): one wavefront per clip.
+//
+// What it replaces: the same reference path as p2c_train.hip (modules/flow/pose_lifting.py:121-144 -> LinearAE.forward,
+// linear_ae.py:50-59 -> ProjectionModule, modules/layers/projection.py:73-123 -> transform_callable -> loss/loc_2d_3d.py:6-17
+// -> backward), for batches of SEVERAL clips per CU. train_clip_kernel (p2c_train.hip) spends a whole workgroup of eight
+// wavefronts and 156 KB of LDS on one clip at a time -- the latency form, right at one clip per CU (B = 256) and a queue of
+// dependent 16-sample chains beyond it (B = 1024: four clips per CU back to back, 57 us). Here
+//
+//   * a workgroup is FOUR wavefronts, one per SIMD, each with the whole register file of its SIMD (512 VGPRs) and each walking
+//     its OWN clips start to finish: no workgroup barrier after the prologue;
+//   * the packed weight image (84 KB) sits in LDS once per workgroup (LDS-DMA, one burst) and serves all four;
+//   * a wavefront's activations live in a private 18 KB LDS region, transposed ([feature row][16 frames], pitch 16 = the
+//     layout of the factor blocks train_wgrad_kernel reads: factor rows leave as straight 1 KB copies): H_0 .. H_5
+//     ping-pong through two small buffers, y^T / grad_y^T share the third; the ReLU masks of H_1 .. H_5 are 48 bits per
+//     lane in registers (lane (frame c, group g) of the dgrad meets exactly the elements it produced in the forward);
+//   * the pose head is the chain-lane arithmetic of p2c_pose_head_chain_dev.h with a different unit: eight lanes own
+//     a (clip, time SEGMENT of two frames) and the wavefront's eight segments cover the clip's sixteen frames. The only
+//     couplings between frames become cross-lane scans: the cumulative rotation (projection.py:190-193) an exclusive scan
+//     of 3x3 products over the segments (three ds_bpermute rounds), the backward's suffix sum of torques an add scan.
+//     y never leaves LDS, grad_y is written over it and is the dgrad chain's first operand: no y / grad_y traffic at any B.
+//
+// Leaves what train_clip_kernel leaves: the clip's factor block (H_0 .. H_5 | G_1 .. G_6, 34 KB) and its three loss sums.
+// MLP arithmetic: the same fmaf chains in the same k order as p2c_mlp_dev.h (fp32 MFMA 16x16x4); pose head: the sums over
+// time associate differently (scan instead of a running product) -- parity 1e-4 against the fp64 oracle, not bitwise
+// against the latency form (tests/test_train_fused_gpu.py).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+
+#include "../../include/p2c.h"
+#include "p2c_mlp_dev.h"
+#include "p2c_pose_head_dev.h"
+#include "p2c_pose_head_chain_dev.h"
+#include "p2c_train_dev.h"
+
+namespace p2c_stream {
+
+using namespace p2c_mlp;
+using namespace p2c_train;
+namespace ch = p2c::chain;
+using ph::M3;
+using ph::V3;
+
+constexpr int SW = 8;                       // wavefronts per workgroup: two per SIMD
+constexpr int PAIRS = 4;                    // ... in four pairs (w, w + 4): a pair shares a SIMD, an LDS region and a clip
+constexpr int PT = 16;                      // LDS pitch of an activation row (floats) = frames of a clip
+constexpr int ROWS_Y = 160;                 // y^T / grad_y^T (156 rows + k padding); H_0 before the first layer
+constexpr int ROWS_A = 80, ROWS_B = 48;     // ping-pong buffers: A holds H_1, H_3, H_5 / G_5, G_3, G_1; B holds H_2, H_4 / G_4, G_2
+constexpr int REGION = (ROWS_Y + ROWS_A + ROWS_B) * PT;
+constexpr int TAB_LOC = 0, TAB_ROT = 4 * ph::J * 3, TAB_FLOATS = 4 * ph::J * 12;
+constexpr int SCRATCH = 16;
+constexpr int LDS_FLOATS = S::w_total() + TAB_FLOATS + SCRATCH + PAIRS * REGION;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS budget");
+
+__host__ __device__ constexpr int ksteps_fwd(int l) { return ((((S::dim_at(l) + 1 + 3) >> 2) + 3) & ~3); }
+__host__ __device__ constexpr int ksteps_bwd(int l) { return ((((S::dim_at(l + 1) + 3) >> 2) + 3) & ~3); }
+__host__ __device__ constexpr int ntiles_fwd(int l) { return (S::dim_at(l + 1) + 16) >> 4; }
+__host__ __device__ constexpr int mtiles_bwd(int l) { return (S::dim_at(l) + 15) >> 4; }
+// first ReLU-mask bit of H_l (l = 1 .. 5): four bits (the lane's four rows) per 16-row tile
+__host__ __device__ constexpr int mask_bit0(int l) {
+  int b = 0;
+  for (int i = 1; i < l; ++i) b += 4 * ntiles_fwd(i - 1);
+  return b;
+}
+static_assert(mask_bit0(NLAY - 1) + 4 * ntiles_fwd(NLAY - 2) <= 64, "ReLU masks fit 64 bits per lane");
+// the buffers the layers meet
+static_assert(ntiles_fwd(0) * 16 <= ROWS_A && ntiles_fwd(2) * 16 <= ROWS_A && ntiles_fwd(4) * 16 <= ROWS_A, "A rows");
+static_assert(ntiles_fwd(1) * 16 <= ROWS_B && ntiles_fwd(3) * 16 <= ROWS_B, "B rows");
+static_assert(ntiles_fwd(5) * 16 <= ROWS_Y && ksteps_bwd(5) * 4 <= ROWS_Y && ksteps_fwd(0) * 4 <= ROWS_Y, "y rows (H_0 before the first layer)");
+
+#ifdef P2C_STREAM_TRACE   // developer build only (tools/streamtrace.py): shader-clock stamps of wave 0 of one workgroup
+static __device__ unsigned long long g_strace[64];
+#ifndef P2C_STREAM_TRACE_BLOCK
+#define P2C_STREAM_TRACE_BLOCK 0
+#endif
+#define ST(i)                                                                            \
+  do {                                                                                   \
+    if (blockIdx.x == P2C_STREAM_TRACE_BLOCK && threadIdx.x == 0) {                      \
+      g_strace[i] = __builtin_readcyclecounter();                                        \
+      if ((i) == 0 || (i) == 63) g_strace[(i) == 0 ? 62 : 61] = wall_clock64();          \
+    }                                                                                    \
+  } while (0)
+#else
+#define ST(i)
+#endif
+
+// timing experiments only (WRONG results): 1 = no pose head, 2 = no LinearAE, 4 = no factor stores, 8 = every clip's factors
+// to the pair's first block (bits combine)
+#ifndef P2C_STREAM_EXPERIMENT
+#define P2C_STREAM_EXPERIMENT 0
+#endif
+constexpr int GROUP = 5;                   // output tiles per pass over k (accumulators in flight)
+
+// A value the optimiser must take as new at this point: everything derived from it is recomputed here instead of being hoisted
+// out of the clip loop and carried (spilled) across the other phases. A handful of integer instructions per phase buys ~50
+// registers of live range.
+__device__ __forceinline__ int fresh(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// first bone and number of bones of chain q (= chain::c_start / c_len, as arithmetic: a lane-indexed __constant__ table is a
+// vector load, and the wait the compiler puts in front of its use drains every older store)
+__device__ __forceinline__ int chain_start(int q) { return q < 5 ? 4 * q : (q == 5 ? 21 : (q == 6 ? 20 : 25)); }
+__device__ __forceinline__ int chain_len(int q) { return q < 6 ? 4 : 1; }
+
+struct WLane {
+  int lane, c, g;        // c = lane & 15: frame (MFMA column), g = lane >> 4
+};
+
+// out^T[n][t] = act(sum_k Waug[n][k] in^T[k][t]) for NT consecutive 16-row output tiles; two accumulators in flight hide the
+// 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 behind its 32-cycle issue
+template <int NT, int KSTEPS, bool RELU>
+__device__ __forceinline__ void fwd_tiles(const WLane &L, const float *wl, const int ld, const int nt0, const float *in, float *out,
+                                          uint64_t &mask, const int bit0) {
+  f32x4 acc[NT];
+  const float *ap[NT];
+#pragma unroll
+  for (int h = 0; h < NT; ++h) {
+    acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ap[h] = wl + ((nt0 + h) * 16 + L.c) * ld + L.g;
+  }
+  const float *bp = in + L.g * PT + L.c;
+  float b0[4], a0[NT][4], b1[4], a1[NT][4];
+  auto load = [&](float (&bv)[4], float (&av)[NT][4], int s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bv[u] = bp[(s + u) * 4 * PT];
+#pragma unroll
+      for (int h = 0; h < NT; ++h) av[h][u] = ap[h][(s + u) * 4];
+    }
+  };
+  auto fma4 = [&](const float (&bv)[4], const float (&av)[NT][4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int h = 0; h < NT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][u], bv[u], acc[h], 0, 0, 0);
+    }
+  };
+  load(b0, a0, 0);
+#pragma unroll
+  for (int s = 4;; s += 8) {     // ping-pong: the operands of k-group s+1 are in flight while the MFMAs of group s run
+    if (s < KSTEPS) load(b1, a1, s);
+    __builtin_amdgcn_sched_barrier(0);
+    fma4(b0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s >= KSTEPS) break;
+    if (s + 4 < KSTEPS) load(b0, a0, s + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    fma4(b1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 4 >= KSTEPS) break;
+  }
+#pragma unroll
+  for (int h = 0; h < NT; ++h) {
+    f32x4 v = acc[h];
+    const int nb = (nt0 + h) * 16 + 4 * L.g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (RELU) {
+        mask |= (uint64_t)(v[r] > 0.f ? 1u : 0u) << (bit0 + (nt0 + h) * 4 + r);
+        v[r] = fmaxf(v[r], 0.f);
+      }
+      out[(nb + r) * PT + L.c] = v[r];     // the unit row of the image makes row n_out == 1, rows beyond it == 0
+    }
+  }
+}
+template <int LL>
+__device__ __forceinline__ void fwd_layer(const WLane &L, const float *img, const float *in, float *out, uint64_t &mask) {
+  constexpr int KS_ = ksteps_fwd(LL), NT_ = ntiles_fwd(LL);
+  constexpr bool RELU = LL < NLAY - 1;
+  const float *wl = img + S::w_off(LL);
+  // up to GROUP tiles share one pass over k: one B operand read feeds GROUP MFMAs, and a pass has one start-up (first operands
+  // exposed) and one epilogue instead of one per pair of tiles
+#pragma unroll
+  for (int nt = 0; nt < NT_; nt += GROUP) {
+    constexpr int REST = NT_ % GROUP;
+    if (nt + GROUP <= NT_) fwd_tiles<GROUP, KS_, RELU>(L, wl, S::ld(LL), nt, in, out, mask, mask_bit0(LL + 1));
+    else fwd_tiles<(REST ? REST : 1), KS_, RELU>(L, wl, S::ld(LL), nt, in, out, mask, mask_bit0(LL + 1));
+  }
+}
+
+// gout^T[m][t] = relu'(H[m][t]) * sum_k W[k][m] gin^T[k][t] for NT consecutive m-tiles (the mask bits stand in for H)
+template <int NT, int KSTEPS>
+__device__ __forceinline__ void dgrad_tiles(const WLane &L, const float *wl, const int ld, const int mt0, const int n_in,
+                                            const float *gin, float *gout, const uint64_t mask, const int bit0) {
+  f32x4 acc[NT];
+  const float *ap[NT];
+#pragma unroll
+  for (int h = 0; h < NT; ++h) {
+    acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ap[h] = wl + L.g * ld + (mt0 + h) * 16 + L.c;
+  }
+  const float *bp = gin + L.g * PT + L.c;
+  float b0[4], a0[NT][4], b1[4], a1[NT][4];
+  auto load = [&](float (&bv)[4], float (&av)[NT][4], int s) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bv[u] = bp[(s + u) * 4 * PT];
+#pragma unroll
+      for (int h = 0; h < NT; ++h) av[h][u] = ap[h][(s + u) * 4 * ld];
+    }
+  };
+  auto fma4 = [&](const float (&bv)[4], const float (&av)[NT][4]) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int h = 0; h < NT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[h][u], bv[u], acc[h], 0, 0, 0);
+    }
+  };
+  load(b0, a0, 0);
+#pragma unroll
+  for (int s = 4;; s += 8) {
+    if (s < KSTEPS) load(b1, a1, s);
+    __builtin_amdgcn_sched_barrier(0);
+    fma4(b0, a0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s >= KSTEPS) break;
+    if (s + 4 < KSTEPS) load(b0, a0, s + 4);
+    __builtin_amdgcn_sched_barrier(0);
+    fma4(b1, a1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 4 >= KSTEPS) break;
+  }
+#pragma unroll
+  for (int h = 0; h < NT; ++h) {
+    const int mb = (mt0 + h) * 16 + 4 * L.g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool on = (mb + r < n_in) && ((mask >> (bit0 + (mt0 + h) * 4 + r)) & 1u);
+      gout[(mb + r) * PT + L.c] = on ? acc[h][r] : 0.f;
+    }
+  }
+}
+template <int LL>   // G_LL from G_{LL+1}, LL = 5 .. 1
+__device__ __forceinline__ void dgrad_layer(const WLane &L, const float *img, const float *gin, float *gout, const uint64_t mask) {
+  constexpr int KS_ = ksteps_bwd(LL), MT_ = mtiles_bwd(LL);
+  const float *wl = img + S::w_off(LL);
+#pragma unroll
+  for (int mt = 0; mt < MT_; mt += GROUP) {
+    constexpr int REST = MT_ % GROUP;
+    if (mt + GROUP <= MT_) dgrad_tiles<GROUP, KS_>(L, wl, S::ld(LL), mt, S::dims(LL), gin, gout, mask, mask_bit0(LL));
+    else dgrad_tiles<(REST ? REST : 1), KS_>(L, wl, S::ld(LL), mt, S::dims(LL), gin, gout, mask, mask_bit0(LL));
+  }
+}
+
+// `rows` rows of a region (64 contiguous bytes each) -> the clip's factor block: straight 16-byte copies, 1 KB per instruction.
+// Two halves: the LDS reads go out before the next layer starts, the stores follow it (the rows wait in registers, no exposed
+// LDS latency, and the region may be overwritten in between).
+template <int ROWS>
+struct RowRegs {
+  f32x4 v[(ROWS * 4 + 63) / 64];
+};
+template <int ROWS>
+__device__ __forceinline__ void rows_read(const float *src, const int lane, RowRegs<ROWS> &r) {
+  const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
+#pragma unroll
+  for (int i = 0; i < (ROWS * 4 + 63) / 64; ++i) {
+    const int p = i * 64 + lane;
+    r.v[i] = s4[((i + 1) * 64 <= ROWS * 4 || p < ROWS * 4) ? p : 0];
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void rows_store(const RowRegs<ROWS> &r, float *dst, const int lane) {
+  f32x4 *d4 = reinterpret_cast<f32x4 *>(dst);
+#pragma unroll
+  for (int i = 0; i < (ROWS * 4 + 63) / 64; ++i) {
+    const int p = i * 64 + lane;
+    // An asm store: hipcc makes every VALU write to a register a pending store of ITS OWN has read wait for that store's
+    // completion (vmcnt) -- with 34 KB of factors per clip in flight the MLP wave drained its queue a dozen times per clip.
+    // The hardware needs two wait states, inside the string (cdna_hip_programming.md, inline-asm rules: stores).
+    if (!(P2C_STREAM_EXPERIMENT & 4) && ((i + 1) * 64 <= ROWS * 4 || p < ROWS * 4))
+      asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(d4 + p), "v"(r.v[i]) : "memory");
+  }
+}
+
+// the x tile of one clip: T x 52 contiguous floats; rows beyond T read as zero
+struct XRegs {
+  f32x4 v[4];
+};
+__device__ __forceinline__ void x_issue(const float *x, const int64_t clip, const int B, const int T, const int lane, XRegs &r) {
+  const f32x4 *p4 = reinterpret_cast<const f32x4 *>(x + (clip < B ? clip : 0) * T * 52);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int i = lane + 64 * u;
+    r.v[u] = (clip < B && i < 13 * T) ? p4[i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+// LDS float offset (row k = feature, column t = frame) of the first element of each of the lane's float4 pieces: a property
+// of the lane alone, worked out once per kernel (a division by 52 per piece)
+struct XOffs {
+  int o[4];
+};
+__device__ __forceinline__ XOffs x_offsets(const int lane) {
+  XOffs r;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = 4 * (lane + 64 * u), t = e / 52, k = e - t * 52;
+    r.o[u] = (lane + 64 * u < 13 * 16) ? k * PT + t : -1;
+  }
+  return r;
+}
+__device__ __forceinline__ void x_commit(const XRegs &r, const XOffs &xo, float *Y, const int lane) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (u < 3 || xo.o[u] >= 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Y[xo.o[u] + j * PT] = r.v[u][j];
+    }
+  }
+  // the constant-one row behind the inputs and the zero rows the k loop reads up to its rounding
+#pragma unroll
+  for (int i = 0; i < (ksteps_fwd(0) * 4 - 52) * PT / 64; ++i) Y[52 * PT + i * 64 + lane] = (i == 0 && lane < PT) ? 1.f : 0.f;
+}
+
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+constexpr int IMG_CHUNKS = ((S::w_total() >> 2) + 63) / 64;          // 1 KB pieces (64 lanes x 16 B)
+
+// targets of one frame for the lane's four bones + the clip's skeleton type: issued at the TOP of an iteration (in front of the
+// forward's factor stores: vmcnt retires in issue order, a load behind 26 stores waits for all of them), consumed by the pose head
+struct PoseIn {
+  ch::FrameIn4 in;
+  int st;
+};
+__device__ __forceinline__ void pose_inputs(const p2c_pose_head_desc &d, const int clip, const int lane_, const int half, PoseIn &pi) {
+  constexpr int NS = ch::NS;
+  const int lane = fresh(lane_);
+  const int T = d.T, t = 8 * half + (lane >> 3), start = chain_start(lane & 7);
+  pi.st = d.skel_type[clip];
+  const size_t c2 = (size_t)T * ph::J * 2 * 4, c3 = (size_t)T * ph::J * 3 * 4;          // bytes per clip
+  const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(d.gt2d) + (size_t)clip * c2), 0, d.gt2d ? (int)c2 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r3 = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(d.gt3d) + (size_t)clip * c3), 0, d.gt3d ? (int)c3 : 0, 0x00020000);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    const int j = start + k < ph::J ? start + k : ph::J - 1;      // (steps a lane does not own: any bone, masked later)
+    const int jf = t * ph::J + j;                                  // frames beyond T: past the records, read as zero
+    const ph::fb_f32x2 a = __builtin_bit_cast(ph::fb_f32x2, __builtin_amdgcn_raw_buffer_load_b64(r2, jf * 8, 0, 0));
+    const ph::fb_f32x3 b = __builtin_bit_cast(ph::fb_f32x3, __builtin_amdgcn_raw_buffer_load_b96(r3, jf * 12, 0, 0));
+    pi.in.g2[k][0] = a[0], pi.in.g2[k][1] = a[1];
+    pi.in.g3[k][0] = b[0], pi.in.g3[k][1] = b[1], pi.in.g3[k][2] = b[2];
+  }
+}
+
+// the loaded values are pinned HERE: the wait the compiler emits for them covers loads only when no store has been issued yet
+__device__ __forceinline__ void pose_inputs_landed(PoseIn &pi) {
+#pragma unroll
+  for (int k = 0; k < ch::NS; ++k) {
+    asm volatile("" : "+v"(pi.in.g2[k][0]), "+v"(pi.in.g2[k][1]), "+v"(pi.in.g3[k][0]), "+v"(pi.in.g3[k][1]), "+v"(pi.in.g3[k][2]));
+  }
+  asm volatile("" : "+v"(pi.st));
+}
+
+// ---- the pose head of ONE clip by the two wavefronts of a pair ------------------------------------------------------------------
+// lane = (segment = lane >> 3, chain = lane & 7: up to four consecutive bones); wavefront `half` of the pair owns frames
+// 8 half + segment: ONE frame per eight-lane unit. Per-frame work is chain::fk_local / fk_base / head4 / subtree4 unchanged (their
+// cross-lane moves stay inside the eight lanes of a unit). The couplings between frames are scans over the segments (ds_bpermute:
+// lane -/+ 8, 16, 32) plus one hand-over between the two wavefronts through LDS: the first half's product of changes to the
+// second, the second half's torque sums to the first. The barriers are the WORKGROUP's (every pair passes them together).
+constexpr int XCH_ROT = 0, XCH_TAU = 8 * ch::NS * 9, XCH_LOSS = XCH_TAU + 8 * ch::NS * 3, XCH_FLOATS = XCH_LOSS + 4;
+static_assert(XCH_FLOATS <= ROWS_A * PT, "the hand-over scratch lives in buffer A (idle during the pose head)");
+
+template <int KIND>
+__device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bool active, const int clip, const int lane_, const int half,
+                                           const PoseIn &pin, float *Y, float *xch, const float *tab, const float coef2, const float coef3) {
+  using K = ph::KindTraits<KIND>;
+  constexpr int NS = ch::NS;
+  const int T = d.T;
+  const int lane = fresh(lane_);
+  ch::Lane L;
+  L.lane = lane, L.slot = lane >> 3, L.chain = lane & 7, L.clip = clip, L.clip_ok = true;
+  L.start = chain_start(L.chain);
+  L.trunk = L.chain == 0, L.head = L.chain == 2, L.leg = (L.chain == 4 || L.chain == 5), L.toe = L.chain >= 6, L.on_hips = L.chain >= 4;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) L.valid[k] = k < chain_len(L.chain);
+  const int t = 8 * half + L.slot;                  // this unit's frame
+  const bool frame_ok = t < T;
+  // cross-segment moves: ds_bpermute with the byte addresses of lane -/+ 8, 16, 32
+  const int up_addr[3] = {(lane - 8) * 4, (lane - 16) * 4, (lane - 32) * 4}, dn_addr[3] = {(lane + 8) * 4, (lane + 16) * 4, (lane + 32) * 4};
+  auto bperm = [](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
+
+  const ch::FrameIn4 &in = pin.in;
+  M3 c[NS], P[NS];                                  // the frame's changes (rows b1, b2, b3); rel_rot BEFORE the frame
+  float gs_n1[NS], gs_n2[NS], gs_d[NS];             // what the pull-back needs besides c: |a1|, |u2|, b1 . a2
+  bool gs_ok[NS];
+  ST(20);
+  if (active) {
+    // ---- the unit's rotations: y^T rows (bone, i) at column t ------------------------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int j = L.start + k < ph::J ? L.start + k : ph::J - 1;
+      float y6[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) y6[i] = Y[(j * 6 + i) * PT + (t & 15)];
+      if (!frame_ok) y6[0] = 1.f, y6[1] = 0.f, y6[2] = 0.f, y6[3] = 0.f, y6[4] = 1.f, y6[5] = 0.f;   // beyond the clip: identity change
+      ph::SixD s;
+      c[k] = ph::rot6d_fwd(y6, s);
+      gs_n1[k] = s.n1, gs_n2[k] = s.n2, gs_d[k] = s.d, gs_ok[k] = s.c1 && s.c2;
+    }
+    // ---- reference skeleton of the clip (data/carla/reference.py tables, staged in LDS) --------------------------------------
+    const int st = __builtin_amdgcn_readfirstlane(pin.st) & 3;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const int j = L.start + k < ph::J ? L.start + k : ph::J - 1;
+      const int row = st * ph::J + j;
+      P[k] = ph::identity();
+      if (K::SCAN) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) P[k].m[i] = tab[TAB_ROT + row * 9 + i];
+      }
+    }
+    ST(21);
+    if (K::SCAN) {
+      // rel_rot[t] = change[t] rel_rot[t-1] (projection.py:190-193): inclusive scan of the changes over the wave's eight frames
+      // (the four bones of a round travel together), then one more move makes it exclusive
+      M3 X[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) X[k] = c[k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        M3 Q[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Q[k].m[i] = bperm(up_addr[r], X[k].m[i]);
+        const bool has = lane >= (8 << r);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) X[k] = ch::sel(has, ph::mul(X[k], Q[k]), X[k]);
+      }
+      if (half == 0 && lane >= 56) {               // the product of frames 0 .. 7: the second wavefront starts from it
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+#pragma unroll
+          for (int i = 0; i < 9; ++i) xch[XCH_ROT + (L.chain * NS + k) * 9 + i] = X[k].m[i];
+      }
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        M3 E;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) E.m[i] = bperm(up_addr[0], X[k].m[i]);
+        X[k] = ch::sel(lane >= 8, E, ph::identity());
+      }
+      // first wavefront: rel_rot before the frame = (exclusive product) x (reference pose), now; the second keeps its exclusive
+      // product in P's place and completes it behind the hand-over: (exclusive product) x (frames 0 .. 7) x (reference pose)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) P[k] = (half == 0) ? ch::sel(lane >= 8, ph::mul(X[k], P[k]), P[k]) : X[k];
+    }
+  }
+  ST(22);
+  lds_barrier();                                   // ---- hand-over 1: the first half's product is in LDS ----
+  ch::Acc acc{0.f, 0.f, 0.f};
+  V3 taup[NS], later[NS], gb1[NS], gb2[NS], gb3[NS];   // rows of the change: what the pull-back needs of it
+  M3 R[NS];                                        // rel_rot of the frame
+  if (active) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      gb1[k] = ph::v3(c[k].m[0], c[k].m[1], c[k].m[2]), gb2[k] = ph::v3(c[k].m[3], c[k].m[4], c[k].m[5]);
+      gb3[k] = ph::v3(c[k].m[6], c[k].m[7], c[k].m[8]);
+    }
+    if (K::SCAN && half != 0) {
+      const int st = __builtin_amdgcn_readfirstlane(pin.st) & 3;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int j = L.start + k < ph::J ? L.start + k : ph::J - 1;
+        const int row = st * ph::J + j;
+        M3 TA, Rref;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) TA.m[i] = xch[XCH_ROT + (L.chain * NS + k) * 9 + i], Rref.m[i] = tab[TAB_ROT + row * 9 + i];
+        P[k] = ph::mul(ph::mul(P[k], TA), Rref);
+      }
+    }
+    ST(23);
+    // ---- forward + backward of the frame down to the parent-frame torques -----------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < NS; ++k) R[k] = K::SCAN ? ph::mul(c[k], P[k]) : c[k];       // rel_rot of the frame; c, P are dead from here
+    V3 l[NS];
+    {
+      const int st = __builtin_amdgcn_readfirstlane(pin.st) & 3;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const int j = L.start + k < ph::J ? L.start + k : ph::J - 1;
+        const int row = st * ph::J + j;
+        l[k] = ph::v3(tab[TAB_LOC + row * 3], tab[TAB_LOC + row * 3 + 1], tab[TAB_LOC + row * 3 + 2]);
+        l[k] = ch::sel(L.valid[k], l[k], ph::v3(0.f, 0.f, 0.f));
+      }
+    }
+    M3 Al[NS], Ap3, BA;
+    V3 xl[NS], BX;
+    ch::fk_local(L, R, l, Al, xl, Ap3);
+    ch::fk_base(L, Al, xl, BA, BX);
+    V3 x[NS], F[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) x[k] = ch::sel(L.valid[k], ph::vmul(xl[k], BA) + BX, ph::v3(0.f, 0.f, 0.f));
+    ST(24);
+    ch::head4<true, true>(d, L, t, x, in, acc, coef2, coef3, F);
+    ST(25);
+    V3 FX[NS], SubF[NS], SubX[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) FX[k] = ph::cross(F[k], x[k]);
+    ch::subtree4(L, F, SubF);
+    ch::subtree4(L, FX, SubX);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const V3 tau = SubX[k] - ph::cross(SubF[k], x[k]);
+      V3 tp = ph::vmulT(tau, BA);                  // tau A_parent^T, A_parent = A'_parent-in-chain A_base
+      if (k > 0) tp = ph::vmulT(tp, (k == 3) ? Ap3 : Al[k - 1]);
+      taup[k] = tp;
+    }
+    ST(26);
+    // ---- suffix sums over time of the torques: inclusive add scan over the wave's frames, the second half's total to LDS ----------
+    if (K::SCAN) {
+      V3 X[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) X[k] = taup[k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        V3 Q[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) Q[k] = ph::v3(bperm(dn_addr[r], X[k].x), bperm(dn_addr[r], X[k].y), bperm(dn_addr[r], X[k].z));
+        const bool has = lane + (8 << r) < 64;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) X[k] = ch::sel(has, X[k] + Q[k], X[k]);
+      }
+      if (half != 0 && lane < 8) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          float *q = xch + XCH_TAU + (L.chain * NS + k) * 3;
+          q[0] = X[k].x, q[1] = X[k].y, q[2] = X[k].z;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NS; ++k) later[k] = X[k];       // S_t of this wave's frames (inclusive)
+    }
+    {   // this half's loss sums
+      const float s2 = ph::wave_sum(acc.sum2), c2 = ph::wave_sum(acc.cnt2), s3 = ph::wave_sum(acc.sum3);
+      acc.sum2 = s2, acc.cnt2 = c2, acc.sum3 = s3;
+      if (half != 0 && lane == 0) xch[XCH_LOSS] = s2, xch[XCH_LOSS + 1] = c2, xch[XCH_LOSS + 2] = s3;
+    }
+  }
+  ST(27);
+  lds_barrier();                                   // ---- hand-over 2: the second half's torque sums (and loss sums) are in LDS ----
+  if (active) {
+    if (half == 0 && lane == 0) {
+      float *pp = d.partials + (size_t)clip * 4;
+      pp[0] = acc.sum2 + xch[XCH_LOSS], pp[1] = acc.cnt2 + xch[XCH_LOSS + 1], pp[2] = acc.sum3 + xch[XCH_LOSS + 2], pp[3] = 0.f;
+    }
+    // ---- pull-back through Gram-Schmidt (closed form, see pose_head_chain_bwd), grad_y^T over y^T ------------------------------
+    // g = S rel_rot[t-1]^T enters only through its components in the frame (b1, b2, b3) = the rows of the change c, and
+    // rel_rot[t-1] = c^T rel_rot[t]: (g . b_i) = (S rel_rot[t]^T c . b_i) = (S rel_rot[t]^T)_i -- neither c nor rel_rot[t-1] is kept
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      const V3 b1 = K::SCAN ? ph::cross(gb2[k], gb3[k]) : gb1[k], b2 = gb2[k], b3 = gb3[k];
+      float al, be, ga;
+      V3 vv = taup[k];
+      if (K::SCAN) {
+        V3 Ssum = later[k];
+        if (half == 0) {
+          const float *q = xch + XCH_TAU + (L.chain * NS + k) * 3;
+          Ssum = Ssum + ph::v3(q[0], q[1], q[2]);
+        }
+        vv = ph::vmulT(Ssum, R[k]);
+        al = vv.x, be = vv.y, ga = vv.z;
+      } else {
+        al = ph::dot(vv, b1), be = ph::dot(vv, b2), ga = ph::dot(vv, b3);
+      }
+      float gy6[6];
+      {
+        const float r1 = ph::frcp(gs_n1[k]), r2 = ph::frcp(gs_n2[k]);
+        const float k3 = (be + al * gs_d[k] * r2) * r1, k2 = -ga * r1, k5 = -al * r2;
+        gy6[0] = fmaf(k3, b3.x, k2 * b2.x), gy6[1] = fmaf(k3, b3.y, k2 * b2.y), gy6[2] = fmaf(k3, b3.z, k2 * b2.z);
+        gy6[3] = k5 * b3.x, gy6[4] = k5 * b3.y, gy6[5] = k5 * b3.z;
+      }
+      const int j = L.start + k < ph::J ? L.start + k : ph::J - 1;
+      if (__any(!gs_ok[k])) {         // (rare, wave-uniform) a norm sits on the 1e-12 clamp: generic chain rule through Gram-Schmidt
+        const M3 cc = M3{{b1.x, b1.y, b1.z, b2.x, b2.y, b2.z, b3.x, b3.y, b3.z}};
+        const V3 g = K::SCAN ? ph::vmul(vv, cc) : vv;                    // S rel_rot[t-1]^T = (S rel_rot[t]^T) c
+        ph::SixD s;
+        s.a2 = ph::v3(Y[(j * 6 + 3) * PT + (t & 15)], Y[(j * 6 + 4) * PT + (t & 15)], Y[(j * 6 + 5) * PT + (t & 15)]);   // (y is still there)
+        s.b1 = b1, s.b2 = b2, s.n1 = gs_n1[k], s.n2 = gs_n2[k], s.d = gs_d[k];
+        s.c1 = gs_n1[k] > 1e-12f, s.c2 = gs_n2[k] > 1e-12f;              // (the clamped norms equal the clamp where it applied)
+        M3 G;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const V3 ci = ph::v3(cc.m[i * 3], cc.m[i * 3 + 1], cc.m[i * 3 + 2]);
+          const V3 h = ph::cross(ci, g) * 0.5f;
+          G.m[i * 3] = h.x, G.m[i * 3 + 1] = h.y, G.m[i * 3 + 2] = h.z;
+        }
+        float slow[6];
+        ph::rot6d_bwd(s, G, slow);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) gy6[i] = gs_ok[k] ? gy6[i] : slow[i];
+      }
+      if (L.valid[k]) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Y[((L.start + k) * 6 + i) * PT + (t & 15)] = frame_ok ? gy6[i] : 0.f;
+      }
+    }
+    // padding rows of G_L (the dgrad k loop reads them)
+    if (half == 0 && lane < (ksteps_bwd(NLAY - 1) * 4 - S::dims(NLAY)) * PT) Y[S::dims(NLAY) * PT + lane] = 0.f;
+  }
+  ST(28);
+  lds_barrier();                                   // ---- grad_y^T is complete ----
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_head_desc d, const ph::GradLosses gl, const ClipArgs m) {
+  extern __shared__ float lds[];
+  const int lane0 = threadIdx.x & 63;
+  WLane L;
+  L.lane = lane0, L.c = L.lane & 15, L.g = L.lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int pair = wave & (PAIRS - 1), half = wave >> 2;      // waves w and w + 4 share a SIMD and a clip
+  float *img = lds;
+  float *tab = lds + S::w_total();
+  float *scratch = tab + TAB_FLOATS;
+  float *Y = scratch + SCRATCH + pair * REGION, *A = Y + ROWS_Y * PT, *Bb = A + ROWS_A * PT;
+  ST(0);
+  const int T = d.T;
+  const int64_t stride = (int64_t)gridDim.x * PAIRS;
+  // pair p of workgroup b walks clips b + gridDim (p + 4 i): clip mod 8 = workgroup mod 8 when the grid is a multiple of 8 (the
+  // XCD whose L2 the factors stay in). Every wavefront runs the trip count of pair 0: the barriers are the workgroup's.
+  int64_t clip = (int64_t)blockIdx.x + (int64_t)gridDim.x * pair;
+  const int n_iter = (int)(((int64_t)d.B - blockIdx.x + stride - 1) / stride);
+  // ---- prologue: first x tile, weight image by LDS-DMA (one burst), tables, pair counts -----------------------------------------
+  // The x tiles are the SECOND wavefront's job: its vector-memory queue holds loads only, so a wait for a tile never has to
+  // drain factor stores (vmcnt retires in issue order, and the compiler's waits in front of loaded values are vmcnt(0)).
+  XRegs xr;
+  if (half != 0) x_issue(m.x, clip, d.B, T, L.lane, xr);
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(m.w_image), 0, S::w_total() * 4, 0x00020000);
+    const unsigned base = (unsigned)(uintptr_t)(lds_void_ptr)img;
+    constexpr int total4 = S::w_total() >> 2;
+#pragma unroll
+    for (int i = 0; i < (IMG_CHUNKS + SW - 1) / SW; ++i) {
+      const int ck = wave + i * SW;                                  // (wave-uniform)
+      if (ck < IMG_CHUNKS && ck * 64 + L.lane < total4)              // the last piece is partial: its tail lanes stay out
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(uintptr_t)(base + ck * 1024), 16, (ck * 64 + L.lane) * 16, 0, 0, 0);
+    }
+  }
+  for (int i = threadIdx.x; i < TAB_FLOATS; i += 64 * SW) tab[i] = i < TAB_ROT ? d.ref_rel_loc[i] : d.ref_rel_rot[i - TAB_ROT];
+  if (blockIdx.x == 0 && (int)threadIdx.x < m.n_counters) m.counters[threadIdx.x] = 0;   // arrival tickets of train_wgrad_kernel
+  {
+    float cnt = 0.f;                               // small integers held in floats: exact in any order
+    for (int i0 = 0; i0 < d.B; i0 += 8 * 64 * SW) {   // eight loads in flight per thread (a dependent add per load is a round trip each)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 64 * SW + (int)threadIdx.x;
+        v[u] = m.counts[i < d.B ? i : 0];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) cnt += (i0 + u * 64 * SW + (int)threadIdx.x < d.B) ? v[u] : 0.f;
+    }
+    cnt = ph::wave_sum(cnt);
+    if (L.lane == 0) scratch[wave] = cnt;
+  }
+  if (half != 0) x_commit(xr, x_offsets(L.lane), Y, L.lane);       // H_0 of the pair's first clip
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  float coef2 = 0.f, coef3 = 0.f;
+  {
+    float n2 = 0.f;
+    for (int w = 0; w < SW; ++w) n2 += scratch[w];
+    ph::loss_coefs_n(d, gl, n2, ph::n3_elems(d), coef2, coef3);
+  }
+
+  ST(1);
+  for (int it = 0; it < n_iter; ++it, clip += stride) {
+    ST(2);
+    const bool active = clip < d.B;
+    float *fdst = m.factors + (size_t)((active && !(P2C_STREAM_EXPERIMENT & 8)) ? clip : blockIdx.x * PAIRS + pair) * F_ROWS * 16;
+    uint64_t mask = 0;
+    PoseIn pin;
+    pin.st = 0;
+    if (active) pose_inputs(d, (int)clip, lane0, half, pin);
+    if (half == 0 && active && !(P2C_STREAM_EXPERIMENT & 2)) {
+      // ---- LinearAE forward by the pair's first wavefront; every H_l leaves for the factor block as soon as it exists ---------------
+      WLane L;
+      L.lane = fresh(lane0), L.c = L.lane & 15, L.g = L.lane >> 4;
+      ST(3);
+      RowRegs<S::dims(0)> h0;
+      rows_read(Y, L.lane, h0);
+      fwd_layer<0>(L, img, Y, A, mask);
+      pose_inputs_landed(pin);                     // (in front of the first factor store)
+      rows_store(h0, fdst + f_h_off(0) * 16, L.lane);
+      ST(4);
+      RowRegs<S::dims(1)> h1;
+      rows_read(A, L.lane, h1);
+      fwd_layer<1>(L, img, A, Bb, mask);
+      rows_store(h1, fdst + f_h_off(1) * 16, L.lane);
+      ST(5);
+      RowRegs<S::dims(2)> h2;
+      rows_read(Bb, L.lane, h2);
+      fwd_layer<2>(L, img, Bb, A, mask);
+      rows_store(h2, fdst + f_h_off(2) * 16, L.lane);
+      ST(6);
+      RowRegs<S::dims(3)> h3;
+      rows_read(A, L.lane, h3);
+      fwd_layer<3>(L, img, A, Bb, mask);
+      rows_store(h3, fdst + f_h_off(3) * 16, L.lane);
+      ST(7);
+      RowRegs<S::dims(4)> h4;
+      rows_read(Bb, L.lane, h4);
+      fwd_layer<4>(L, img, Bb, A, mask);
+      rows_store(h4, fdst + f_h_off(4) * 16, L.lane);
+      ST(8);
+      RowRegs<S::dims(5)> h5;
+      rows_read(A, L.lane, h5);
+      fwd_layer<5>(L, img, A, Y, mask);
+      rows_store(h5, fdst + f_h_off(5) * 16, L.lane);
+      ST(9);
+    } else {
+      pose_inputs_landed(pin);                     // (every path pins them: no wait is left for the common code behind the barrier)
+    }
+    lds_barrier();                                 // ---- y^T is complete (and buffer A is free: the pose head's hand-over scratch) ----
+    // ---- pose head forward + backward by both wavefronts of the pair: y^T -> grad_y^T in place --------------------------------------
+    pose_phase<KIND>(d, active && !(P2C_STREAM_EXPERIMENT & 1), (int)clip, lane0, half, pin, Y, A, tab, coef2, coef3);
+    ST(32);
+    const bool mlp = half == 0 && active && !(P2C_STREAM_EXPERIMENT & 2);
+    WLane Ld;
+    Ld.lane = fresh(lane0), Ld.c = Ld.lane & 15, Ld.g = Ld.lane >> 4;
+    RowRegs<S::dims(6)> g6;
+    if (half != 0) x_issue(m.x, clip + stride, d.B, T, Ld.lane, xr);   // the pair's next clip: lands behind the first dgrad layer
+    if (mlp) {
+      // ---- dgrad chain; every G_l leaves as soon as it exists ----------------------------------------------------------------------
+      rows_read(Y, Ld.lane, g6);
+      dgrad_layer<5>(Ld, img, Y, A, mask);
+      rows_store(g6, fdst + f_g_off(6) * 16, Ld.lane);
+      ST(33);
+    }
+    lds_barrier();                                 // ---- grad_y^T has been read: the y rows are free for the next clip's H_0 ----
+    if (half != 0 && clip + stride < d.B) x_commit(xr, x_offsets(Ld.lane), Y, Ld.lane);
+    if (mlp) {
+      const WLane &L = Ld;
+      RowRegs<S::dims(5)> g5;
+      rows_read(A, L.lane, g5);
+      dgrad_layer<4>(L, img, A, Bb, mask);
+      rows_store(g5, fdst + f_g_off(5) * 16, L.lane);
+      ST(34);
+      RowRegs<S::dims(4)> g4;
+      rows_read(Bb, L.lane, g4);
+      dgrad_layer<3>(L, img, Bb, A, mask);
+      rows_store(g4, fdst + f_g_off(4) * 16, L.lane);
+      ST(35);
+      RowRegs<S::dims(3)> g3;
+      rows_read(A, L.lane, g3);
+      dgrad_layer<2>(L, img, A, Bb, mask);
+      rows_store(g3, fdst + f_g_off(3) * 16, L.lane);
+      ST(36);
+      RowRegs<S::dims(2)> g2;
+      rows_read(Bb, L.lane, g2);
+      dgrad_layer<1>(L, img, Bb, A, mask);
+      rows_store(g2, fdst + f_g_off(2) * 16, L.lane);
+      RowRegs<S::dims(1)> g1;
+      rows_read(A, L.lane, g1);
+      rows_store(g1, fdst + f_g_off(1) * 16, L.lane);
+      ST(37);
+    }
+    lds_barrier();                                 // ---- the next clip's H_0 is in place ----
+    ST(63);
+  }
+}
+
+}  // namespace p2c_stream
+
+using namespace p2c_stream;
+
+#ifdef P2C_STREAM_TRACE
+extern "C" P2C_API int p2c_debug_stream_trace(unsigned long long *out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_stream::g_strace), sizeof(unsigned long long) * 64);
+}
+#endif
+
+bool p2c_internal_train_stream_supported(const p2c_pose_head_desc &d) {
+  if (d.kind != P2C_KIND_POSE_CHANGES_6D && d.kind != P2C_KIND_RELATIVE_ROT_6D) return false;
+  if (d.dloc || d.drot || d.gt_rot) return false;
+  if (d.T < 1 || d.T > 16) return false;
+  if (d.transform != P2C_TRANSFORM_NONE && (d.n_hips != 1 || d.n_neck != 1 || d.hips_idx[0] != ch::HIPS || d.neck_idx[0] != ch::NECK))
+    return false;
+  if (d.gt2d && (d.gt2d_joints != P2C_JOINTS || d.gt2d_channels != 2)) return false;
+  if (d.gt3d && d.gt3d_joints != P2C_JOINTS) return false;
+  for (int j = 0; j < P2C_JOINTS; ++j)
+    if ((d.gt2d && d.gmap2d[j] != j) || (d.gt3d && d.gmap3d[j] != j)) return false;
+  return true;
+}
+
+int p2c_internal_train_stream_launch(const p2c_pose_head_desc &d, const p2c::GradLosses &gl, const ClipArgs &m, hipStream_t stream) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void *)train_stream_kernel<P2C_KIND_POSE_CHANGES_6D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)train_stream_kernel<P2C_KIND_RELATIVE_ROT_6D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  constexpr int kCUs = 256;
+  const int want = (d.B + PAIRS - 1) / PAIRS;
+  const dim3 grid((unsigned)(want < kCUs ? want : kCUs));
+  const size_t lds_bytes = (size_t)LDS_FLOATS * sizeof(float);
+  if (d.kind == P2C_KIND_POSE_CHANGES_6D)
+    hipLaunchKernelGGL(train_stream_kernel<P2C_KIND_POSE_CHANGES_6D>, grid, dim3(64 * SW), lds_bytes, stream, d, gl, m);
+  else
+    hipLaunchKernelGGL(train_stream_kernel<P2C_KIND_RELATIVE_ROT_6D>, grid, dim3(64 * SW), lds_bytes, stream, d, gl, m);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

@@ -538,7 +538,9 @@ class Trainer:
             rc = _lib.lib().p2c_graph_node_counts(graph.raw_cuda_graph(), ctypes.byref(total), ctypes.byref(kernels))
         except Exception:                       # noqa: BLE001 -- no handle: keep the graph
             return None
-        if rc != 0 or total.value != 2 or kernels.value != 2:
+        # two launches (clip kernel + weight gradient / optimizer / losses), or three at large batches (streamed weight
+        # gradient + its reduction): nothing else may sit in the graph
+        if rc != 0 or total.value != kernels.value or kernels.value not in (2, 3):
             return None
         plan = rec[0]
         plan['device_index'] = plan['device'].index if plan['device'].index is not None else torch.cuda.current_device()

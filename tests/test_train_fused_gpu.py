@@ -51,16 +51,34 @@ def test_fused_step_is_bit_identical_to_the_separate_kernels(monkeypatch, otype)
     assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
 
 
-@pytest.mark.parametrize('B,T,missing,transform', [(5, 16, 0.1, 'hips_neck_bbox'), (33, 7, 0.2, 'hips_neck'),
-                                                   (64, 16, 0.0, 'bbox'), (1, 1, 0.0, 'none'),
-                                                   (300, 16, 0.1, 'hips_neck_bbox'), (777, 5, 0.1, 'hips_neck')])
-def test_fused_step_matches_cpu_pipeline(monkeypatch, B, T, missing, transform):
+@pytest.fixture
+def first_launch_form(request):
+    """'latency': train_clip_kernel (a workgroup per clip) at every batch size; 'stream': train_stream_kernel (a pair of
+    wavefronts per clip, csrc/p2c_train_stream.hip) at every batch size; '+wgrad': the second launch in its throughput form
+    (wgrad_stream_kernel + wgrad_reduce_kernel) at every batch size, else never. The library's own thresholds are restored."""
+    from pedestrians_video_2_carla_amd import _lib
+    lib = _lib.lib()
+    prev = lib.p2c_train_step_set_stream_min_batch(1 if request.param.startswith('stream') else (1 << 30))
+    prev_w = lib.p2c_train_step_set_wgrad_stream_min_batch(1 if request.param.endswith('wgrad') else (1 << 30))
+    yield request.param
+    lib.p2c_train_step_set_stream_min_batch(prev)
+    lib.p2c_train_step_set_wgrad_stream_min_batch(prev_w)
+
+
+@pytest.mark.parametrize('first_launch_form', ['latency', 'stream', 'stream+wgrad', 'latency+wgrad'], indirect=True)
+@pytest.mark.parametrize('B,T,missing,transform,otype', [
+    (5, 16, 0.1, 'hips_neck_bbox', 'pose_changes'), (33, 7, 0.2, 'hips_neck', 'pose_changes'),
+    (64, 16, 0.0, 'bbox', 'pose_changes'), (1, 1, 0.0, 'none', 'pose_changes'),
+    (300, 16, 0.1, 'hips_neck_bbox', 'pose_changes'), (777, 5, 0.1, 'hips_neck', 'pose_changes'),
+    (40, 16, 0.1, 'hips_neck', 'relative_rot'), (1030, 16, 0.1, 'hips_neck', 'pose_changes'), (19, 15, 0.3, 'none', 'relative_rot')])
+def test_fused_step_matches_cpu_pipeline(monkeypatch, first_launch_form, B, T, missing, transform, otype):
     """loss + every parameter gradient of one fused train step == LinearAE on CPU (fp64) + oracle pose head; ragged batch,
-    clips shorter than the 16-sample tile, every built-in transform, missing joints; B > 256: the per-clip kernel is
-    persistent (a workgroup walks 2 - 4 clips, weight image staged once)."""
+    clips shorter than the 16-sample tile, every built-in transform, missing joints, both 6-D kinds; B > 256: the per-clip
+    kernel is persistent (a workgroup walks 2 - 4 clips, weight image staged once); both forms of the first launch."""
     from pedestrians_video_2_carla_amd.data.base.base_transforms import BaseTransforms
     monkeypatch.setenv('P2C_FUSED_UPDATE', '0')                  # keep the gradients: the optimizer is a separate launch
-    flow, dm = make(B=B, T=T, missing=missing, transform=BaseTransforms[transform])
+    flow, dm = make(B=B, T=T, missing=missing, transform=BaseTransforms[transform], otype=otype)
+    kind = {'pose_changes': 'pose_changes_6d', 'relative_rot': 'relative_rot_6d'}[otype]
     cpu_model = copy.deepcopy(flow.movements_model).double()
     trainer = _trainer(flow, dm)
     trainer.optimizers[0].zero_grad_in_step = False
@@ -70,7 +88,7 @@ def test_fused_step_matches_cpu_pipeline(monkeypatch, B, T, missing, transform):
     torch.cuda.synchronize()
     assert _took_fused_path(flow)
     gt2d = targets['projection_2d_transformed' if transform != 'none' else 'projection_2d']
-    o = O.pose_head(cpu_model(frames.double().cpu()), 'pose_changes_6d', meta['skel_type'].cpu(), transform=transform,
+    o = O.pose_head(cpu_model(frames.double().cpu()), kind, meta['skel_type'].cpu(), transform=transform,
                     gt2d=gt2d.double().cpu(), gt3d=targets['absolute_pose_loc'].double().cpu())
     o['loc_2d_3d'].backward()
     close(loss, o['loc_2d_3d'], 'loss')
@@ -78,7 +96,7 @@ def test_fused_step_matches_cpu_pipeline(monkeypatch, B, T, missing, transform):
     close(flow.logged['train_loss/loc_3d'], o['loc_3d'], 'loc_3d')
     # fp32 tolerance rule of tests/test_pose_head_gpu.py: max(1e-4, 2 x the error the fp32 CPU pipeline itself makes)
     cpu32 = copy.deepcopy(cpu_model).float()
-    o32 = O.pose_head(cpu32(frames.float().cpu()), 'pose_changes_6d', meta['skel_type'].cpu(), transform=transform,
+    o32 = O.pose_head(cpu32(frames.float().cpu()), kind, meta['skel_type'].cpu(), transform=transform,
                       gt2d=gt2d.float().cpu(), gt3d=targets['absolute_pose_loc'].float().cpu())
     o32['loc_2d_3d'].backward()
     for (n, p), q, q32 in zip(flow.movements_model.named_parameters(), cpu_model.parameters(), cpu32.parameters()):

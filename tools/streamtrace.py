@@ -1,0 +1,37 @@
+"""Developer tool: phase timeline of train_stream_kernel, wave 0 of one workgroup, LAST clip it walked
+(needs a build with EXTRA=-DP2C_STREAM_TRACE; P2C_LIB_PATH selects it)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+import torch
+from test_flow_gpu import make, dev
+from pedestrians_video_2_carla_amd import _lib
+from pedestrians_video_2_carla_amd.trainer import Trainer
+
+os.environ['P2C_FUSED_TRAIN_MAX_B'] = str(1 << 20)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+lib = _lib.lib()
+lib.p2c_train_step_set_stream_min_batch(1)
+flow, dm = make(B=B, missing=0.1)
+tr = Trainer(device=dev(), use_graph=True).setup(flow, dm)
+batch = dm.generate_batch(dev())
+for i in range(30):
+    tr.train_step(flow, batch, i)
+torch.cuda.synchronize()
+lib.p2c_debug_stream_trace.argtypes = [ctypes.c_void_p]
+buf = (ctypes.c_ulonglong * 64)()
+assert lib.p2c_debug_stream_trace(buf) == 0
+t = list(buf)
+names = {1: 'prologue', 2: 'loop top', 3: 'x commit + next issue', 4: 'fwd L0 + store', 5: 'fwd L1', 6: 'fwd L2', 7: 'fwd L3', 8: 'fwd L4',
+         9: 'fwd L5', 20: 'pose: target loads issued', 21: 'read y, 6D->R (2 frames)', 22: 'tables + prefix scan', 23: 'A f0: R, FK',
+         24: 'A f0: head4', 25: 'A f0: subtree, torque', 26: 'A f1: R, FK', 27: 'A f1: head4', 28: 'A f1: subtree, torque',
+         29: 'loss sums', 30: 'suffix scan', 31: 'B: pull-back + write', 32: 'pad rows', 33: 'G6 store + dgrad L5 + store', 34: 'dgrad L4',
+         35: 'dgrad L3', 36: 'dgrad L2', 37: 'dgrad L1', 63: 'end'}
+cyc, wall = t[63] - t[0], (t[61] - t[62]) * 10.0
+print(f'B={B}: kernel (wave 0) {cyc} cycles, {wall:.0f} ns, {cyc / max(wall, 1):.2f} GHz; last clip {t[63] - t[2]} cycles')
+order = sorted((v, i) for i, v in enumerate(t[:61]) if v >= t[2] and i > 2) + [(t[63], 63)]
+prev = t[2]
+for v, i in order:
+    print(f'   [{i:2d}] +{v - prev:6d}  {names.get(i, "")}')
+    prev = v
+print(f'   prologue {t[1] - t[0]} cycles')
