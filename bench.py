@@ -22,6 +22,9 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
                bytes (vs 8 TB/s HBM) per launch / measured duration, PMC traffic; `other` = the rest
   roofline_sweep  the pose-head kernels p2c_pose_head_fwd / _bwd dispatch to at B = 256, 1024, 8192, 16384, 65536 (time-parallel,
                   joint-lane, chain-lane by batch; each kernel timed alone, the forward op with its loss reduction beside it)
+  step_sweep   the FULL train step at B = 256, 1024, 8192, 65536: ms per step, clips/s, the fraction of the fp32-MFMA peak (1.61
+               MFLOP per clip) and of the HBM peak (11 652 B per clip) that rate is, the step's launches one by one, and which
+               form of the fused step ran (a workgroup per clip / a pair of wavefronts per clip; weight gradient per tile / streamed)
   extra_configs  BASELINE.json configs[1] (B = 1024), configs[2] (autoencoder, Seq2SeqEmbeddings, B = 512) and one GPU's share
                  of configs[4] (PoseFormer, clip_length 81, B = 32) on this GPU
   cpu_baseline the op-for-op CPU port of the reference step (oracle/reference_port.py) timed on this host's cores:
@@ -342,6 +345,51 @@ def gemm_times(device, rows=2336 * 9, width=832):
         out['K16 TN qkv weight gradient (2496 x 832 from 21024 rows; slabs + sum)'] = _graph_us(lambda: ops.gemm_tn(gy, x, out=gw), stream, reps=5, rounds=3)
     flops = {k: 2.0 * rows * width * 3 * width for k in out}
     return out, flops
+
+
+STEP_FLOPS_PER_CLIP = 2.0 * (17212 + 33072) * T_FRAMES      # LinearAE forward + dgrad + wgrad of one clip
+STEP_BYTES_PER_CLIP = 4 * T_FRAMES * JOINTS * (2 + 2 + 3) + 4   # frames + both targets in, nothing out but three scalars
+
+
+def step_sweep(device, sizes=(256, 1024, 8192, 65536)):
+    """The whole train step (trainer.train_step on a resident batch: LinearAE pose_changes, loc_2d_3d, fp32, AdamW in the step) at
+    several batch sizes: ms per step from three blocks of wall-clocked steps (min), clips/s, the fraction of the fp32-MFMA peak
+    (1.61 MFLOP per clip) and of the HBM peak (11 652 B per clip) that rate corresponds to, and the step's launches, each timed
+    through p2c_train_step_launch. `forms` names which form of the two launches ran (latency / throughput)."""
+    from pedestrians_video_2_carla_amd import _lib
+    lib = _lib.lib()
+    stream_min, wgrad_min = lib.p2c_train_step_set_stream_min_batch(-1), lib.p2c_train_step_set_wgrad_stream_min_batch(-1)
+    out = []
+    for Bs in sizes:
+        flow, dm, trainer, batch = build_step(device, Bs, True, True)
+        steps = max(10, min(200, (1 << 21) // Bs))
+        for i in range(10):
+            trainer.train_step(flow, batch, i)
+        torch.cuda.synchronize(device)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for i in range(steps):
+                trainer.train_step(flow, batch, i)
+            torch.cuda.synchronize(device)
+            ts.append((time.perf_counter() - t0) / steps)
+        sec = min(ts)
+        rate = Bs / sec
+        entry = {'B': Bs, 'ms_per_step': round(sec * 1e3, 4), 'clips_per_s': round(rate, 1),
+                 'frac_mfma_f32': round(rate * STEP_FLOPS_PER_CLIP / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                 'frac_hbm': round(rate * STEP_BYTES_PER_CLIP / 1e9 / HBM_PEAK_GBPS, 5),
+                 'two_launch_step': getattr(flow, '_pair_counts', None) is not None}
+        fused = fused_step_times(device, flow, trainer, batch)
+        if fused is not None:
+            entry['launch_us'] = {k: round(v, 2) for k, v in fused[0].items()}
+            entry['forms'] = {'first_launch': 'train_stream_kernel (a pair of wavefronts per clip)' if Bs >= stream_min
+                              else 'train_clip_kernel (a workgroup per clip)',
+                              'second_launch': 'wgrad_stream_kernel + wgrad_reduce_kernel' if Bs >= wgrad_min
+                              else 'train_wgrad_kernel (combine, AdamW and losses in the launch)'}
+        out.append(entry)
+        del flow, dm, trainer, batch
+        torch.cuda.empty_cache()
+    return out
 
 
 def mfma_entry(name, B, us, flops):
@@ -809,6 +857,12 @@ def main():
                     e['us_per_op_with_loss_finalize'] = round(k['fwd_op'], 2)
                 sweep.append(e)
         result['roofline_sweep'] = sweep
+        # the FULL train step over batch sizes (SURVEY section 8d units: 1.61 MFLOP of LinearAE forward + dgrad + wgrad and 11 652 B of
+        # frames + targets per clip): clips/s and both roofline fractions, with the launches the step consists of at that size
+        try:
+            result['step_sweep'] = step_sweep(device)
+        except Exception as e:                                      # noqa: BLE001 -- a sweep point must not sink the headline
+            result['step_sweep'] = {'error': repr(e)[:300]}
     if not args.no_extra_configs and world == 1:
         extra = {}
         for name in ('cfg2', 'cfg3', 'cfg5'):

@@ -166,19 +166,27 @@ __device__ __forceinline__ void fwd_tiles(const WLane &L, const float *wl, const
     }
   }
 }
-template <int LL>
-__device__ __forceinline__ void fwd_layer(const WLane &L, const float *img, const float *in, float *out, uint64_t &mask) {
-  constexpr int KS_ = ksteps_fwd(LL), NT_ = ntiles_fwd(LL);
+// The two wavefronts of a pair split a layer's output tiles: the first takes tiles [0, ceil(n / 2)), the second the rest. Both
+// sit on one SIMD and share its matrix pipe -- the split buys no MFMA rate, it fills one wave's start-up (first operands exposed),
+// epilogue and factor stores with the other's MFMAs. The same split of H_l's tiles in the forward (as layer l-1's output) and in
+// the dgrad (as layer l's m-tiles) keeps a lane's ReLU mask bits with the wave that needs them.
+__host__ __device__ constexpr int split0(int n) { return (n + 1) / 2; }
+template <int LL, int T0, int CNT>
+__device__ __forceinline__ void fwd_range(const WLane &L, const float *img, const float *in, float *out, uint64_t &mask) {
+  constexpr int KS_ = ksteps_fwd(LL);
   constexpr bool RELU = LL < NLAY - 1;
   const float *wl = img + S::w_off(LL);
-  // up to GROUP tiles share one pass over k: one B operand read feeds GROUP MFMAs, and a pass has one start-up (first operands
-  // exposed) and one epilogue instead of one per pair of tiles
-#pragma unroll
-  for (int nt = 0; nt < NT_; nt += GROUP) {
-    constexpr int REST = NT_ % GROUP;
-    if (nt + GROUP <= NT_) fwd_tiles<GROUP, KS_, RELU>(L, wl, S::ld(LL), nt, in, out, mask, mask_bit0(LL + 1));
-    else fwd_tiles<(REST ? REST : 1), KS_, RELU>(L, wl, S::ld(LL), nt, in, out, mask, mask_bit0(LL + 1));
+  // up to GROUP tiles share one pass over k: one B operand read feeds GROUP MFMAs, and a pass has one start-up and one epilogue
+  if constexpr (CNT > 0) {
+    static_assert(CNT <= GROUP, "one pass per wave and layer");
+    fwd_tiles<CNT, KS_, RELU>(L, wl, S::ld(LL), T0, in, out, mask, mask_bit0(LL + 1));
   }
+}
+template <int LL>
+__device__ __forceinline__ void fwd_layer(const WLane &L, const int half, const float *img, const float *in, float *out, uint64_t &mask) {
+  constexpr int NT_ = ntiles_fwd(LL), N0 = split0(NT_);
+  if (half == 0) fwd_range<LL, 0, N0>(L, img, in, out, mask);
+  else fwd_range<LL, N0, NT_ - N0>(L, img, in, out, mask);
 }
 
 // gout^T[m][t] = relu'(H[m][t]) * sum_k W[k][m] gin^T[k][t] for NT consecutive m-tiles (the mask bits stand in for H)
@@ -233,16 +241,21 @@ __device__ __forceinline__ void dgrad_tiles(const WLane &L, const float *wl, con
     }
   }
 }
-template <int LL>   // G_LL from G_{LL+1}, LL = 5 .. 1
-__device__ __forceinline__ void dgrad_layer(const WLane &L, const float *img, const float *gin, float *gout, const uint64_t mask) {
-  constexpr int KS_ = ksteps_bwd(LL), MT_ = mtiles_bwd(LL);
+template <int LL, int T0, int CNT>
+__device__ __forceinline__ void dgrad_range(const WLane &L, const float *img, const float *gin, float *gout, const uint64_t mask) {
+  constexpr int KS_ = ksteps_bwd(LL);
   const float *wl = img + S::w_off(LL);
-#pragma unroll
-  for (int mt = 0; mt < MT_; mt += GROUP) {
-    constexpr int REST = MT_ % GROUP;
-    if (mt + GROUP <= MT_) dgrad_tiles<GROUP, KS_>(L, wl, S::ld(LL), mt, S::dims(LL), gin, gout, mask, mask_bit0(LL));
-    else dgrad_tiles<(REST ? REST : 1), KS_>(L, wl, S::ld(LL), mt, S::dims(LL), gin, gout, mask, mask_bit0(LL));
+  if constexpr (CNT > 0) {
+    static_assert(CNT <= GROUP, "one pass per wave and layer");
+    dgrad_tiles<CNT, KS_>(L, wl, S::ld(LL), T0, S::dims(LL), gin, gout, mask, mask_bit0(LL));
   }
+}
+template <int LL>   // G_LL from G_{LL+1}, LL = 5 .. 1
+__device__ __forceinline__ void dgrad_layer(const WLane &L, const int half, const float *img, const float *gin, float *gout, const uint64_t mask) {
+  constexpr int MT_ = mtiles_bwd(LL), M0 = split0(MT_);
+  static_assert(LL == 0 || mtiles_bwd(LL) == ntiles_fwd(LL - 1) || LL < 1, "H_l: same tiles in the forward and in the dgrad");
+  if (half == 0) dgrad_range<LL, 0, M0>(L, img, gin, gout, mask);
+  else dgrad_range<LL, M0, MT_ - M0>(L, img, gin, gout, mask);
 }
 
 // `rows` rows of a region (64 contiguous bytes each) -> the clip's factor block: straight 16-byte copies, 1 KB per instruction.
@@ -252,6 +265,17 @@ template <int ROWS>
 struct RowRegs {
   f32x4 v[(ROWS * 4 + 63) / 64];
 };
+// the first wavefront's share of `rows` factor rows: whole 16-row (1 KB) pieces, about half of them
+__host__ __device__ constexpr int rows0(int rows) { return ((rows / 16 + 1) / 2) * 16 < rows ? ((rows / 16 + 1) / 2) * 16 : rows; }
+template <int ROWS>
+struct HalfRows {          // registers for either share
+  static constexpr int R0 = rows0(ROWS), R1 = ROWS - rows0(ROWS), RM = R0 > R1 ? R0 : R1;
+  RowRegs<(RM > 0 ? RM : 1)> r;
+};
+template <int ROWS>
+__device__ __forceinline__ void half_read(const float *src, const int lane, const int half, HalfRows<ROWS> &h);
+template <int ROWS>
+__device__ __forceinline__ void half_store(const HalfRows<ROWS> &h, float *dst, const int lane, const int half);
 template <int ROWS>
 __device__ __forceinline__ void rows_read(const float *src, const int lane, RowRegs<ROWS> &r) {
   const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src);
@@ -272,6 +296,29 @@ __device__ __forceinline__ void rows_store(const RowRegs<ROWS> &r, float *dst, c
     // The hardware needs two wait states, inside the string (cdna_hip_programming.md, inline-asm rules: stores).
     if (!(P2C_STREAM_EXPERIMENT & 4) && ((i + 1) * 64 <= ROWS * 4 || p < ROWS * 4))
       asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(d4 + p), "v"(r.v[i]) : "memory");
+  }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void half_read(const float *src, const int lane, const int half, HalfRows<ROWS> &h) {
+  constexpr int R0 = HalfRows<ROWS>::R0, R1 = HalfRows<ROWS>::R1, RM = HalfRows<ROWS>::RM;
+  const f32x4 *s4 = reinterpret_cast<const f32x4 *>(src) + (half ? R0 * 4 : 0);
+  const int n4 = (half ? R1 : R0) * 4;
+#pragma unroll
+  for (int i = 0; i < (RM * 4 + 63) / 64; ++i) {
+    const int p = i * 64 + lane;
+    h.r.v[i] = s4[p < n4 ? p : 0];
+  }
+}
+template <int ROWS>
+__device__ __forceinline__ void half_store(const HalfRows<ROWS> &h, float *dst, const int lane, const int half) {
+  constexpr int R0 = HalfRows<ROWS>::R0, R1 = HalfRows<ROWS>::R1, RM = HalfRows<ROWS>::RM;
+  f32x4 *d4 = reinterpret_cast<f32x4 *>(dst) + (half ? R0 * 4 : 0);
+  const int n4 = (half ? R1 : R0) * 4;
+#pragma unroll
+  for (int i = 0; i < (RM * 4 + 63) / 64; ++i) {
+    const int p = i * 64 + lane;
+    if (!(P2C_STREAM_EXPERIMENT & 4) && p < n4) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(d4 + p), "v"(h.r.v[i]) : "memory");
   }
 }
 
@@ -675,90 +722,119 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
     PoseIn pin;
     pin.st = 0;
     if (active) pose_inputs(d, (int)clip, lane0, half, pin);
-    if (half == 0 && active && !(P2C_STREAM_EXPERIMENT & 2)) {
-      // ---- LinearAE forward by the pair's first wavefront; every H_l leaves for the factor block as soon as it exists ---------------
+    const bool mlp = active && !(P2C_STREAM_EXPERIMENT & 2);
+    {
+      // ---- LinearAE forward, the pair's two wavefronts side by side (one barrier per layer); every H_l leaves for the factor
+      // block as soon as it exists ---------------------------------------------------------------------------------------------------
       WLane L;
       L.lane = fresh(lane0), L.c = L.lane & 15, L.g = L.lane >> 4;
       ST(3);
-      RowRegs<S::dims(0)> h0;
-      rows_read(Y, L.lane, h0);
-      fwd_layer<0>(L, img, Y, A, mask);
-      pose_inputs_landed(pin);                     // (in front of the first factor store)
-      rows_store(h0, fdst + f_h_off(0) * 16, L.lane);
+      HalfRows<S::dims(0)> h0;
+      if (mlp) {
+        half_read(Y, L.lane, half, h0);
+        fwd_layer<0>(L, half, img, Y, A, mask);
+        pose_inputs_landed(pin);                   // (in front of the first factor store: the wait covers loads only)
+        half_store(h0, fdst + f_h_off(0) * 16, L.lane, half);
+      }
+      lds_barrier();
       ST(4);
-      RowRegs<S::dims(1)> h1;
-      rows_read(A, L.lane, h1);
-      fwd_layer<1>(L, img, A, Bb, mask);
-      rows_store(h1, fdst + f_h_off(1) * 16, L.lane);
+      HalfRows<S::dims(1)> h1;
+      if (mlp) {
+        half_read(A, L.lane, half, h1);
+        fwd_layer<1>(L, half, img, A, Bb, mask);
+        half_store(h1, fdst + f_h_off(1) * 16, L.lane, half);
+      }
+      lds_barrier();
       ST(5);
-      RowRegs<S::dims(2)> h2;
-      rows_read(Bb, L.lane, h2);
-      fwd_layer<2>(L, img, Bb, A, mask);
-      rows_store(h2, fdst + f_h_off(2) * 16, L.lane);
+      HalfRows<S::dims(2)> h2;
+      if (mlp) {
+        half_read(Bb, L.lane, half, h2);
+        fwd_layer<2>(L, half, img, Bb, A, mask);
+        half_store(h2, fdst + f_h_off(2) * 16, L.lane, half);
+      }
+      lds_barrier();
       ST(6);
-      RowRegs<S::dims(3)> h3;
-      rows_read(A, L.lane, h3);
-      fwd_layer<3>(L, img, A, Bb, mask);
-      rows_store(h3, fdst + f_h_off(3) * 16, L.lane);
+      HalfRows<S::dims(3)> h3;
+      if (mlp) {
+        half_read(A, L.lane, half, h3);
+        fwd_layer<3>(L, half, img, A, Bb, mask);
+        half_store(h3, fdst + f_h_off(3) * 16, L.lane, half);
+      }
+      lds_barrier();
       ST(7);
-      RowRegs<S::dims(4)> h4;
-      rows_read(Bb, L.lane, h4);
-      fwd_layer<4>(L, img, Bb, A, mask);
-      rows_store(h4, fdst + f_h_off(4) * 16, L.lane);
+      HalfRows<S::dims(4)> h4;
+      if (mlp) {
+        half_read(Bb, L.lane, half, h4);
+        fwd_layer<4>(L, half, img, Bb, A, mask);
+        half_store(h4, fdst + f_h_off(4) * 16, L.lane, half);
+      }
+      lds_barrier();
       ST(8);
-      RowRegs<S::dims(5)> h5;
-      rows_read(A, L.lane, h5);
-      fwd_layer<5>(L, img, A, Y, mask);
-      rows_store(h5, fdst + f_h_off(5) * 16, L.lane);
+      HalfRows<S::dims(5)> h5;
+      if (mlp) {
+        half_read(A, L.lane, half, h5);
+        fwd_layer<5>(L, half, img, A, Y, mask);
+        half_store(h5, fdst + f_h_off(5) * 16, L.lane, half);
+      }
       ST(9);
-    } else {
-      pose_inputs_landed(pin);                     // (every path pins them: no wait is left for the common code behind the barrier)
     }
     lds_barrier();                                 // ---- y^T is complete (and buffer A is free: the pose head's hand-over scratch) ----
     // ---- pose head forward + backward by both wavefronts of the pair: y^T -> grad_y^T in place --------------------------------------
     pose_phase<KIND>(d, active && !(P2C_STREAM_EXPERIMENT & 1), (int)clip, lane0, half, pin, Y, A, tab, coef2, coef3);
     ST(32);
-    const bool mlp = half == 0 && active && !(P2C_STREAM_EXPERIMENT & 2);
-    WLane Ld;
-    Ld.lane = fresh(lane0), Ld.c = Ld.lane & 15, Ld.g = Ld.lane >> 4;
-    RowRegs<S::dims(6)> g6;
-    if (half != 0) x_issue(m.x, clip + stride, d.B, T, Ld.lane, xr);   // the pair's next clip: lands behind the first dgrad layer
-    if (mlp) {
-      // ---- dgrad chain; every G_l leaves as soon as it exists ----------------------------------------------------------------------
-      rows_read(Y, Ld.lane, g6);
-      dgrad_layer<5>(Ld, img, Y, A, mask);
-      rows_store(g6, fdst + f_g_off(6) * 16, Ld.lane);
+    {
+      WLane L;
+      L.lane = fresh(lane0), L.c = L.lane & 15, L.g = L.lane >> 4;
+      if (half != 0) x_issue(m.x, clip + stride, d.B, T, L.lane, xr);   // the pair's next clip: lands behind the first dgrad layer
+      // ---- dgrad chain, side by side; every G_l leaves as soon as it exists ----------------------------------------------------------
+      HalfRows<S::dims(6)> g6;
+      if (mlp) {
+        half_read(Y, L.lane, half, g6);
+        dgrad_layer<5>(L, half, img, Y, A, mask);
+        half_store(g6, fdst + f_g_off(6) * 16, L.lane, half);
+      }
+      lds_barrier();                               // ---- grad_y^T has been read: the y rows are free for the next clip's H_0 ----
       ST(33);
-    }
-    lds_barrier();                                 // ---- grad_y^T has been read: the y rows are free for the next clip's H_0 ----
-    if (half != 0 && clip + stride < d.B) x_commit(xr, x_offsets(Ld.lane), Y, Ld.lane);
-    if (mlp) {
-      const WLane &L = Ld;
-      RowRegs<S::dims(5)> g5;
-      rows_read(A, L.lane, g5);
-      dgrad_layer<4>(L, img, A, Bb, mask);
-      rows_store(g5, fdst + f_g_off(5) * 16, L.lane);
+      HalfRows<S::dims(5)> g5;
+      if (mlp) {
+        half_read(A, L.lane, half, g5);
+        dgrad_layer<4>(L, half, img, A, Bb, mask);
+        half_store(g5, fdst + f_g_off(5) * 16, L.lane, half);
+      }
+      if (half != 0 && clip + stride < d.B) x_commit(xr, x_offsets(L.lane), Y, L.lane);   // (its share of this layer is the small one)
+      lds_barrier();
       ST(34);
-      RowRegs<S::dims(4)> g4;
-      rows_read(Bb, L.lane, g4);
-      dgrad_layer<3>(L, img, Bb, A, mask);
-      rows_store(g4, fdst + f_g_off(4) * 16, L.lane);
+      HalfRows<S::dims(4)> g4;
+      if (mlp) {
+        half_read(Bb, L.lane, half, g4);
+        dgrad_layer<3>(L, half, img, Bb, A, mask);
+        half_store(g4, fdst + f_g_off(4) * 16, L.lane, half);
+      }
+      lds_barrier();
       ST(35);
-      RowRegs<S::dims(3)> g3;
-      rows_read(A, L.lane, g3);
-      dgrad_layer<2>(L, img, A, Bb, mask);
-      rows_store(g3, fdst + f_g_off(3) * 16, L.lane);
+      HalfRows<S::dims(3)> g3;
+      if (mlp) {
+        half_read(A, L.lane, half, g3);
+        dgrad_layer<2>(L, half, img, A, Bb, mask);
+        half_store(g3, fdst + f_g_off(3) * 16, L.lane, half);
+      }
+      lds_barrier();
       ST(36);
-      RowRegs<S::dims(2)> g2;
-      rows_read(Bb, L.lane, g2);
-      dgrad_layer<1>(L, img, Bb, A, mask);
-      rows_store(g2, fdst + f_g_off(2) * 16, L.lane);
-      RowRegs<S::dims(1)> g1;
-      rows_read(A, L.lane, g1);
-      rows_store(g1, fdst + f_g_off(1) * 16, L.lane);
+      HalfRows<S::dims(2)> g2;
+      if (mlp) {
+        half_read(Bb, L.lane, half, g2);
+        dgrad_layer<1>(L, half, img, Bb, A, mask);
+        half_store(g2, fdst + f_g_off(2) * 16, L.lane, half);
+      }
+      lds_barrier();
+      HalfRows<S::dims(1)> g1;
+      if (mlp) {
+        half_read(A, L.lane, half, g1);
+        half_store(g1, fdst + f_g_off(1) * 16, L.lane, half);
+      }
       ST(37);
     }
-    lds_barrier();                                 // ---- the next clip's H_0 is in place ----
+    lds_barrier();                                 // ---- the next clip's H_0 is in place, buffer A has been read ----
     ST(63);
   }
 }

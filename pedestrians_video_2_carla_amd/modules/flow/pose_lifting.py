@@ -168,7 +168,7 @@ class LitPoseLiftingFlow(LitBaseFlow):
     def _fused_train_plan(self, frames, targets):
         """(PoseHeadSpec, gt2d, gt3d) when this batch can take ``ops.fused_train_step`` -- LinearAE with the 6-D rotation
         output on CARLA nodes, built-in transform, fusable losses, lean outputs, one clip per 16-sample tile, a small
-        batch (``P2C_FUSED_TRAIN_MAX_B``, default 2048: the measured crossover with the separate kernels -- 1536: 107 vs 120 us, 2048: 139 vs 141, 3072: 202 vs 189) -- else None.
+        batch where only the one-workgroup-per-clip form applies (world motion or foreign target layouts: up to 2048 clips, the measured crossover with the separate kernels; ``P2C_FUSED_TRAIN_MAX_B`` sets a hard limit) -- else None.
         ``P2C_FUSED_TRAIN=0`` turns the path off. Everything but the two target tensors is a function of the configuration
         and the batch shape: it is worked out once per (shape, configuration) and cached."""
         import os
@@ -185,7 +185,7 @@ class LitPoseLiftingFlow(LitBaseFlow):
             return spec, (targets[gt2d_key] if gt2d_key else None), (targets.get('absolute_pose_loc') if want3d else None)
         transform_callable = self.datamodule.transform_callable
         key = (tuple(frames.shape), frames.device, frames.dtype, tuple(targets.keys()), os.environ.get('P2C_FUSED_TRAIN', '1'),
-               os.environ.get('P2C_FUSED_TRAIN_MAX_B', '2048'), self.lean_train_outputs, type(model), model.eval_slice.start,
+               os.environ.get('P2C_FUSED_TRAIN_MAX_B', ''), self.lean_train_outputs, type(model), model.eval_slice.start,
                model.eval_slice.stop, getattr(model, 'rotation_output_format', None), id(transform_callable),
                id(self.trajectory_model), bool(self.mask_missing_joints), model.fused_mlp, model.training, model.mlp_precision,
                tuple(targets[k].shape for k in ('projection_2d_transformed', 'projection_2d', 'absolute_pose_loc') if k in targets))
@@ -210,7 +210,10 @@ class LitPoseLiftingFlow(LitBaseFlow):
         if not (frames.is_cuda and frames.dtype == torch.float32 and frames.ndim == 4):
             return None
         B, T = frames.shape[0], frames.shape[1]
-        if B > int(os.environ.get('P2C_FUSED_TRAIN_MAX_B', '2048')) or model.input_nodes is not CARLA_SKELETON:
+        if model.input_nodes is not CARLA_SKELETON:
+            return None
+        max_b = os.environ.get('P2C_FUSED_TRAIN_MAX_B')
+        if max_b is not None and B > int(max_b):
             return None
         if model.output_type not in (MovementsModelOutputType.pose_changes, MovementsModelOutputType.relative_rot) \
                 or getattr(model, 'rotation_output_format', None) != 'rotation_6d':
@@ -228,6 +231,15 @@ class LitPoseLiftingFlow(LitBaseFlow):
         absolute = (self.trajectory_model.output_type == TrajectoryModelOutputType.loc_rot
                     and not bool(getattr(self.trajectory_model, 'is_identity', False)))
         spec = ops.PoseHeadSpec(kind=kind, world_absolute=absolute, **self._spec_kwargs(transform_callable, targets))
+        if max_b is None and B > 2048:
+            # Beyond ~2 000 clips the fused step pays only in its throughput form (csrc/p2c_train_stream.hip: a pair of wavefronts
+            # per clip; 8192 clips: 345 us against 383 us for the separate kernels and 520 us for the one-workgroup-per-clip form),
+            # which needs the plain case: no world motion, targets in the model's own joint layout.
+            ident = list(range(len(spec.gmap2d)))
+            plain = (bool(getattr(self.trajectory_model, 'is_identity', False)) and list(spec.gmap2d) == ident
+                     and list(spec.gmap3d) == ident)
+            if not plain:
+                return None
         return spec, gt2d_key, ('loc_3d' in names)
 
     def _fused_train_step(self, frames, targets, stage):

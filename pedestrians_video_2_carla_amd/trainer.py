@@ -14,6 +14,7 @@ Two execution modes:
 """
 import contextlib
 import os
+import sys
 from typing import Dict, Iterable, List, Optional
 
 import torch
@@ -497,7 +498,7 @@ class Trainer:
         if not (diff <= 0.05 * scale):                       # (NaN compares false)
             print(f'[trainer] the captured step does not replay reproducibly (its update differs from the eager step\'s by {diff:.3e} '
                   f'of {scale:.3e} after other allocations): a framework reduction in its backward? Falling back to eager steps.',
-                  flush=True)
+                  file=sys.stderr, flush=True)
             self._graphs = None
             self._direct = None
             self.use_graph = False
@@ -582,7 +583,7 @@ class Trainer:
         if strict:
             raise RuntimeError(f'P2C_GRAPH_ALLREDUCE=1: capturing the all-reduce failed ({err!r})')
         if dist.get_rank() == 0:
-            print(f'[trainer] captured all-reduce unavailable ({err!r}); using the eager collective', flush=True)
+            print(f'[trainer] captured all-reduce unavailable ({err!r}); using the eager collective', file=sys.stderr, flush=True)
         return False
 
     def _state_tensors(self, flow):
