@@ -572,6 +572,9 @@ P2C_API int p2c_gemm(const p2c_gemm_desc *desc, void *stream);
  * row_scale[k / rows_per_scale] as it is loaded (dy of a layer whose output carried a per-sample stochastic-depth factor).
  * bias_out (M) or NULL: the column sums of the scaled A (= db) from the same pass. */
 P2C_API int64_t p2c_gemm_tn_workspace_floats(int32_t M, int32_t N, int32_t K);
+/* The tile / slice experiment variables (P2C_GEMM_BN, P2C_GEMM_TN_BN, P2C_GEMM_TN_SLICES) are read once; a tool that changes
+ * them inside one process calls this to have them read again. */
+P2C_API void p2c_gemm_reload_env(void);
 P2C_API int p2c_gemm_tn(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t M, int32_t N,
                 int32_t K, int32_t accumulate, const float *row_scale, int32_t rows_per_scale, float *bias_out,
                 float *workspace, void *stream);

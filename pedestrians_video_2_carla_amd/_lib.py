@@ -121,6 +121,7 @@ SYMBOLS = {
     'p2c_debug_poison_lds': (ctypes.c_int, [_vp]),
     'p2c_frame_mean_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     'p2c_gemm_tn_workspace_floats': (_i64, [_i32, _i32, _i32]),
+    'p2c_gemm_reload_env': (None, []),
     'p2c_gemm_tn': (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     'p2c_pose_head_bwd': (ctypes.c_int, [ctypes.POINTER(PoseHeadDesc), ctypes.POINTER(_vp * 3), _vp, _vp, _vp, _vp, _vp]),
     'p2c_normalize_fwd': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _ip, _i32, _ip,

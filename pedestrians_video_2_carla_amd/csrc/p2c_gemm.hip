@@ -847,12 +847,29 @@ static void launch(const p2c_gemm_desc &d, bool vec, hipStream_t s) {
 
 }  // namespace p2c_gemm_impl
 
+// Experiment knobs (tools/tn_bench.py, tools/gemm_bench.py): read from the environment ONCE -- dense() routes every fp32 2-D linear
+// here, and a getenv per eager launch is host time; a workspace sized under one value and a launch under another would also
+// write past the workspace. p2c_gemm_reload_env() re-reads them (the sweep tools call it after changing a variable).
+static int g_env_tn_bn = -1, g_env_tn_slices = -1, g_env_bn = -1;
+static bool g_env_read = false;
+static void gemm_env() {
+  if (g_env_read) return;
+  const char *e = getenv("P2C_GEMM_TN_BN");
+  g_env_tn_bn = e ? atoi(e) : 0;
+  e = getenv("P2C_GEMM_TN_SLICES");
+  g_env_tn_slices = e ? atoi(e) : 0;
+  e = getenv("P2C_GEMM_BN");
+  g_env_bn = e ? atoi(e) : 0;
+  g_env_read = true;
+}
+extern "C" P2C_API void p2c_gemm_reload_env(void) {
+  g_env_read = false;
+  gemm_env();
+}
 static int tn_bn(int N) {
   int bn = N > 32 ? 64 : 32;                          // (64: measured ahead of 128 at 832 x 832, equal elsewhere)
-  if (const char *e = getenv("P2C_GEMM_TN_BN")) {     // (experiments)
-    const int v = atoi(e);
-    if (v == 32 || v == 64 || v == 128) bn = v;
-  }
+  gemm_env();
+  if (g_env_tn_bn == 32 || g_env_tn_bn == 64 || g_env_tn_bn == 128) bn = g_env_tn_bn;     // (experiments)
   return bn;
 }
 static int tn_slices(int M, int N, int K) {
@@ -861,10 +878,8 @@ static int tn_slices(int M, int N, int K) {
   const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
   int max_s = K / (16 * BK);                             // at least 16 k-tiles per slice
   max_s = max_s < 1 ? 1 : (max_s > 1024 ? 1024 : max_s);
-  if (const char *e = getenv("P2C_GEMM_TN_SLICES")) {     // (experiments: tools/tn_bench.py sweeps it)
-    const int v = atoi(e);
-    if (v >= 1) return v > max_s ? max_s : v;
-  }
+  gemm_env();
+  if (g_env_tn_slices >= 1) return g_env_tn_slices > max_s ? max_s : g_env_tn_slices;     // (experiments: tools/tn_bench.py sweeps it)
   if (tiles < 64) {
     // a skinny output over very many rows (the spatial blocks' 96 x 32 from 546 624 rows) is a streaming pass over A and B:
     // what counts is enough workgroups in flight to pull the rows in -- about four per CU
@@ -976,10 +991,8 @@ extern "C" int p2c_gemm(const p2c_gemm_desc *desc, void *stream_) {
   if (d.K <= 128)
     for (int cand = bn >> 1; cand >= 32; cand >>= 1)
       if ((d.N + cand - 1) / cand * cand < (d.N + bn - 1) / bn * bn) bn = cand;
-  if (const char *e = getenv("P2C_GEMM_BN")) {        // (experiments)
-    const int v = atoi(e);
-    if (v == 32 || v == 64 || v == 128) bn = v;
-  }
+  gemm_env();
+  if (g_env_bn == 32 || g_env_bn == 64 || g_env_bn == 128) bn = g_env_bn;     // (experiments)
   if (d.trans_b) {
     if (bn == 128) launch<128, true>(d, vec, s);
     else if (bn == 64) launch<64, true>(d, vec, s);

@@ -326,6 +326,12 @@ class Trainer:
         if (gt2d is not None and key2 is None) or (gt3d is not None and key3 is None):
             return None
         d = self._direct['desc']
+        # the recorded call must read the static batch's OWN tensors: a converted copy inside the recorded step would be swapped out
+        # silently by a hand-over
+        want = (frames.data_ptr(), gt2d.data_ptr() if gt2d is not None else d.head.gt2d,
+                gt3d.data_ptr() if gt3d is not None else d.head.gt3d, st.data_ptr())
+        if (d.mlp.x, d.head.gt2d, d.head.gt3d, d.head.skel_type) != want:
+            return None
         return {'key2': key2, 'key3': key3, 'device': frames.device,
                 'shapes': (tuple(frames.shape), tuple(gt2d.shape) if gt2d is not None else None,
                            tuple(gt3d.shape) if gt3d is not None else None, tuple(st.shape)),
@@ -363,7 +369,7 @@ class Trainer:
             if shape is None:
                 continue
             if not (isinstance(t, torch.Tensor) and t.device == dev and t.dtype == dt and tuple(t.shape) == shape
-                    and t.is_contiguous()):
+                    and t.is_contiguous() and t.data_ptr() % 16 == 0):      # (p2c_train_step_launch wants 16-byte aligned rows)
                 return refuse()
         d = self._direct['desc']
         d.mlp.x, d.head.skel_type = frames.data_ptr(), st.data_ptr()
@@ -457,7 +463,9 @@ class Trainer:
             self._verify_replay(flow, snapshot)
 
     def _verify_replay(self, flow, snapshot):
-        """Capture-time check: the new graph is replayed twice -- other tensors allocated, written and freed before each replay --
+        """(Single-GPU captures only: the distributed captures -- all-reduce in the graph, or stage A with an eager optimizer -- are
+        NOT compared with an eager step here; ``ranks_agree`` only establishes that every rank holds the same bits.)
+        Capture-time check: the new graph is replayed twice -- other tensors allocated, written and freed before each replay --
         and its parameter update compared with the same step issued eagerly from the same parameters and random-number state
         (a captured step draws the same philox offsets as the eager one; the build's kernels give the same bits either way:
         measured difference exactly 0 for cfg2 / cfg3 / cfg5 with dropout and stochastic depth on). A step that reads memory the
