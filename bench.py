@@ -500,9 +500,10 @@ def cpu_baseline(batch_size, seconds):
               'sample': f'{n} steps of B={batch_size},T={T_FRAMES} (op-for-op port of the reference step, eager PyTorch '
                         f'CPU fp32, {torch.get_num_threads()} threads)',
               'cpu_model': _cpu_model(), 'host_cores': os.cpu_count(),
-              'note': 'optimistic by about 1.8x: the port builds a light per-clip object where the reference builds a '
-                      'ControlledPedestrian + P3dPose + 26 mock transforms per clip (BASELINE.md section 2: 447.6 ms for the '
-                      'real reference vs about 250 ms for this port on the same 8 vCPU)'}
+              'note': 'per-clip Python objects restated object for object since round 4 (ControlledPedestrian + P3dPose(nn.Module) + '
+                      'one mock Transform / Location / Rotation per bone): 262 us per clip against 297 us for the reference\'s own '
+                      'constructor timed in the build container, the whole step 513 ms there against 447.6 ms for the reference '
+                      'in BASELINE.md section 2 (another, quieter 8-vCPU container)'}
     # one thread
     torch.set_num_threads(1)
     n1, t0 = 0, time.perf_counter()
@@ -677,13 +678,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, script=None, have=None):
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks here, as the reference starts its own
     (modeling.py:275-282 -> Lightning re-runs the script once per GPU under `--gpus=0,1 --accelerator=ddp`, README.md:74-75).
     N fresh child processes of this script, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; this parent makes no GPU call
     (torch.cuda.device_count() only reads the device list) and does not replace itself. Rank 0's stdout is passed through
     (the ONE JSON line); any failing rank stops the others and the exit code is non-zero."""
-    have = torch.cuda.device_count()
+    # (script / have: the rank program and the device count, for the CPU test of this launcher -- tests/test_host_logic.py)
+    have = torch.cuda.device_count() if have is None else have
     if have < n:
         raise SystemExit(f'bench.py --gpus {n}: this host shows {have} GPU(s); refusing to report an n_gpus={n} line from fewer ranks')
     env0 = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(os.environ.get('MASTER_PORT') or _free_port()),
@@ -692,7 +694,7 @@ def launch_ranks(n, argv):
     try:
         for r in range(n):
             env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(script or __file__)] + list(argv), env=env,
                                           stdout=None if r == 0 else subprocess.DEVNULL))
         rc, pending = 0, list(procs)
         while pending and rc == 0:

@@ -14,46 +14,132 @@ loss/base_pose_loss.py:36-66, loss/loc_3d.py:12-40; modules/flow/base.py:397-469
 """
 import copy
 import math
+import time
 from collections import OrderedDict
 from typing import Dict, List
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
 from oracle import pose_head as O
 
 
-class _Transform:                       # stand-in for the 26 mock carla.Transform objects built per clip
-    __slots__ = ('loc', 'rot')
+# ---- the per-clip Python object, restated object for object (round 4: the round-3 port built one light object per bone and no Pose;
+# bench.py labelled its time "optimistic by about 1.8x") ------------------------------------------------------------------------
+class _Location:                        # carla_utils/mock_carla.py:20-30
+    def __init__(self, x: float = 0.0, y: float = 0.0, z: float = 0.0):
+        self.x = x
+        self.y = y
+        self.z = z
 
-    def __init__(self, loc, rot):
-        self.loc, self.rot = loc, rot
+
+class _Rotation:                        # mock_carla.py:33-43
+    def __init__(self, pitch: float = 0.0, yaw: float = 0.0, roll: float = 0.0):
+        self.pitch = pitch
+        self.yaw = yaw
+        self.roll = roll
+
+
+class _Transform:                       # mock_carla.py:8-17: a Transform always owns a Location and a Rotation object
+    def __init__(self, location=None, rotation=None):
+        self.location = location if location is not None else _Location()
+        self.rotation = rotation if rotation is not None else _Rotation()
+
+
+_FILES = {}
+
+
+def _load(kind: str):
+    """data/carla/utils.py:16-37 ``load`` (lru_cache): the parsed reference files -- 'structure' as the nested {bone: [children]}
+    list of structure.yaml, a skeleton as {'transforms': {bone: {'location': {x, y, z}, 'rotation': {pitch, yaw, roll}}}} in cm / deg."""
+    if kind not in _FILES:
+        data = O.load_skeleton_data()
+        if kind == 'structure':
+            par, names = O.parents(), list(data['bones'])
+
+            def node(j):
+                kids = [node(c) for c in range(len(par)) if par[c] == j]
+                return {names[j]: kids if kids else None}
+            _FILES[kind] = {'structure': [node(0)]}
+        else:
+            sk = data['skeletons'][kind]
+            _FILES[kind] = {'transforms': {
+                name: {'location': {'x': float(loc[0]), 'y': float(loc[1]), 'z': float(loc[2])},
+                       'rotation': {'pitch': float(rot[0]), 'yaw': float(rot[1]), 'roll': float(rot[2])}}
+                for name, loc, rot in zip(data['bones'], sk['location_cm'], sk['rotation_deg'])}}
+    return _FILES[kind]
+
+
+class _PortPoseBase(object):
+    def __init__(self, *args, **kwargs):
+        super().__init__()              # (pose.py:27: continues along the MRO into torch.nn.Module.__init__)
+
+
+class _PortPose(_PortPoseBase, torch.nn.Module):
+    """walker_control/pose.py:22-39 ``Pose.__init__`` + walker_control/p3d_pose.py:23-32 ``P3dPose(Pose, torch.nn.Module).__init__``:
+    the bone order from the structure file by recursion into an OrderedDict, a deepcopy of it, the modification stamp -- on an
+    nn.Module, as in the reference: every attribute assignment goes through Module.__setattr__ (a third of the object's cost)."""
+
+    def __init__(self):
+        super().__init__()
+        self._structure = _load('structure')['structure']
+        self._relative_pose = OrderedDict()
+        self._add_to_pose(self._structure[0])
+        self._empty_pose = copy.deepcopy(self._relative_pose)
+        self._last_rel_mod = time.time_ns()
+        self._last_abs_mod = None
+        self._last_abs = None
+        self._rel_loc = None
+        self._rel_rot = None
+        self._last_rel = None
+        self._last_rel_get = None
+
+    def _add_to_pose(self, structure):
+        (bone_name, substructures) = list(structure.items())[0]
+        self._relative_pose[bone_name] = None
+        if substructures is not None:
+            for substructure in substructures:
+                self._add_to_pose(substructure)
+
+    def set_relative(self, pose_dict):
+        """p3d_pose.py:223-229 (setter) -> 34-54 pose_to_tensors: a python zip over the 26 transforms with three numpy deg2rad
+        calls each, two torch.tensor constructions, euler_angles_to_matrix."""
+        locations, rotations = zip(*[(
+            (p.location.x, p.location.y, -p.location.z),
+            (np.deg2rad(-p.rotation.roll), np.deg2rad(-p.rotation.pitch), np.deg2rad(-p.rotation.yaw))
+        ) for p in pose_dict.values()])
+        self._rel_loc = torch.tensor(locations, dtype=torch.float32)
+        self._rel_rot = O.euler_angles_to_matrix_xyz(torch.tensor(rotations, dtype=torch.float32))
+        self._last_rel_mod = time.time_ns()
 
 
 class PortPedestrian:
-    """What ``ControlledPedestrian(world=None, age, gender, reference_pose=P3dPose)`` costs: dict of 26 transforms
-    from the (cached) skeleton file, converted to tensors with a python zip + euler_angles_to_matrix."""
-    _raw = None
+    """What ``ControlledPedestrian(world=None, age, gender, device, reference_pose=P3dPose)`` does per clip
+    (walker_control/controlled_pedestrian.py:24-59): _load_reference_pose (:142-147 -> data/carla/utils.py:40-77: one mock Transform
+    with its Location and Rotation per bone from the nested dict of the cached file, a copy of the hips / root for the root
+    transform, the hips moved to the origin), a fresh P3dPose, the relative setter, and the spawn / initial / world transforms."""
 
     def __init__(self, age: str, gender: str):
-        if PortPedestrian._raw is None:
-            PortPedestrian._raw = O.load_skeleton_data()
-        data = PortPedestrian._raw
-        sk = data['skeletons'][f'{age}_{gender}']
-        pose = OrderedDict()
-        for name, loc, rot in zip(data['bones'], sk['location_cm'], sk['rotation_deg']):
-            pose[name] = _Transform([loc[0] / 100.0, loc[1] / 100.0, loc[2] / 100.0], list(rot))
-        root_hips = copy.deepcopy(pose['crl_hips__C'])      # utils.py:64-67 keeps a copy of the original
-        pose['crl_hips__C'].loc = [0.0, 0.0, 0.0]
-        self.root_hips = root_hips
-        locs, angs = zip(*[((p.loc[0], p.loc[1], -p.loc[2]),
-                            (math.radians(-p.rot[2]), math.radians(-p.rot[0]), math.radians(-p.rot[1])))
-                           for p in pose.values()])
-        self.rel_loc = torch.tensor(locs, dtype=torch.float32)
-        self.rel_rot = O.euler_angles_to_matrix_xyz(torch.tensor(angs, dtype=torch.float32))
+        unreal = _load(f'{age}_{gender}')['transforms']
+        pose = {name: _Transform(location=_Location(x=t['location']['x'] / 100.0, y=t['location']['y'] / 100.0, z=t['location']['z'] / 100.0),
+                                 rotation=_Rotation(pitch=t['rotation']['pitch'], yaw=t['rotation']['yaw'], roll=t['rotation']['roll']))
+                for (name, t) in unreal.items()}
+        hl, rr = pose['crl_hips__C'].location, pose['crl_root'].rotation
+        self.root_hips = _Transform(location=_Location(hl.x, hl.y, hl.z), rotation=_Rotation(rr.pitch, rr.yaw, rr.roll))   # deepcopy_location / _rotation
+        pose['crl_hips__C'].location = _Location()
+        self._current_pose = _PortPose()
+        self._current_pose.set_relative(pose)
+        self._spawn_loc = _Location()
+        self._world = None
+        self._walker = None
+        self._initial_transform = _Transform()
+        self._world_transform = _Transform()
+        self._max_spawn_tries = 10
+        self.rel_loc, self.rel_rot = self._current_pose._rel_loc, self._current_pose._rel_rot
 
     @property
-    def tensors(self):
+    def tensors(self):                  # p3d_pose.py:265-277
         return self.rel_loc.detach().clone(), self.rel_rot.detach().clone()
 
 

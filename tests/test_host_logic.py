@@ -282,6 +282,49 @@ def test_bench_refuses_to_report_more_gpus_than_ranks(tmp_path):
     assert r.returncode != 0 and 'n_gpus' not in r.stdout and 'WORLD_SIZE=1' in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])
 
 
+def test_bench_launcher_starts_n_ranks_relays_one_line_and_fails_with_a_rank(tmp_path):
+    """bench.launch_ranks on a stub rank program (no GPU): N children, each with RANK / LOCAL_RANK / WORLD_SIZE and the same
+    MASTER_ADDR / MASTER_PORT; only rank 0's stdout comes through (ONE JSON line); a failing rank makes the launcher return its
+    exit code and stops the ranks that are still running."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = tmp_path / 'rank_stub.py'
+    stub.write_text(
+        'import json, os, sys, time\n'
+        'r = int(os.environ["RANK"])\n'
+        'rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}\n'
+        'rec["argv"] = sys.argv[1:]\n'
+        'open(os.path.join(sys.argv[1], f"rank{r}.json"), "w").write(json.dumps(rec))\n'
+        'if len(sys.argv) > 2 and sys.argv[2] == "fail" and r == 1:\n'
+        '    sys.exit(7)\n'
+        'if len(sys.argv) > 2 and sys.argv[2] == "fail" and r != 1:\n'
+        '    time.sleep(60)          # must be stopped by the launcher, not run out\n'
+        'print(json.dumps({"rank": r, "n_gpus": int(os.environ["WORLD_SIZE"])}), flush=True)\n')
+    driver = ('import sys; sys.path.insert(0, %r); import bench; '
+              'sys.exit(bench.launch_ranks(3, sys.argv[1:], script=%r, have=3))' % (root, str(stub)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    ok = tmp_path / 'ok'
+    ok.mkdir()
+    r = subprocess.run([sys.executable, '-c', driver, str(ok)], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {'rank': 0, 'n_gpus': 3}, r.stdout      # rank 0's line, nobody else's
+    recs = [json.loads((ok / f'rank{i}.json').read_text()) for i in range(3)]
+    assert [x['RANK'] for x in recs] == ['0', '1', '2'] and [x['LOCAL_RANK'] for x in recs] == ['0', '1', '2']
+    assert all(x['WORLD_SIZE'] == '3' and x['MASTER_ADDR'] == '127.0.0.1' and x['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' for x in recs)
+    assert len({x['MASTER_PORT'] for x in recs}) == 1 and recs[0]['MASTER_PORT'].isdigit()
+    assert all(x['argv'] == [str(ok)] for x in recs)
+    bad = tmp_path / 'bad'
+    bad.mkdir()
+    import time
+    t0 = time.time()
+    r = subprocess.run([sys.executable, '-c', driver, str(bad), 'fail'], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7 and time.time() - t0 < 45, (r.returncode, time.time() - t0)       # rank 1's code; the sleepers were stopped
+    assert 'n_gpus' not in r.stdout
+
+
 def test_static_batch_owns_an_int32_skeleton_type_index():
     """Graph mode: the captured launches keep the address of meta['skel_type'], so staging must hand the flow ONE int32 tensor
     on the frames' device whatever the batch carried -- an int64 tensor, age / gender strings, or nothing (adult female,
