@@ -407,11 +407,21 @@ def roofline_entry(name, B, us, nbytes_per_clip, traffic=None):
 
 
 def load_traffic():
+    """profiles/traffic.json (PMC passes, tools/make_traffic.py), minus the entries measured on kernel sources that have changed
+    since (their stamp, tools/traffic_stamp.py, no longer matches the tree): a stale figure is dropped, not printed."""
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(path):
-        with open(path) as f:
-            return json.load(f)
-    return {}
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        stored = json.load(f)
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    try:
+        from traffic_stamp import src_sha16
+    except Exception:                                                   # noqa: BLE001 -- no stamps: nothing can be trusted
+        return {}
+    finally:
+        sys.path.pop(0)
+    return {k: v for k, v in stored.items() if v.get('src_sha16') is not None and v.get('src_sha16') == src_sha16(k)}
 
 
 def _cpu_model():

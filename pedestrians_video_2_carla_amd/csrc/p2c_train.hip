@@ -605,7 +605,7 @@ struct RowBlock {          // one dense block: n-tiles [n0, n0 + NA) x m-tiles [
   int l, n0, na, nb, tile0;
 };
 template <int NA, int NB>
-__device__ __forceinline__ void wgrad_block(const WgradArgs &a, const RowBlock rb, const int first, const int step, const int lane,
+__device__ __forceinline__ void wgrad_block(const WgradArgs &a, const RowBlock rb, const int first, const int step, const int end, const int lane,
                                             f32x4 (&acc)[NA * NB]) {
   const int r = lane & 15, k = lane >> 4;
   int32_t dd[NLAY + 1];
@@ -655,7 +655,7 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs &a, const RowBlock r
   // go out -- with one clip of look-ahead the loop ran at one HBM round trip per clip (B = 8192: 93 us for 35 us of MFMA)
   constexpr int DEPTH = (NA + NB) * 4 * 6 <= 176 ? 6 : 5;
   f32x4 ar[DEPTH][NA], br[DEPTH][NB];
-  const int last = a.n_stiles - 1;
+  const int last = end - 1;                       // (a valid clip even for an empty slice: end >= 1)
   // (every load is unconditional, from a clamped clip: a load inside a branch makes the compiler drain the queue at the join;
   // what a set holds beyond the slice is never multiplied)
 #pragma unroll
@@ -664,18 +664,18 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs &a, const RowBlock r
     load(cl < last ? cl : last, ar[dth], br[dth]);
   }
   int st = first;
-  for (; st + (2 * DEPTH - 1) * step < a.n_stiles; st += DEPTH * step) {      // steady state: no tests inside
+  for (; st + (2 * DEPTH - 1) * step < end; st += DEPTH * step) {      // steady state: no tests inside
 #pragma unroll
     for (int dth = 0; dth < DEPTH; ++dth) {
       fma(ar[dth], br[dth]);
       load(st + (dth + DEPTH) * step, ar[dth], br[dth]);
     }
   }
-  for (; st < a.n_stiles; st += DEPTH * step) {                               // the last one or two rounds
+  for (; st < end; st += DEPTH * step) {                               // the last one or two rounds
 #pragma unroll
     for (int dth = 0; dth < DEPTH; ++dth) {
       const int cur = st + dth * step, nxt = cur + DEPTH * step;
-      if (cur < a.n_stiles) fma(ar[dth], br[dth]);
+      if (cur < end) fma(ar[dth], br[dth]);
       load(nxt < last ? nxt : last, ar[dth], br[dth]);
     }
   }
@@ -690,36 +690,41 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs &a, const RowBlock r
 
 __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_stream_kernel(const WgradArgs a) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int first = blockIdx.x, step = gridDim.x;      // clips b, b + grid, ...: those written on this XCD (grid = 0 mod 8)
+#ifdef P2C_WGRAD_CONTIGUOUS       // (A/B timing: a contiguous slice of clips per workgroup instead of the strided one)
+  const int per = (a.n_stiles + gridDim.x - 1) / gridDim.x;
+  const int first = blockIdx.x * per, step = 1, end = (first + per < a.n_stiles) ? first + per : a.n_stiles;
+#else
+  const int first = blockIdx.x, step = gridDim.x, end = a.n_stiles;      // clips b, b + grid, ...: those written on this XCD (grid = 0 mod 8)
+#endif
   // tile index of (layer l, n-tile n, m-tile 0): layers 0..5 hold 8, 2, 1, 3, 15, 50 tiles
   constexpr int T0 = 0, T1 = 8, T2 = 10, T3 = 11, T4 = 14, T5 = 29;
   if (wave < 5) {
     f32x4 acc[10];
-    wgrad_block<2, 5>(a, RowBlock{5, 2 * wave, 2, 5, T5 + 2 * wave * 5}, first, step, lane, acc);
+    wgrad_block<2, 5>(a, RowBlock{5, 2 * wave, 2, 5, T5 + 2 * wave * 5}, first, step, end, lane, acc);
   } else if (wave == 5) {
     f32x4 acc[9];
-    wgrad_block<3, 3>(a, RowBlock{4, 0, 3, 3, T4}, first, step, lane, acc);
+    wgrad_block<3, 3>(a, RowBlock{4, 0, 3, 3, T4}, first, step, end, lane, acc);
   } else if (wave == 6) {
     {
       f32x4 acc[6];
-      wgrad_block<2, 3>(a, RowBlock{4, 3, 2, 3, T4 + 9}, first, step, lane, acc);
+      wgrad_block<2, 3>(a, RowBlock{4, 3, 2, 3, T4 + 9}, first, step, end, lane, acc);
     }
     {
       f32x4 acc[3];
-      wgrad_block<3, 1>(a, RowBlock{3, 0, 3, 1, T3}, first, step, lane, acc);
+      wgrad_block<3, 1>(a, RowBlock{3, 0, 3, 1, T3}, first, step, end, lane, acc);
     }
   } else {
     {
       f32x4 acc[8];
-      wgrad_block<2, 4>(a, RowBlock{0, 0, 2, 4, T0}, first, step, lane, acc);
+      wgrad_block<2, 4>(a, RowBlock{0, 0, 2, 4, T0}, first, step, end, lane, acc);
     }
     {
       f32x4 acc[2];
-      wgrad_block<1, 2>(a, RowBlock{1, 0, 1, 2, T1}, first, step, lane, acc);
+      wgrad_block<1, 2>(a, RowBlock{1, 0, 1, 2, T1}, first, step, end, lane, acc);
     }
     {
       f32x4 acc[1];
-      wgrad_block<1, 1>(a, RowBlock{2, 0, 1, 1, T2}, first, step, lane, acc);
+      wgrad_block<1, 1>(a, RowBlock{2, 0, 1, 1, T2}, first, step, end, lane, acc);
     }
   }
 }

@@ -37,8 +37,27 @@ def _fused_ok(rnn, x) -> bool:
     """The HIP recurrence covers one nn.LSTM stack (uni- or bidirectional), fp32 on the GPU, hidden size a multiple of 16 up to
     64. Per-layer hidden sizes (an nn.Sequential of LSTMs, which the reference cannot run either: seq2seq.py:38-45 hands the
     first layer's tuple to the second) and CPU parity runs take nn.LSTM."""
-    return (isinstance(rnn, nn.LSTM) and rnn.proj_size == 0 and x.is_cuda
-            and x.dtype == torch.float32 and rnn.hidden_size in (16, 32, 48, 64))
+    ok = (isinstance(rnn, nn.LSTM) and rnn.proj_size == 0 and x.is_cuda
+          and x.dtype == torch.float32 and rnn.hidden_size in (16, 32, 48, 64))
+    if not ok and x.is_cuda and x.dtype == torch.float32 and isinstance(rnn, nn.LSTM):
+        _warn_fallback(rnn)
+    return ok
+
+
+_WARNED = set()
+
+
+def _warn_fallback(rnn):
+    """Once per shape: an fp32 LSTM stack on the GPU that the HIP recurrence does not cover runs through the framework's RNN
+    (MIOpen: about 15x slower per step at cfg3's sizes) -- e.g. the reference's own ``hidden_size: 128`` configs
+    (configs/compare/carla-recorded_autoencoder_tests.yaml:38). Not silent."""
+    key = (rnn.hidden_size, rnn.proj_size)
+    if key in _WARNED:
+        return
+    _WARNED.add(key)
+    warnings.warn(f'Seq2Seq: nn.LSTM(hidden_size={rnn.hidden_size}, proj_size={rnn.proj_size}) is outside the HIP recurrence '
+                  f'(hidden sizes 16 / 32 / 48 / 64, no projection): this stack runs on the framework RNN path, roughly an order of '
+                  f'magnitude slower per step', RuntimeWarning, stacklevel=3)
 
 
 def _run_stack(rnn: nn.LSTM, x: Tensor, hidden: Tensor = None, cell: Tensor = None, input_map=None):

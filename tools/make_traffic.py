@@ -12,6 +12,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_summary import summarise
+from traffic_stamp import src_sha16
 
 GROUPS = {
     # lean training kernels only (the materialising pose_head_rot_fwd<.., true> runs once at set-up, not in the step)
@@ -21,7 +22,7 @@ GROUPS = {
     'mlp_bwd(+reduce)': ('mlp_bwd_kernel', 'mlp_wgrad_kernel', 'mlp_reduce_kernel', 'mlp_reduce_small_kernel'),
     'mlp_bwd(+reduce+adamw)': ('mlp_bwd_kernel', 'mlp_wgrad_kernel', 'mlp_reduce_kernel', 'mlp_reduce_small_kernel'),
     'adamw': ('adamw_kernel',),
-    'train_clip_kernel': ('train_clip_kernel',),
+    'train_clip_kernel': ('train_clip_kernel', 'train_stream_kernel'),      # (the first launch: latency / throughput form by batch)
     # the names bench.py's roofline_sweep uses (head_kernel_names): one kernel each, the forward without its finalize launch
     'pose_head_rot_fwd_tp<6D>': ('pose_head_rot_fwd_tp<0',),
     'pose_head_rot_bwd_tangent_tp<6D>': ('pose_head_rot_bwd_tangent_tp<0',),
@@ -29,7 +30,7 @@ GROUPS = {
     'pose_head_rot_bwd_tangent<6D>': ('pose_head_rot_bwd_tangent<0>',),
     'pose_head_chain_fwd<6D>': ('pose_head_chain_fwd<0>',),
     'pose_head_chain_bwd<6D>': ('pose_head_chain_bwd<0>',),
-    'train_wgrad_kernel(+adamw+loss)': ('train_wgrad_kernel',),
+    'train_wgrad_kernel(+adamw+loss)': ('train_wgrad_kernel', 'wgrad_stream_kernel', 'wgrad_reduce_kernel'),
 }
 
 
@@ -55,7 +56,7 @@ def main():
         wr = group_bytes(summarise(write_dir), 'WRITE_SIZE', 1.0)
         for g in rd:
             traffic[f'{g}@B{B}'] = {'read_bytes': round(rd[g]), 'write_bytes': round(wr.get(g, 0.0)),
-                                   'bytes': round(rd[g] + wr.get(g, 0.0))}
+                                   'bytes': round(rd[g] + wr.get(g, 0.0)), 'src_sha16': src_sha16(g)}
     with open(out_path, 'w') as f:
         json.dump(traffic, f, indent=1, sort_keys=True)
     print(json.dumps(traffic, indent=1, sort_keys=True))
