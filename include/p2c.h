@@ -312,7 +312,8 @@ P2C_API int p2c_fold_bwd(const float *w_ih, const float *W, const float *b, int6
 /* ---- LSTM recurrence (K7b) ---------------------------------------------------------------------------------------------
  * The time loop of one torch.nn.LSTM layer (gate order i, f, g, o; reference seq2seq.py:36-58 Encoder / Decoder):
  *   gates[t] = gx[t] + h[t-1] W_hh^T ;  c[t] = f c[t-1] + i g ;  h[t] = o tanh(c[t])
- * with gx[t] = x[t] W_ih^T + b_ih + b_hh computed by the caller (one dense library GEMM for all t). H in {16,32,48,64},
+ * with gx[t] = x[t] W_ih^T + b_ih + b_hh computed by the caller (one dense library GEMM for all t). H in {16,32,48,64,96,128}
+ * (above 64 the W_hh image is staged through LDS in two chunks),
  * all tensors fp32 row-major, 16-byte aligned. Forward fills out (T,B,H), optional hT/cT (B,H) and the saved activations
  * acts (T,B,4H) / cs (T,B,H). Backward takes g_out / g_hT / g_cT (each optional), acts, cs, c0, w_hh and writes
  * g_gx (T,B,4H) = d gates (from which the caller forms dW_hh = sum_t g_gx[t]^T h[t-1], dW_ih, db with library GEMMs)

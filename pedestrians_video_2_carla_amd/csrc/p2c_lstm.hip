@@ -50,12 +50,20 @@ __device__ __forceinline__ f32x4 load4(const float *p, bool ok) {
 // ---- forward -----------------------------------------------------------------------------------------------------------
 // W_hh (4H x H floats) -> LDS with coalesced 16-byte loads (a strided per-lane gather from global costs ~10 us per
 // launch, which is most of a single-step decoder call); pitch H + 1 keeps the fragment pick-up conflict-free
+// Hidden sizes above 64 (the reference's own `hidden_size: 128` configs): 4H x (H + 1) floats no longer fit LDS (264 KB at 128),
+// so the image is staged in CHUNKS of whole gates -- two chunks of 2H rows -- and a lane picks up the fragments whose rows the
+// chunk in LDS holds (a compile-time test in the 16-sequence kernels, a per-lane one in the 4-sequence kernels).
 template <int H>
-__device__ __forceinline__ void stage_w(const float *w_hh, float *wl) {
-  constexpr int N4 = 4 * H * H / 4;
-  const f32x4 *src = reinterpret_cast<const f32x4 *>(w_hh);
+struct Chunks {
+  static constexpr int N = H > 64 ? 2 : 1, ROWS = 4 * H / N;
+};
+template <int H>
+__device__ __forceinline__ void stage_w(const float *w_hh, float *wl, const int chunk = 0) {
+  constexpr int N4 = Chunks<H>::ROWS * H / 4;
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(w_hh) + (size_t)chunk * N4;
   constexpr int SB = 8;                           // loads in flight per thread: the 64 KB image is two round trips, not 16
   const int nt = blockDim.x;
+  if (chunk > 0) __syncthreads();                 // every fragment of the previous chunk has been picked up
   for (int i0 = threadIdx.x; i0 < N4; i0 += nt * SB) {
     f32x4 v[SB];
 #pragma unroll
@@ -85,12 +93,17 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
   const int B = a.B, T = a.T;
   const int off4 = (b * 4 * H + u0) * 4, off1 = (b * H + u0) * 4;   // byte offsets inside one step's rows
 
-  stage_w<H>(a.w_hh, dyn_lds);
   float frag[4][KS];                              // A fragments: gate q, rows 16w + (lane & 15), k = 4 ks + g
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int ch = 0; ch < Chunks<H>::N; ++ch) {
+    stage_w<H>(a.w_hh, dyn_lds, ch);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) frag[q][ks] = dyn_lds[(q * H + w * 16 + c) * (H + 1) + 4 * ks + g];
+    for (int q = 0; q < 4; ++q)
+      if (q * H / Chunks<H>::ROWS == ch) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) frag[q][ks] = dyn_lds[(q * H - ch * Chunks<H>::ROWS + w * 16 + c) * (H + 1) + 4 * ks + g];
+      }
+  }
 
   f32x4 cst = a.c0 ? load4(a.c0 + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
   {
@@ -185,10 +198,14 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
   const int B = a.B, T = a.T;
   const int off4 = (b * 4 * H + u0) * 4, off1 = (b * H + u0) * 4;
 
-  stage_w<H>(a.w_hh, dyn_lds);
   float frag[KS];                                 // A fragments of W_hh^T: rows = units 16w + (lane & 15), k = gate row 4 ks + g
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) frag[ks] = dyn_lds[(4 * ks + g) * (H + 1) + w * 16 + c];
+  for (int ch = 0; ch < Chunks<H>::N; ++ch) {
+    stage_w<H>(a.w_hh, dyn_lds, ch);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      if (4 * ks / Chunks<H>::ROWS == ch) frag[ks] = dyn_lds[(4 * ks + g - ch * Chunks<H>::ROWS) * (H + 1) + w * 16 + c];
+  }
   __syncthreads();                                // the staging image is dead: its space becomes the d-gates buffers
 
   f32x4 dh = a.g_hT ? load4(a.g_hT + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -285,10 +302,16 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_narrow_kernel(cons
   const int B = a.B, T = a.T;
   const int offg = (b * 4 * H + u) * 4, offh = (b * H + u) * 4;   // byte offsets inside one step's rows
 
-  stage_w<H>(a.w_hh, dyn_lds);
   float frag[H];                                  // A operand: row (lane & 3) = gate, of this lane's block = unit; k = 0..H-1
 #pragma unroll
-  for (int k = 0; k < H; ++k) frag[k] = dyn_lds[(s * H + u) * (H + 1) + k];
+  for (int ch = 0; ch < Chunks<H>::N; ++ch) {
+    stage_w<H>(a.w_hh, dyn_lds, ch);
+    const int row = s * H + u - ch * Chunks<H>::ROWS;          // this lane's gate row inside the chunk, if it is there
+    if (row >= 0 && row < Chunks<H>::ROWS) {
+#pragma unroll
+      for (int k = 0; k < H; ++k) frag[k] = dyn_lds[row * (H + 1) + k];
+    }
+  }
 
   float cst = (a.c0 && ok) ? a.c0[(size_t)b * H + u] : 0.f;
   hs[0][s][u] = (a.h0 && ok) ? a.h0[(size_t)b * H + u] : 0.f;
@@ -366,10 +389,16 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(cons
   const int B = a.B, T = a.T;
   const int offg = (b * 4 * H + u) * 4, offh = (b * H + u) * 4;
 
-  stage_w<H>(a.w_hh, dyn_lds);
   float frag[H];                                  // A operand: row (lane & 3) -> unit 16w + 4ug + (lane & 3); k -> gate row q H + k
 #pragma unroll
-  for (int k = 0; k < H; ++k) frag[k] = dyn_lds[(q * H + k) * (H + 1) + w * 16 + 4 * ug + s];
+  for (int ch = 0; ch < Chunks<H>::N; ++ch) {
+    stage_w<H>(a.w_hh, dyn_lds, ch);
+    const int row0 = q * H - ch * Chunks<H>::ROWS;             // the lane's quarter of the gate rows inside the chunk, if it is there
+    if (row0 >= 0 && row0 < Chunks<H>::ROWS) {
+#pragma unroll
+      for (int k = 0; k < H; ++k) frag[k] = dyn_lds[(row0 + k) * (H + 1) + w * 16 + 4 * ug + s];
+    }
+  }
 
   float dh = (a.g_hT && ok) ? a.g_hT[(size_t)b * H + u] : 0.f;
   float dc = (a.g_cT && ok) ? a.g_cT[(size_t)b * H + u] : 0.f;
@@ -443,7 +472,7 @@ using namespace p2c_lstm;
 static int check(const p2c_lstm_desc *d, Args &a) {
   if (!d || !d->w_hh) return P2C_E_NULL;
   if (d->T < 0 || d->B < 0 || d->B > (1 << 20)) return P2C_E_SHAPE;   // buffer offsets: (B + 16) * 4H * 4 bytes < 2^31
-  if (d->H != 16 && d->H != 32 && d->H != 48 && d->H != 64) return P2C_E_SHAPE;
+  if (d->H != 16 && d->H != 32 && d->H != 48 && d->H != 64 && d->H != 96 && d->H != 128) return P2C_E_SHAPE;
   a = Args{};
   a.gx = d->gx, a.h0 = d->h0, a.c0 = d->c0, a.w_hh = d->w_hh, a.out = d->out, a.hT = d->hT, a.cT = d->cT;
   a.acts = d->acts, a.cs = d->cs, a.g_out = d->g_out, a.g_hT = d->g_hT, a.g_cT = d->g_cT, a.g_gx = d->g_gx;
@@ -454,17 +483,21 @@ static int check(const p2c_lstm_desc *d, Args &a) {
 }
 
 static size_t lds_bytes(int H, bool bwd) {
-  size_t image = (size_t)4 * H * (H + 1), dgates = (size_t)2 * 4 * H * TP;
+  size_t image = (size_t)(H > 64 ? 2 : 4) * H * (H + 1), dgates = (size_t)2 * 4 * H * TP;     // (one chunk of the staging image)
   return sizeof(float) * ((bwd && dgates > image) ? dgates : image);
 }
 template <int H>
 static void allow_lds() {
   static bool done = false;
   if (done) return;
-  (void)hipFuncSetAttribute((const void *)lstm_rec_fwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  (void)hipFuncSetAttribute((const void *)lstm_rec_bwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  (void)hipFuncSetAttribute((const void *)lstm_rec_fwd_narrow_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  (void)hipFuncSetAttribute((const void *)lstm_rec_bwd_narrow_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  // exactly what each kernel asks for: static + dynamic LDS must stay within 160 KB or the attribute call fails (and leaves its
+  // error behind for the next hipGetLastError)
+  const int f = (int)lds_bytes(H, false), bw = (int)lds_bytes(H, true);
+  (void)hipFuncSetAttribute((const void *)lstm_rec_fwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, f);
+  (void)hipFuncSetAttribute((const void *)lstm_rec_bwd_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, bw);
+  (void)hipFuncSetAttribute((const void *)lstm_rec_fwd_narrow_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, f);
+  (void)hipFuncSetAttribute((const void *)lstm_rec_bwd_narrow_kernel<H>, hipFuncAttributeMaxDynamicSharedMemorySize, f);
+  (void)hipGetLastError();
   done = true;
 }
 #define P2C_LSTM_DISPATCH(KERNEL, BWD)                                                                                     \
@@ -472,6 +505,8 @@ static void allow_lds() {
     case 16: allow_lds<16>(); hipLaunchKernelGGL(KERNEL<16>, grid, dim3(64), lds_bytes(16, BWD), (hipStream_t)stream, a); break;   \
     case 32: allow_lds<32>(); hipLaunchKernelGGL(KERNEL<32>, grid, dim3(128), lds_bytes(32, BWD), (hipStream_t)stream, a); break;  \
     case 48: allow_lds<48>(); hipLaunchKernelGGL(KERNEL<48>, grid, dim3(192), lds_bytes(48, BWD), (hipStream_t)stream, a); break;  \
+    case 96: allow_lds<96>(); hipLaunchKernelGGL(KERNEL<96>, grid, dim3(384), lds_bytes(96, BWD), (hipStream_t)stream, a); break;  \
+    case 128: allow_lds<128>(); hipLaunchKernelGGL(KERNEL<128>, grid, dim3(512), lds_bytes(128, BWD), (hipStream_t)stream, a); break;  \
     default: allow_lds<64>(); hipLaunchKernelGGL(KERNEL<64>, grid, dim3(256), lds_bytes(64, BWD), (hipStream_t)stream, a);         \
   }
 

@@ -34,11 +34,11 @@ def _stack(in_size, hid_dim, n_layers, dropout, bidirectional):
 
 
 def _fused_ok(rnn, x) -> bool:
-    """The HIP recurrence covers one nn.LSTM stack (uni- or bidirectional), fp32 on the GPU, hidden size a multiple of 16 up to
-    64. Per-layer hidden sizes (an nn.Sequential of LSTMs, which the reference cannot run either: seq2seq.py:38-45 hands the
+    """The HIP recurrence covers one nn.LSTM stack (uni- or bidirectional), fp32 on the GPU, hidden size 16 / 32 / 48 / 64 / 96 / 128
+    (128: the reference's configs/compare/carla-recorded_autoencoder_tests.yaml:38). Per-layer hidden sizes (an nn.Sequential of LSTMs, which the reference cannot run either: seq2seq.py:38-45 hands the
     first layer's tuple to the second) and CPU parity runs take nn.LSTM."""
     ok = (isinstance(rnn, nn.LSTM) and rnn.proj_size == 0 and x.is_cuda
-          and x.dtype == torch.float32 and rnn.hidden_size in (16, 32, 48, 64))
+          and x.dtype == torch.float32 and rnn.hidden_size in (16, 32, 48, 64, 96, 128))
     if not ok and x.is_cuda and x.dtype == torch.float32 and isinstance(rnn, nn.LSTM):
         _warn_fallback(rnn)
     return ok
@@ -56,7 +56,7 @@ def _warn_fallback(rnn):
         return
     _WARNED.add(key)
     warnings.warn(f'Seq2Seq: nn.LSTM(hidden_size={rnn.hidden_size}, proj_size={rnn.proj_size}) is outside the HIP recurrence '
-                  f'(hidden sizes 16 / 32 / 48 / 64, no projection): this stack runs on the framework RNN path, roughly an order of '
+                  f'(hidden sizes 16 / 32 / 48 / 64 / 96 / 128, no projection): this stack runs on the framework RNN path, roughly an order of '
                   f'magnitude slower per step', RuntimeWarning, stacklevel=3)
 
 

@@ -950,7 +950,7 @@ def joint_embeddings(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tens
 # LSTM layer: library GEMM for the input projection + one HIP launch for the recurrence (K7b)
 # ----------------------------------------------------------------------------------------------------------------------
 def lstm_supported(hidden_size: int) -> bool:
-    return hidden_size in (16, 32, 48, 64)
+    return hidden_size in (16, 32, 48, 64, 96, 128)
 
 
 class LSTMRecurrenceFunction(torch.autograd.Function):

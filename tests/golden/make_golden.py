@@ -577,6 +577,29 @@ def golden_models_extra():
         npz('model_' + name, frames=frames, n_params=sum(p.numel() for p in model.parameters()), **outs, **sd)
 
 
+def golden_seq2seq_h128():
+    """model_seq2seq_embeddings_h128_pose_changes.npz: the reference's Seq2SeqEmbeddings at the hidden size its own configs use
+    (configs/compare/carla-recorded_autoencoder_tests.yaml:38: hidden_size 128) with the pose_changes output (156 features per frame,
+    seq2seq.py:245-288), eval mode, fixed state_dict. single_joint_embeddings_size=8 keeps the fixture at ~1.5 MB (the encoder's first
+    input projection is 512 x (26 x 8) instead of 512 x 1664)."""
+    if not os.path.isdir(REF_SRC):
+        sys.exit('reference tree not present: the committed .npz files are the artefact to use')
+    install_standins()
+    sys.path.insert(0, REF_SRC)
+    from pedestrians_video_2_carla.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla.modules.movements.seq2seq.seq2seq_embeddings import Seq2SeqEmbeddings
+    g = torch.Generator().manual_seed(7)
+    frames = torch.randn(3, 16, 26, 2, generator=g)
+    torch.manual_seed(22742)
+    model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_changes,
+                              hidden_size=128, single_joint_embeddings_size=8).eval()
+    with torch.no_grad():
+        out = model(frames)
+    sd = {('sd__' + k): v for k, v in model.state_dict().items()}
+    npz('model_seq2seq_embeddings_h128_pose_changes', frames=frames, out=out, n_params=sum(p.numel() for p in model.parameters()), **sd)
+
+
 class StandInPoseTransformer(torch.nn.Module):
     """Stand-in for the THIRD-PARTY transformer ``third_party/PoseFormer common/model_poseformer.PoseTransformer`` (empty
     git submodule in the reference checkout, like pytorch3d a package the image lacks): same constructor keywords, same
@@ -747,6 +770,8 @@ if __name__ == '__main__':
         golden_metrics_extra()
     elif sys.argv[1:] == ['models_extra']:
         golden_models_extra()
+    elif sys.argv[1:] == ['seq2seq_h128']:
+        golden_seq2seq_h128()
     elif sys.argv[1:] == ['losses_extra']:
         golden_losses_extra()
     elif sys.argv[1:] == ['collate']:

@@ -245,6 +245,17 @@ def test_linear_ae_residual_drops_in(golden, name, kw):
     assert isinstance(model.configure_optimizers()['optimizer'], torch.optim.Adam)
 
 
+def test_seq2seq_embeddings_at_the_reference_configs_hidden_size(golden):
+    """hidden_size 128 + pose_changes (reference configs/compare/carla-recorded_autoencoder_tests.yaml:38, seq2seq.py:245-288): the
+    reference's own state_dict loads and its own output comes back (CPU: the nn.LSTM path; the device side of the same fixture is
+    tests/test_lstm_gpu.py::test_reference_run_of_the_hidden_128_model_on_the_hip_recurrence)."""
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2SeqEmbeddings
+    g, model = _load(golden, 'model_seq2seq_embeddings_h128_pose_changes', Seq2SeqEmbeddings, movements_output_type=MT.pose_changes,
+                     hidden_size=128, single_joint_embeddings_size=8)
+    assert torch.allclose(model(g['frames']), g['out'], atol=1e-5)
+
+
 @pytest.mark.parametrize('name', ['a', 'b', 'c'])
 def test_seq2seq_residual_variants_drop_in(golden, name):
     from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON

@@ -27,7 +27,8 @@ def close(a, b, what, rtol=RTOL):
     assert err <= rtol * scale + 1e-30, f'{what}: {err:.3e} vs scale {scale:.3e}'
 
 
-@pytest.mark.parametrize('T,B,I,H', [(1, 1, 5, 16), (16, 6, 52, 64), (7, 33, 20, 32), (16, 130, 64, 64), (3, 17, 9, 48)])
+@pytest.mark.parametrize('T,B,I,H', [(1, 1, 5, 16), (16, 6, 52, 64), (7, 33, 20, 32), (16, 130, 64, 64), (3, 17, 9, 48),
+                                     (16, 37, 52, 128), (5, 130, 156, 128), (9, 21, 20, 96)])      # 128: the reference's own hidden_size (configs/compare/carla-recorded_autoencoder_tests.yaml:38)
 @pytest.mark.parametrize('with_state', [False, True])
 def test_layer_matches_torch_lstm(T, B, I, H, with_state):
     from pedestrians_video_2_carla_amd import ops
@@ -80,6 +81,70 @@ def test_seq2seq_model_uses_the_fused_stack_and_matches_cpu():
     close(y, yr, 'model output', rtol=bound(y32, yr))
     for (n, pg), (_, pc), (_, p32) in zip(gpu.named_parameters(), cpu.named_parameters(), cpu32.named_parameters()):
         close(pg.grad, pc.grad, 'grad ' + n, rtol=bound(p32.grad, pc.grad))
+
+
+@pytest.mark.parametrize('hidden,otype,O', [(128, 'pose_2d', 2), (128, 'pose_changes', 6), (96, 'pose_2d', 2)])
+def test_seq2seq_shapes_of_the_reference_configs_stay_on_the_hip_recurrence(hidden, otype, O, monkeypatch):
+    """hidden_size 128 (reference configs/compare/carla-recorded_autoencoder_tests.yaml:38,45,48) and the pose_changes output
+    (156 features per frame, reference seq2seq.py:245-288: the decoder loop takes the per-step path through K7b): whole
+    Seq2SeqEmbeddings model against the same module in fp64 on the CPU; nn.LSTM.forward must not be entered on the GPU side and no
+    fall-back warning may be raised."""
+    import copy
+    import warnings
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2SeqEmbeddings
+    d = dev()
+    torch.manual_seed(5)
+    model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT[otype], p_dropout=0.0,
+                              hidden_size=hidden).train()
+    cpu = copy.deepcopy(model).double()
+    cpu32 = copy.deepcopy(model)
+    x = torch.randn(5, 16, 26, 2)
+    yr = cpu(x.double())
+    up = torch.randn(*yr.shape)
+    (yr * up.double()).sum().backward()
+    y32 = cpu32(x)
+    (y32 * up).sum().backward()
+    gpu = model.to(d)
+
+    def refuse(*a, **k):
+        raise AssertionError('nn.LSTM.forward entered: the stack left the HIP path')
+    monkeypatch.setattr(torch.nn.LSTM, 'forward', refuse)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error', RuntimeWarning)
+        y = gpu(x.to(d))
+        (y * up.to(d)).sum().backward()
+    monkeypatch.undo()
+
+    def bound(a32, a64):
+        return max(1e-4, 2.0 * (a32.double() - a64).abs().max().item() / (a64.abs().max().item() + 1e-30))
+    close(y, yr, 'model output', rtol=bound(y32, yr))
+    for (n, pg), (_, pc), (_, p32) in zip(gpu.named_parameters(), cpu.named_parameters(), cpu32.named_parameters()):
+        assert pg.grad is not None, n
+        close(pg.grad, pc.grad, 'grad ' + n, rtol=bound(p32.grad, pc.grad))
+
+
+def test_reference_run_of_the_hidden_128_model_on_the_hip_recurrence(golden, monkeypatch):
+    """tests/golden/model_seq2seq_embeddings_h128_pose_changes.npz = the REFERENCE's Seq2SeqEmbeddings(hidden_size=128, pose_changes) run by
+    tests/golden/make_golden.py: its state_dict on the device, its frames in, its output back within 1e-4 -- through the HIP recurrence
+    (nn.LSTM.forward refused)."""
+    from pedestrians_video_2_carla_amd.data.carla.skeleton import CARLA_SKELETON
+    from pedestrians_video_2_carla_amd.modules.flow.output_types import MovementsModelOutputType as MT
+    from pedestrians_video_2_carla_amd.modules.movements.seq2seq import Seq2SeqEmbeddings
+    g = golden('model_seq2seq_embeddings_h128_pose_changes')
+    model = Seq2SeqEmbeddings(input_nodes=CARLA_SKELETON, output_nodes=CARLA_SKELETON, movements_output_type=MT.pose_changes,
+                              hidden_size=128, single_joint_embeddings_size=8).eval()
+    model.load_state_dict({k[4:]: v for k, v in g.items() if k.startswith('sd__')})
+    model = model.to(dev())
+
+    def refuse(*a, **k):
+        raise AssertionError('nn.LSTM.forward entered: the stack left the HIP path')
+    monkeypatch.setattr(torch.nn.LSTM, 'forward', refuse)
+    with torch.no_grad():
+        out = model(g['frames'].to(dev()))
+    monkeypatch.undo()
+    close(out, g['out'].double(), 'reference output', rtol=1e-4)
 
 
 @pytest.mark.parametrize('embeddings', [False, True])
@@ -258,7 +323,8 @@ def test_decoder_stack_from_the_encoder_state(T, B, O, with_drop, sinks):
         close(p_.grad, want, 'grad ' + name, rtol=2e-4)
 
 
-@pytest.mark.parametrize('T,B,I,H,sinks', [(1, 3, 5, 16, False), (16, 37, 52, 64, True), (9, 130, 20, 32, False), (16, 64, 52, 64, False)])
+@pytest.mark.parametrize('T,B,I,H,sinks', [(1, 3, 5, 16, False), (16, 37, 52, 64, True), (9, 130, 20, 32, False), (16, 64, 52, 64, False),
+                                           (16, 37, 52, 128, True), (7, 19, 20, 96, False)])
 def test_encoder_stack_matches_torch_lstm(T, B, I, H, sinks):
     """The 2-layer encoder as one explicit launch sequence (batch-first input, biases added in the recurrence, final states
     written into the stacked tensors, one grouped weight-gradient launch) against torch.nn.LSTM(num_layers=2) in fp64: final
