@@ -104,6 +104,27 @@ def test_fused_step_matches_cpu_pipeline(monkeypatch, first_launch_form, B, T, m
         close(p.grad, q.grad, n, rtol=max(1e-4, 2 * ref_err))
 
 
+@pytest.mark.parametrize('B', [1024, 8192])
+def test_throughput_forms_match_the_separate_kernels_at_full_size(monkeypatch, B):
+    """B = 1 024 (cfg2 / cfg4 per GPU) and 8 192, 10 % missing joints, default thresholds (train_stream_kernel; at 8 192 also the
+    streamed weight gradient): loss and the whole flat gradient of one step against the separate kernels (mlp_fwd / pose head /
+    mlp_bwd: P2C_FUSED_TRAIN=0), 1e-4 of the gradient's scale; the loss itself to 1e-6."""
+    grads = {}
+    monkeypatch.setenv('P2C_FUSED_UPDATE', '0')
+    for fused in ('0', '1'):
+        monkeypatch.setenv('P2C_FUSED_TRAIN', fused)
+        flow, dm = make(B=B, missing=0.1)
+        trainer = _trainer(flow, dm)
+        trainer.optimizers[0].zero_grad_in_step = False
+        batch = dm.generate_batch(dev())
+        loss = trainer._forward_backward(flow, batch, 0)
+        torch.cuda.synchronize()
+        assert _took_fused_path(flow) == (fused == '1')
+        grads[fused] = (loss.clone(), trainer.flat.flat_grad.clone())
+    close(grads['1'][0], grads['0'][0], 'loss', rtol=1e-6)
+    close(grads['1'][1], grads['0'][1], 'flat gradient', rtol=1e-4)
+
+
 def test_fused_step_with_world_motion_and_body25_targets_matches_separate_kernels(monkeypatch):
     """Non-identity trajectory (dloc / drot) and an eval slice: fused step vs the separate kernels (tolerance: the two paths
     run different weight-gradient orders at this batch size)."""
