@@ -43,7 +43,7 @@ using ph::M3;
 using ph::V3;
 
 constexpr int SW = 8;                       // wavefronts per workgroup: two per SIMD
-constexpr int PAIRS = 4;                    // ... in four pairs (w, w + 4): a pair shares a SIMD, an LDS region and a clip
+constexpr int PAIRS = 4;                    // ... in four pairs (2p, 2p + 1): a pair shares an LDS region and a clip
 constexpr int PT = 16;                      // LDS pitch of an activation row (floats) = frames of a clip
 constexpr int ROWS_Y = 160;                 // y^T / grad_y^T (156 rows + k padding); H_0 before the first layer
 constexpr int ROWS_A = 80, ROWS_B = 48;     // ping-pong buffers: A holds H_1, H_3, H_5 / G_5, G_3, G_1; B holds H_2, H_4 / G_4, G_2
@@ -104,6 +104,21 @@ __device__ __forceinline__ int fresh(int v) {
 // vector load, and the wait the compiler puts in front of its use drains every older store)
 __device__ __forceinline__ int chain_start(int q) { return q < 5 ? 4 * q : (q == 5 ? 21 : (q == 6 ? 20 : 25)); }
 __device__ __forceinline__ int chain_len(int q) { return q < 6 ? 4 : 1; }
+
+// Rendezvous of the TWO wavefronts of a pair (no workgroup barrier inside the clip loop: the four pairs of a workgroup run free of
+// each other). Each wave owns a counter in LDS: it publishes its own arrival number behind its LDS traffic and waits until its
+// partner's counter has reached the same number. Both waves of a pair are resident in the same workgroup: the wait is bounded.
+struct PairSync {
+  int *mine, *other;
+  int epoch;
+  __device__ __forceinline__ void sync() {
+    ++epoch;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __hip_atomic_store(mine, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (__hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  }
+};
 
 struct WLane {
   int lane, c, g;        // c = lane & 15: frame (MFMA column), g = lane >> 4
@@ -405,13 +420,14 @@ __device__ __forceinline__ void pose_inputs_landed(PoseIn &pi) {
 // 8 half + segment: ONE frame per eight-lane unit. Per-frame work is chain::fk_local / fk_base / head4 / subtree4 unchanged (their
 // cross-lane moves stay inside the eight lanes of a unit). The couplings between frames are scans over the segments (ds_bpermute:
 // lane -/+ 8, 16, 32) plus one hand-over between the two wavefronts through LDS: the first half's product of changes to the
-// second, the second half's torque sums to the first. The barriers are the WORKGROUP's (every pair passes them together).
+// second, the second half's torque sums to the first. The rendezvous are the pair's own (PairSync).
 constexpr int XCH_ROT = 0, XCH_TAU = 8 * ch::NS * 9, XCH_LOSS = XCH_TAU + 8 * ch::NS * 3, XCH_FLOATS = XCH_LOSS + 4;
 static_assert(XCH_FLOATS <= ROWS_A * PT, "the hand-over scratch lives in buffer A (idle during the pose head)");
 
 template <int KIND>
 __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bool active, const int clip, const int lane_, const int half,
-                                           const PoseIn &pin, float *Y, float *xch, const float *tab, const float coef2, const float coef3) {
+                                           const PoseIn &pin, float *Y, float *xch, const float *tab, const float coef2, const float coef3,
+                                           PairSync &ps) {
   using K = ph::KindTraits<KIND>;
   constexpr int NS = ch::NS;
   const int T = d.T;
@@ -496,7 +512,7 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
     }
   }
   ST(22);
-  lds_barrier();                                   // ---- hand-over 1: the first half's product is in LDS ----
+  ps.sync();                                       // ---- hand-over 1: the first half's product is in LDS ----
   ch::Acc acc{0.f, 0.f, 0.f};
   V3 taup[NS], later[NS], gb1[NS], gb2[NS], gb3[NS];   // rows of the change: what the pull-back needs of it
   M3 R[NS];                                        // rel_rot of the frame
@@ -587,7 +603,7 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
     }
   }
   ST(27);
-  lds_barrier();                                   // ---- hand-over 2: the second half's torque sums (and loss sums) are in LDS ----
+  ps.sync();                                       // ---- hand-over 2: the second half's torque sums (and loss sums) are in LDS ----
   if (active) {
     if (half == 0 && lane == 0) {
       float *pp = d.partials + (size_t)clip * 4;
@@ -648,7 +664,7 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
     if (half == 0 && lane < (ksteps_bwd(NLAY - 1) * 4 - S::dims(NLAY)) * PT) Y[S::dims(NLAY) * PT + lane] = 0.f;
   }
   ST(28);
-  lds_barrier();                                   // ---- grad_y^T is complete ----
+  ps.sync();                                       // ---- grad_y^T is complete ----
 }
 
 template <int KIND>
@@ -658,7 +674,11 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
   WLane L;
   L.lane = lane0, L.c = L.lane & 15, L.g = L.lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int pair = wave & (PAIRS - 1), half = wave >> 2;      // waves w and w + 4 share a SIMD and a clip
+  // Waves 2p and 2p + 1 share a clip and sit on DIFFERENT SIMDs (a workgroup's waves go to the SIMDs cyclically, w and w + 4 to the
+  // same one): the tile split of the MLP layers runs on two matrix pipes, and every SIMD hosts one wave of pair p and one of pair
+  // p + 2. The pairs run FREE of each other (PairSync, no workgroup barrier in the loop): 250 -> 221 us at B = 8192 against the
+  // lockstep version (every rendezvous then waited for the slowest of eight waves).
+  const int pair = wave >> 1, half = wave & 1;
   float *img = lds;
   float *tab = lds + S::w_total();
   float *scratch = tab + TAB_FLOATS;
@@ -667,9 +687,9 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
   const int T = d.T;
   const int64_t stride = (int64_t)gridDim.x * PAIRS;
   // pair p of workgroup b walks clips b + gridDim (p + 4 i): clip mod 8 = workgroup mod 8 when the grid is a multiple of 8 (the
-  // XCD whose L2 the factors stay in). Every wavefront runs the trip count of pair 0: the barriers are the workgroup's.
+  // XCD whose L2 the factors stay in).
   int64_t clip = (int64_t)blockIdx.x + (int64_t)gridDim.x * pair;
-  const int n_iter = (int)(((int64_t)d.B - blockIdx.x + stride - 1) / stride);
+  const int n_iter = clip < d.B ? (int)(((int64_t)d.B - clip + stride - 1) / stride) : 0;   // this pair's own clips
   // ---- prologue: first x tile, weight image by LDS-DMA (one burst), tables, pair counts -----------------------------------------
   // The x tiles are the SECOND wavefront's job: its vector-memory queue holds loads only, so a wait for a tile never has to
   // drain factor stores (vmcnt retires in issue order, and the compiler's waits in front of loaded values are vmcnt(0)).
@@ -688,6 +708,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
   }
   for (int i = threadIdx.x; i < TAB_FLOATS; i += 64 * SW) tab[i] = i < TAB_ROT ? d.ref_rel_loc[i] : d.ref_rel_rot[i - TAB_ROT];
   if (blockIdx.x == 0 && (int)threadIdx.x < m.n_counters) m.counters[threadIdx.x] = 0;   // arrival tickets of train_wgrad_kernel
+  if (threadIdx.x < SW) reinterpret_cast<int *>(scratch + 8)[threadIdx.x] = 0;            // the waves' rendezvous counters
   {
     float cnt = 0.f;                               // small integers held in floats: exact in any order
     for (int i0 = 0; i0 < d.B; i0 += 8 * 64 * SW) {   // eight loads in flight per thread (a dependent add per load is a round trip each)
@@ -714,9 +735,16 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
   }
 
   ST(1);
+  PairSync ps;
+  ps.mine = reinterpret_cast<int *>(scratch + 8) + wave, ps.other = reinterpret_cast<int *>(scratch + 8) + (wave ^ 1), ps.epoch = 0;
+#ifndef P2C_STREAM_STAGGER
+#define P2C_STREAM_STAGGER 0        // x 8 k cycles of head start for pairs 0, 1 (A/B timing: 0 / 3 / 6 / 12 -> 221 / 227 / 234 / 246 us at
+#endif                              // B = 8192: the steady state does not care how the pairs of a SIMD are phased; the delay is just lost)
+  if (P2C_STREAM_STAGGER > 0 && pair >= 2 && n_iter >= 2)
+    for (int i = 0; i < P2C_STREAM_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
   for (int it = 0; it < n_iter; ++it, clip += stride) {
     ST(2);
-    const bool active = clip < d.B;
+    const bool active = true;
     float *fdst = m.factors + (size_t)((active && !(P2C_STREAM_EXPERIMENT & 8)) ? clip : blockIdx.x * PAIRS + pair) * F_ROWS * 16;
     uint64_t mask = 0;
     PoseIn pin;
@@ -736,7 +764,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         pose_inputs_landed(pin);                   // (in front of the first factor store: the wait covers loads only)
         half_store(h0, fdst + f_h_off(0) * 16, L.lane, half);
       }
-      lds_barrier();
+      ps.sync();     
       ST(4);
       HalfRows<S::dims(1)> h1;
       if (mlp) {
@@ -744,7 +772,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         fwd_layer<1>(L, half, img, A, Bb, mask);
         half_store(h1, fdst + f_h_off(1) * 16, L.lane, half);
       }
-      lds_barrier();
+      ps.sync();     
       ST(5);
       HalfRows<S::dims(2)> h2;
       if (mlp) {
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         fwd_layer<2>(L, half, img, Bb, A, mask);
         half_store(h2, fdst + f_h_off(2) * 16, L.lane, half);
       }
-      lds_barrier();
+      ps.sync();     
       ST(6);
       HalfRows<S::dims(3)> h3;
       if (mlp) {
@@ -760,7 +788,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         fwd_layer<3>(L, half, img, A, Bb, mask);
         half_store(h3, fdst + f_h_off(3) * 16, L.lane, half);
       }
-      lds_barrier();
+      ps.sync();     
       ST(7);
       HalfRows<S::dims(4)> h4;
       if (mlp) {
@@ -768,7 +796,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         fwd_layer<4>(L, half, img, Bb, A, mask);
         half_store(h4, fdst + f_h_off(4) * 16, L.lane, half);
       }
-      lds_barrier();
+      ps.sync();     
       ST(8);
       HalfRows<S::dims(5)> h5;
       if (mlp) {
@@ -778,9 +806,9 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       }
       ST(9);
     }
-    lds_barrier();                                 // ---- y^T is complete (and buffer A is free: the pose head's hand-over scratch) ----
+    ps.sync();                                      // ---- y^T is complete (and buffer A is free: the pose head's hand-over scratch) ----
     // ---- pose head forward + backward by both wavefronts of the pair: y^T -> grad_y^T in place --------------------------------------
-    pose_phase<KIND>(d, active && !(P2C_STREAM_EXPERIMENT & 1), (int)clip, lane0, half, pin, Y, A, tab, coef2, coef3);
+    pose_phase<KIND>(d, active && !(P2C_STREAM_EXPERIMENT & 1), (int)clip, lane0, half, pin, Y, A, tab, coef2, coef3, ps);
     ST(32);
     {
       WLane L;
@@ -793,7 +821,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         dgrad_layer<5>(L, half, img, Y, A, mask);
         half_store(g6, fdst + f_g_off(6) * 16, L.lane, half);
       }
-      lds_barrier();                               // ---- grad_y^T has been read: the y rows are free for the next clip's H_0 ----
+      ps.sync();                                    // ---- grad_y^T has been read: the y rows are free for the next clip's H_0 ----
       ST(33);
       HalfRows<S::dims(5)> g5;
       if (mlp) {
@@ -802,7 +830,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         half_store(g5, fdst + f_g_off(5) * 16, L.lane, half);
       }
       if (half != 0 && clip + stride < d.B) x_commit(xr, x_offsets(L.lane), Y, L.lane);   // (its share of this layer is the small one)
-      lds_barrier();
+      ps.sync();     
       ST(34);
       HalfRows<S::dims(4)> g4;
       if (mlp) {
@@ -810,7 +838,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         dgrad_layer<3>(L, half, img, Bb, A, mask);
         half_store(g4, fdst + f_g_off(4) * 16, L.lane, half);
       }
-      lds_barrier();
+      ps.sync();     
       ST(35);
       HalfRows<S::dims(3)> g3;
       if (mlp) {
@@ -818,7 +846,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         dgrad_layer<2>(L, half, img, A, Bb, mask);
         half_store(g3, fdst + f_g_off(3) * 16, L.lane, half);
       }
-      lds_barrier();
+      ps.sync();     
       ST(36);
       HalfRows<S::dims(2)> g2;
       if (mlp) {
@@ -826,7 +854,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
         dgrad_layer<1>(L, half, img, Bb, A, mask);
         half_store(g2, fdst + f_g_off(2) * 16, L.lane, half);
       }
-      lds_barrier();
+      ps.sync();     
       HalfRows<S::dims(1)> g1;
       if (mlp) {
         half_read(A, L.lane, half, g1);
@@ -834,7 +862,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       }
       ST(37);
     }
-    lds_barrier();                                 // ---- the next clip's H_0 is in place, buffer A has been read ----
+    ps.sync();                                      // ---- the next clip's H_0 is in place, buffer A has been read ----
     ST(63);
   }
 }
