@@ -382,6 +382,10 @@ def step_sweep(device, sizes=(256, 1024, 8192, 65536)):
         fused = fused_step_times(device, flow, trainer, batch)
         if fused is not None:
             entry['launch_us'] = {k: round(v, 2) for k, v in fused[0].items()}
+            traffic = load_traffic()
+            entry['traffic'] = {k: (traffic.get(f'{k}@B{Bs}') or {}).get('bytes')      # HBM bytes per launch (PMC passes, profiles/traffic.json)
+                                for k in ('train_clip_kernel', 'train_wgrad_kernel(+adamw+loss)')}
+            entry['algorithmic_bytes'] = STEP_BYTES_PER_CLIP * Bs
             entry['forms'] = {'first_launch': 'train_stream_kernel (a pair of wavefronts per clip)' if Bs >= stream_min
                               else 'train_clip_kernel (a workgroup per clip)',
                               'second_launch': 'wgrad_stream_kernel + wgrad_reduce_kernel' if Bs >= wgrad_min
@@ -623,7 +627,10 @@ def extra_config(device, name, steps=100, warmup=10):
                     la = t.train_step(f, batch, i)
                 torch.cuda.synchronize(device)
                 ms = (time.perf_counter() - t0) / steps * 1e3
-                return {'ms_per_step': round(ms, 3), 'clips_per_s': round(B / ms * 1e3, 1), 'final_loss': float(la)}
+                # (replayed_as_graph False = the trainer's capture-time check refused the captured step -- it says why on stderr -- and
+                # the arm ran as eager launches: the bf16-autocast arms on this stack; the fp32 per-window headline is captured)
+                return {'ms_per_step': round(ms, 3), 'clips_per_s': round(B / ms * 1e3, 1), 'final_loss': float(la),
+                        'replayed_as_graph': bool(t.use_graph and getattr(t, '_graphs', None) is not None)}
             except Exception as e:                                      # noqa: BLE001
                 return {'error': repr(e)[:200]}
         out['bf16_autocast'] = arm(compute_dtype=torch.bfloat16)
