@@ -117,7 +117,7 @@ def _case_failed_capture():
         return real(self)
     GradientExchange.all_reduce_gradients = broken
     printed = io.StringIO()
-    with contextlib.redirect_stdout(printed):
+    with contextlib.redirect_stderr(printed):             # (the trainer's notices go to stderr: stdout is bench.py's one JSON line)
         tb = Trainer(device=d, use_graph=True).setup(flow_b, dm)
         got = torch.stack([tb.train_step(flow_b, batch, i).clone() for i in range(6)]).cpu()
     assert tb._graphs[1] is not None                       # the eager-collective structure
