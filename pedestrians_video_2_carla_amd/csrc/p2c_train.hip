@@ -428,10 +428,20 @@ struct WgradArgs {
 
 __device__ __forceinline__ void finalize_losses(const WgradArgs &a, double (*sh)[256]) {   // = p2c::loss_finalize
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < a.n_stiles; i += 256) {
-    s0 += (double)a.loss_partials[i * 4 + 0];
-    s1 += (double)a.loss_partials[i * 4 + 1];
-    s2 += (double)a.loss_partials[i * 4 + 2];
+  // one 16-byte load per clip, eight in flight per thread, added in index order (the sums are the same doubles as a plain loop's:
+  // same terms, same order per thread). With one dependent round trip per clip this one workgroup was the long pole of the
+  // launch from a few thousand clips on (B = 8192: 20 us).
+  const f32x4 *lp = reinterpret_cast<const f32x4 *>(a.loss_partials);
+  for (int i0 = threadIdx.x; i0 < a.n_stiles; i0 += 8 * 256) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      v[u] = lp[i < a.n_stiles ? i : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * 256 < a.n_stiles) s0 += (double)v[u][0], s1 += (double)v[u][1], s2 += (double)v[u][2];
   }
   sh[0][threadIdx.x] = s0, sh[1][threadIdx.x] = s1, sh[2][threadIdx.x] = s2;
   __syncthreads();
@@ -601,131 +611,153 @@ __global__ __launch_bounds__(64 * WG_WAVES) void train_wgrad_kernel(const WgradA
 // slice, and a workgroup leaves one 79 KB partial. wgrad_reduce_kernel adds the partials in workgroup order (fixed: bitwise
 // reproducible), applies AdamW, refreshes the weight image and finishes the losses.
 constexpr int WS_BLOCKS_MAX = 256;
+// Every factor row enters the CU ONCE: the eight waves copy a clip's 34 KB block into an LDS slot by LDS-DMA (buffer_load ... lds,
+// 1 KB pieces dealt round-robin), three slots in a ring, and take their operand fragments from there (ds_read_b128: a fragment's
+// 16 rows x 16 bytes are contiguous per sample quarter). Loaded straight into registers (first version) the H rows of a layer were
+// fetched by every wave that owns a tile column of it -- 61 KB per clip through a CU's vector-memory path (about 11 B/clk) for a
+// 34 KB block: 77 us at B = 8192, the same at any prefetch depth and twice that on half the CUs.
+constexpr int WS_SLOT_PIECES = (F_ROWS * 64 + 1023) / 1024, WS_SLOT_FLOATS = WS_SLOT_PIECES * 256, WS_SLOTS = 3;   // (four slots: 76 vs 74 us at B = 8192)
+static_assert(WS_SLOTS * WS_SLOT_FLOATS * 4 <= 160 * 1024, "LDS budget of the factor ring");
+typedef __attribute__((address_space(3))) void *ws_lds_ptr;
+
 struct RowBlock {          // one dense block: n-tiles [n0, n0 + NA) x m-tiles [0, NB) of layer l; its first dW tile index
-  int l, n0, na, nb, tile0;
+  int l, n0, tile0;
 };
 template <int NA, int NB>
-__device__ __forceinline__ void wgrad_block(const WgradArgs &a, const RowBlock rb, const int first, const int step, const int end, const int lane,
-                                            f32x4 (&acc)[NA * NB]) {
-  const int r = lane & 15, k = lane >> 4;
-  int32_t dd[NLAY + 1];
-#pragma unroll
-  for (int i = 0; i <= NLAY; ++i) dd[i] = S::dim_at(i);
-  const int n_in = dd[rb.l], n_out = dd[rb.l + 1];
-  int g_row = F_HALF, h_row = 0;                               // first factor row of G_{l+1} / H_l
-  for (int i = 1; i <= rb.l; ++i) g_row += dd[i];
-  for (int i = 0; i < rb.l; ++i) h_row += dd[i];
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, ones = {1.f, 1.f, 1.f, 1.f};
-  size_t a_off[NA], b_off[NB];
+struct BlockState {
+  int a_off[NA], b_off[NB];                 // float offsets of the lane's fragments inside a slot
   bool a_ok[NA], b_ok[NB], b_one[NB];
+  f32x4 acc[NA * NB];
+  int tile0, mtiles;
+  __device__ __forceinline__ void init(const RowBlock rb, const int lane) {
+    const int r = lane & 15, k = lane >> 4;
+    int32_t dd[NLAY + 1];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int n = (rb.n0 + i) * 16 + r;
-    a_ok[i] = n < n_out, a_off[i] = (size_t)(g_row + (a_ok[i] ? n : 0)) * 16 + 4 * k;
+    for (int i = 0; i <= NLAY; ++i) dd[i] = S::dim_at(i);
+    const int n_in = dd[rb.l], n_out = dd[rb.l + 1];
+    int g_row = F_HALF, h_row = 0;                               // first factor row of G_{l+1} / H_l
+    for (int i = 1; i <= rb.l; ++i) g_row += dd[i];
+    for (int i = 0; i < rb.l; ++i) h_row += dd[i];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int n = (rb.n0 + i) * 16 + r;
+      a_ok[i] = n < n_out, a_off[i] = (g_row + (a_ok[i] ? n : 0)) * 16 + 4 * k;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int mm = j * 16 + r;
+      b_ok[j] = mm < n_in, b_one[j] = mm == n_in, b_off[j] = (h_row + (b_ok[j] ? mm : 0)) * 16 + 4 * k;
+    }
+#pragma unroll
+    for (int i = 0; i < NA * NB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    tile0 = rb.tile0, mtiles = (n_in + 1 + 15) >> 4;
   }
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const int mm = j * 16 + r;
-    b_ok[j] = mm < n_in, b_one[j] = mm == n_in, b_off[j] = (size_t)(h_row + (b_ok[j] ? mm : 0)) * 16 + 4 * k;
-  }
-#pragma unroll
-  for (int i = 0; i < NA * NB; ++i) acc[i] = zero;
-  const size_t f_tile = (size_t)F_ROWS * 16;
-  auto load = [&](int st, f32x4 (&av)[NA], f32x4 (&bv)[NB]) {      // unconditional loads from clamped rows, selected afterwards
-    const float *f = a.factors + (size_t)st * f_tile;
-#pragma unroll
-    for (int i = 0; i < NA; ++i) av[i] = *reinterpret_cast<const f32x4 *>(f + a_off[i]);
-#pragma unroll
-    for (int j = 0; j < NB; ++j) bv[j] = *reinterpret_cast<const f32x4 *>(f + b_off[j]);
-  };
-  auto fma = [&](const f32x4 (&av_)[NA], const f32x4 (&bv_)[NB]) {
+  __device__ __forceinline__ void fma(const float *slot) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f}, ones = {1.f, 1.f, 1.f, 1.f};
     f32x4 av[NA], bv[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) av[i] = a_ok[i] ? av_[i] : zero;
+    for (int i = 0; i < NA; ++i) av[i] = *reinterpret_cast<const f32x4 *>(slot + a_off[i]);
 #pragma unroll
-    for (int j = 0; j < NB; ++j) bv[j] = b_one[j] ? ones : (b_ok[j] ? bv_[j] : zero);
+    for (int j = 0; j < NB; ++j) bv[j] = *reinterpret_cast<const f32x4 *>(slot + b_off[j]);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) av[i] = a_ok[i] ? av[i] : zero;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bv[j] = b_one[j] ? ones : (b_ok[j] ? bv[j] : zero);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int i = 0; i < NA; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i * NB + j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][u], bv[j][u], acc[i * NB + j], 0, 0, 0);
-  };
-  // DEPTH clips in flight per wave (a ring of register sets): behind every clip's MFMAs the loads of the clip DEPTH steps ahead
-  // go out -- with one clip of look-ahead the loop ran at one HBM round trip per clip (B = 8192: 93 us for 35 us of MFMA)
-  constexpr int DEPTH = (NA + NB) * 4 * 6 <= 176 ? 6 : 5;
-  f32x4 ar[DEPTH][NA], br[DEPTH][NB];
-  const int last = end - 1;                       // (a valid clip even for an empty slice: end >= 1)
-  // (every load is unconditional, from a clamped clip: a load inside a branch makes the compiler drain the queue at the join;
-  // what a set holds beyond the slice is never multiplied)
-#pragma unroll
-  for (int dth = 0; dth < DEPTH; ++dth) {
-    const int cl = first + dth * step;
-    load(cl < last ? cl : last, ar[dth], br[dth]);
-  }
-  int st = first;
-  for (; st + (2 * DEPTH - 1) * step < end; st += DEPTH * step) {      // steady state: no tests inside
-#pragma unroll
-    for (int dth = 0; dth < DEPTH; ++dth) {
-      fma(ar[dth], br[dth]);
-      load(st + (dth + DEPTH) * step, ar[dth], br[dth]);
-    }
-  }
-  for (; st < end; st += DEPTH * step) {                               // the last one or two rounds
-#pragma unroll
-    for (int dth = 0; dth < DEPTH; ++dth) {
-      const int cur = st + dth * step, nxt = cur + DEPTH * step;
-      if (cur < end) fma(ar[dth], br[dth]);
-      load(nxt < last ? nxt : last, ar[dth], br[dth]);
-    }
   }
   // the block's partial tiles, in MFMA C layout (one 16-byte store per lane and tile)
-  f32x4 *out = reinterpret_cast<f32x4 *>(a.slices) + ((size_t)blockIdx.x * a.n_tiles_w + rb.tile0) * 64 + lane;
-  const int mtiles = (n_in + 1 + 15) >> 4;
+  __device__ __forceinline__ void store(const WgradArgs &a, const int lane) const {
+    // tile-major: the partials of one tile from all workgroups are contiguous (gridDim KB): the reduction streams them
+    f32x4 *out = reinterpret_cast<f32x4 *>(a.slices) + ((size_t)tile0 * gridDim.x + blockIdx.x) * 64 + lane;
 #pragma unroll
-  for (int i = 0; i < NA; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-    for (int j = 0; j < NB; ++j) out[(size_t)(i * mtiles + j) * 64] = acc[i * NB + j];
+      for (int j = 0; j < NB; ++j) out[(size_t)(i * mtiles + j) * gridDim.x * 64] = acc[i * NB + j];
+  }
+};
+
+// the clips of this workgroup through the LDS ring; compute(slot) is the wave's own tile work on one resident clip
+template <class F>
+__device__ __forceinline__ void ws_clip_loop(const WgradArgs &a, float *ring, const int first, const int step, const int end, const int wave,
+                                             const int lane, F &&compute) {
+  const int my_pieces = (WS_SLOT_PIECES - wave + WG_WAVES - 1) / WG_WAVES;        // pieces wave, wave + 8, ...
+  auto issue = [&](int clip, int slot) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.factors) + (size_t)clip * F_ROWS * 16, 0, F_ROWS * 64, 0x00020000);
+    const unsigned base = (unsigned)(uintptr_t)(ws_lds_ptr)(ring + slot * WS_SLOT_FLOATS);
+#pragma unroll
+    for (int i = 0; i < (WS_SLOT_PIECES + WG_WAVES - 1) / WG_WAVES; ++i) {
+      const int pc = wave + i * WG_WAVES;                            // (wave-uniform; the tail of the last piece reads past the records: zeros)
+      if (pc < WS_SLOT_PIECES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (ws_lds_ptr)(uintptr_t)(base + pc * 1024), 16, (pc * 64 + lane) * 16, 0, 0, 0);
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < WS_SLOTS - 1; ++s)
+    if (first + s * step < end) issue(first + s * step, s);
+  int slot = 0;
+  for (int clip = first; clip < end; clip += step) {
+    // this wave's pieces of THIS clip have landed once only the later clips' are outstanding (vector-memory operations retire in
+    // issue order: my_pieces per clip still in flight); then the barrier: everybody's have
+    int later = 0;                                  // clips already requested behind this one (at most WS_SLOTS - 2)
+#pragma unroll
+    for (int s = 1; s <= WS_SLOTS - 2; ++s) later += (clip + s * step < end) ? 1 : 0;
+    switch (later * my_pieces) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+      case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(ring + slot * WS_SLOT_FLOATS);
+    // the slot WS_SLOTS - 1 ahead (= the one behind) was read in the previous iteration: every wave finished with it before it
+    // passed the barrier above
+    const int ahead = slot >= 1 ? slot - 1 : WS_SLOTS - 1;
+    if (clip + (WS_SLOTS - 1) * step < end) issue(clip + (WS_SLOTS - 1) * step, ahead);
+    slot = slot + 1 == WS_SLOTS ? 0 : slot + 1;
+  }
 }
+static_assert(WS_SLOTS >= 3 && WS_SLOTS <= 5, "the counted waits above: up to three clips behind the current one");
+static_assert((WS_SLOT_PIECES + WG_WAVES - 1) / WG_WAVES == 5 && WS_SLOT_PIECES / WG_WAVES == 4, "the counted waits above: four or five pieces per wave");
 
 __global__ __launch_bounds__(64 * WG_WAVES) void wgrad_stream_kernel(const WgradArgs a) {
+  extern __shared__ float ws_ring[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-#ifdef P2C_WGRAD_CONTIGUOUS       // (A/B timing: a contiguous slice of clips per workgroup instead of the strided one)
-  const int per = (a.n_stiles + gridDim.x - 1) / gridDim.x;
-  const int first = blockIdx.x * per, step = 1, end = (first + per < a.n_stiles) ? first + per : a.n_stiles;
-#else
-  const int first = blockIdx.x, step = gridDim.x, end = a.n_stiles;      // clips b, b + grid, ...: those written on this XCD (grid = 0 mod 8)
-#endif
+  const int first = blockIdx.x, step = gridDim.x, end = a.n_stiles;      // clips b, b + grid, ...
   // tile index of (layer l, n-tile n, m-tile 0): layers 0..5 hold 8, 2, 1, 3, 15, 50 tiles
   constexpr int T0 = 0, T1 = 8, T2 = 10, T3 = 11, T4 = 14, T5 = 29;
   if (wave < 5) {
-    f32x4 acc[10];
-    wgrad_block<2, 5>(a, RowBlock{5, 2 * wave, 2, 5, T5 + 2 * wave * 5}, first, step, end, lane, acc);
+    BlockState<2, 5> b0;
+    b0.init(RowBlock{5, 2 * wave, T5 + 2 * wave * 5}, lane);
+    ws_clip_loop(a, ws_ring, first, step, end, wave, lane, [&](const float *slot) { b0.fma(slot); });
+    b0.store(a, lane);
   } else if (wave == 5) {
-    f32x4 acc[9];
-    wgrad_block<3, 3>(a, RowBlock{4, 0, 3, 3, T4}, first, step, end, lane, acc);
+    BlockState<3, 3> b0;
+    b0.init(RowBlock{4, 0, T4}, lane);
+    ws_clip_loop(a, ws_ring, first, step, end, wave, lane, [&](const float *slot) { b0.fma(slot); });
+    b0.store(a, lane);
   } else if (wave == 6) {
-    {
-      f32x4 acc[6];
-      wgrad_block<2, 3>(a, RowBlock{4, 3, 2, 3, T4 + 9}, first, step, end, lane, acc);
-    }
-    {
-      f32x4 acc[3];
-      wgrad_block<3, 1>(a, RowBlock{3, 0, 3, 1, T3}, first, step, end, lane, acc);
-    }
+    BlockState<2, 3> b0;
+    BlockState<3, 1> b1;
+    b0.init(RowBlock{4, 3, T4 + 9}, lane), b1.init(RowBlock{3, 0, T3}, lane);
+    ws_clip_loop(a, ws_ring, first, step, end, wave, lane, [&](const float *slot) { b0.fma(slot), b1.fma(slot); });
+    b0.store(a, lane), b1.store(a, lane);
   } else {
-    {
-      f32x4 acc[8];
-      wgrad_block<2, 4>(a, RowBlock{0, 0, 2, 4, T0}, first, step, end, lane, acc);
-    }
-    {
-      f32x4 acc[2];
-      wgrad_block<1, 2>(a, RowBlock{1, 0, 1, 2, T1}, first, step, end, lane, acc);
-    }
-    {
-      f32x4 acc[1];
-      wgrad_block<1, 1>(a, RowBlock{2, 0, 1, 1, T2}, first, step, end, lane, acc);
-    }
+    BlockState<2, 4> b0;
+    BlockState<1, 2> b1;
+    BlockState<1, 1> b2;
+    b0.init(RowBlock{0, 0, T0}, lane), b1.init(RowBlock{1, 0, T1}, lane), b2.init(RowBlock{2, 0, T2}, lane);
+    ws_clip_loop(a, ws_ring, first, step, end, wave, lane, [&](const float *slot) { b0.fma(slot), b1.fma(slot), b2.fma(slot); });
+    b0.store(a, lane), b1.store(a, lane), b2.store(a, lane);
   }
 }
 
@@ -766,8 +798,8 @@ __global__ __launch_bounds__(RED_L * RED_G) void wgrad_reduce_kernel(const Wgrad
       pv[r] = o.param[off], mv[r] = o.exp_avg[off], vv[r] = o.exp_avg_sq[off];
     }
   }
-  const size_t stride = (size_t)a.n_tiles_w * 64;
-  const f32x4 *p = reinterpret_cast<const f32x4 *>(a.slices) + (size_t)t * 64 + lane;
+  const size_t stride = 64;                              // tile-major partials: workgroup w's copy of tile t at (t n_blocks + w) KB
+  const f32x4 *p = reinterpret_cast<const f32x4 *>(a.slices) + (size_t)t * n_blocks * 64 + lane;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   int w = q;
   for (; w + 7 * RED_G < n_blocks; w += 8 * RED_G) {     // eight loads in flight, added in workgroup order
@@ -995,9 +1027,17 @@ extern "C" int p2c_train_step_launch(const p2c_train_step_desc *desc, const floa
   if (d.B >= wgrad_stream_min_b()) {
     // thousands of clips: every factor block crosses HBM once (wgrad_stream_kernel), the per-workgroup partials are added by a third launch
     int blocks = d.B / 8;                                         // at least eight clips per workgroup; a multiple of 8 (XCD affinity)
-    blocks = blocks > WS_BLOCKS_MAX ? WS_BLOCKS_MAX : (blocks & ~7);
+    static const int max_blocks = getenv("P2C_WGRAD_STREAM_BLOCKS") ? atoi(getenv("P2C_WGRAD_STREAM_BLOCKS")) : WS_BLOCKS_MAX;   // (A/B timing)
+    const int cap = max_blocks < WS_BLOCKS_MAX ? (max_blocks < 8 ? 8 : max_blocks) : WS_BLOCKS_MAX;
+    blocks = blocks > cap ? cap : (blocks & ~7);
     if (blocks < 8) blocks = 8;
-    hipLaunchKernelGGL(wgrad_stream_kernel, dim3((unsigned)blocks), dim3(64 * WG_WAVES), 0, stream, wa);
+    static bool ws_attr = false;
+    if (!ws_attr) {
+      (void)hipFuncSetAttribute((const void *)wgrad_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WS_SLOTS * WS_SLOT_FLOATS * 4);
+      (void)hipGetLastError();
+      ws_attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_stream_kernel, dim3((unsigned)blocks), dim3(64 * WG_WAVES), WS_SLOTS * WS_SLOT_FLOATS * 4, stream, wa);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const dim3 grid_r((unsigned)(tiles * (64 / RED_L) + 1));
