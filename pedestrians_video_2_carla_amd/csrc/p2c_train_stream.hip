@@ -90,6 +90,9 @@ static __device__ unsigned long long g_strace[64];
 #ifndef P2C_STREAM_EXPERIMENT
 #define P2C_STREAM_EXPERIMENT 0
 #endif
+#ifndef P2C_STREAM_PRIO
+#define P2C_STREAM_PRIO 1                   // s_setprio of a wave in its MLP phases (pose phases: 0): its sparse MFMA issue does not
+#endif                                      // queue behind the VALU stream of the other pair on its SIMD (B = 8192: 221 -> 213 us)
 constexpr int GROUP = 5;                   // output tiles per pass over k (accumulators in flight)
 
 // A value the optimiser must take as new at this point: everything derived from it is recomputed here instead of being hoisted
@@ -678,7 +681,16 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
   // same one): the tile split of the MLP layers runs on two matrix pipes, and every SIMD hosts one wave of pair p and one of pair
   // p + 2. The pairs run FREE of each other (PairSync, no workgroup barrier in the loop): 250 -> 221 us at B = 8192 against the
   // lockstep version (every rendezvous then waited for the slowest of eight waves).
-  const int pair = wave >> 1, half = wave & 1;
+#ifndef P2C_STREAM_PAIRING
+#define P2C_STREAM_PAIRING 0
+#endif
+  const int pair = P2C_STREAM_PAIRING ? (wave & 3) : (wave >> 1), half = P2C_STREAM_PAIRING ? (wave >> 2) : (wave & 1);
+  // which share of an odd tile split a wave takes: pairs p and p + 2 share their SIMDs, so the larger share alternates between
+  // the two SIMDs (layer 5's dgrad: 3 + 2 m-tiles -> 200 + 200 MFMAs per SIMD instead of 240 + 160 when both pairs are in it)
+#ifndef P2C_STREAM_SWAP
+#define P2C_STREAM_SWAP 0        // (A/B: alternating the larger share of an odd tile split between pairs p and p + 2: 220 vs 212 us)
+#endif
+  const int role = P2C_STREAM_SWAP ? (half ^ ((pair >> 1) & 1)) : half;
   float *img = lds;
   float *tab = lds + S::w_total();
   float *scratch = tab + TAB_FLOATS;
@@ -736,7 +748,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
 
   ST(1);
   PairSync ps;
-  ps.mine = reinterpret_cast<int *>(scratch + 8) + wave, ps.other = reinterpret_cast<int *>(scratch + 8) + (wave ^ 1), ps.epoch = 0;
+  ps.mine = reinterpret_cast<int *>(scratch + 8) + wave, ps.other = reinterpret_cast<int *>(scratch + 8) + (wave ^ (P2C_STREAM_PAIRING ? 4 : 1)), ps.epoch = 0;
 #ifndef P2C_STREAM_STAGGER
 #define P2C_STREAM_STAGGER 0        // x 8 k cycles of head start for pairs 0, 1 (A/B timing: 0 / 3 / 6 / 12 -> 221 / 227 / 234 / 246 us at
 #endif                              // B = 8192: the steady state does not care how the pairs of a SIMD are phased; the delay is just lost)
@@ -757,10 +769,13 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       WLane L;
       L.lane = fresh(lane0), L.c = L.lane & 15, L.g = L.lane >> 4;
       ST(3);
+#if P2C_STREAM_PRIO
+      __builtin_amdgcn_s_setprio(P2C_STREAM_PRIO);
+#endif
       HalfRows<S::dims(0)> h0;
       if (mlp) {
         half_read(Y, L.lane, half, h0);
-        fwd_layer<0>(L, half, img, Y, A, mask);
+        fwd_layer<0>(L, role, img, Y, A, mask);
         pose_inputs_landed(pin);                   // (in front of the first factor store: the wait covers loads only)
         half_store(h0, fdst + f_h_off(0) * 16, L.lane, half);
       }
@@ -769,7 +784,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       HalfRows<S::dims(1)> h1;
       if (mlp) {
         half_read(A, L.lane, half, h1);
-        fwd_layer<1>(L, half, img, A, Bb, mask);
+        fwd_layer<1>(L, role, img, A, Bb, mask);
         half_store(h1, fdst + f_h_off(1) * 16, L.lane, half);
       }
       ps.sync();     
@@ -777,7 +792,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       HalfRows<S::dims(2)> h2;
       if (mlp) {
         half_read(Bb, L.lane, half, h2);
-        fwd_layer<2>(L, half, img, Bb, A, mask);
+        fwd_layer<2>(L, role, img, Bb, A, mask);
         half_store(h2, fdst + f_h_off(2) * 16, L.lane, half);
       }
       ps.sync();     
@@ -785,7 +800,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       HalfRows<S::dims(3)> h3;
       if (mlp) {
         half_read(A, L.lane, half, h3);
-        fwd_layer<3>(L, half, img, A, Bb, mask);
+        fwd_layer<3>(L, role, img, A, Bb, mask);
         half_store(h3, fdst + f_h_off(3) * 16, L.lane, half);
       }
       ps.sync();     
@@ -793,7 +808,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       HalfRows<S::dims(4)> h4;
       if (mlp) {
         half_read(Bb, L.lane, half, h4);
-        fwd_layer<4>(L, half, img, Bb, A, mask);
+        fwd_layer<4>(L, role, img, Bb, A, mask);
         half_store(h4, fdst + f_h_off(4) * 16, L.lane, half);
       }
       ps.sync();     
@@ -801,24 +816,30 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       HalfRows<S::dims(5)> h5;
       if (mlp) {
         half_read(A, L.lane, half, h5);
-        fwd_layer<5>(L, half, img, A, Y, mask);
+        fwd_layer<5>(L, role, img, A, Y, mask);
         half_store(h5, fdst + f_h_off(5) * 16, L.lane, half);
       }
       ST(9);
     }
     ps.sync();                                      // ---- y^T is complete (and buffer A is free: the pose head's hand-over scratch) ----
     // ---- pose head forward + backward by both wavefronts of the pair: y^T -> grad_y^T in place --------------------------------------
+#if P2C_STREAM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     pose_phase<KIND>(d, active && !(P2C_STREAM_EXPERIMENT & 1), (int)clip, lane0, half, pin, Y, A, tab, coef2, coef3, ps);
     ST(32);
     {
       WLane L;
       L.lane = fresh(lane0), L.c = L.lane & 15, L.g = L.lane >> 4;
+#if P2C_STREAM_PRIO
+      __builtin_amdgcn_s_setprio(P2C_STREAM_PRIO);
+#endif
       if (half != 0) x_issue(m.x, clip + stride, d.B, T, L.lane, xr);   // the pair's next clip: lands behind the first dgrad layer
       // ---- dgrad chain, side by side; every G_l leaves as soon as it exists ----------------------------------------------------------
       HalfRows<S::dims(6)> g6;
       if (mlp) {
         half_read(Y, L.lane, half, g6);
-        dgrad_layer<5>(L, half, img, Y, A, mask);
+        dgrad_layer<5>(L, role, img, Y, A, mask);
         half_store(g6, fdst + f_g_off(6) * 16, L.lane, half);
       }
       ps.sync();                                    // ---- grad_y^T has been read: the y rows are free for the next clip's H_0 ----
@@ -826,7 +847,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       HalfRows<S::dims(5)> g5;
       if (mlp) {
         half_read(A, L.lane, half, g5);
-        dgrad_layer<4>(L, half, img, A, Bb, mask);
+        dgrad_layer<4>(L, role, img, A, Bb, mask);
         half_store(g5, fdst + f_g_off(5) * 16, L.lane, half);
       }
       if (half != 0 && clip + stride < d.B) x_commit(xr, x_offsets(L.lane), Y, L.lane);   // (its share of this layer is the small one)
@@ -835,7 +856,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       HalfRows<S::dims(4)> g4;
       if (mlp) {
         half_read(Bb, L.lane, half, g4);
-        dgrad_layer<3>(L, half, img, Bb, A, mask);
+        dgrad_layer<3>(L, role, img, Bb, A, mask);
         half_store(g4, fdst + f_g_off(4) * 16, L.lane, half);
       }
       ps.sync();     
@@ -843,7 +864,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       HalfRows<S::dims(3)> g3;
       if (mlp) {
         half_read(A, L.lane, half, g3);
-        dgrad_layer<2>(L, half, img, A, Bb, mask);
+        dgrad_layer<2>(L, role, img, A, Bb, mask);
         half_store(g3, fdst + f_g_off(3) * 16, L.lane, half);
       }
       ps.sync();     
@@ -851,7 +872,7 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       HalfRows<S::dims(2)> g2;
       if (mlp) {
         half_read(Bb, L.lane, half, g2);
-        dgrad_layer<1>(L, half, img, Bb, A, mask);
+        dgrad_layer<1>(L, role, img, Bb, A, mask);
         half_store(g2, fdst + f_g_off(2) * 16, L.lane, half);
       }
       ps.sync();     

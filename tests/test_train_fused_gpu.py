@@ -125,6 +125,26 @@ def test_throughput_forms_match_the_separate_kernels_at_full_size(monkeypatch, B
     close(grads['1'][1], grads['0'][1], 'flat gradient', rtol=1e-4)
 
 
+@pytest.mark.parametrize('first_launch_form', ['stream+wgrad', 'latency'], indirect=True)
+def test_eval_slice_in_both_forms_matches_the_separate_kernels(monkeypatch, first_launch_form):
+    """An eval slice (frames 2 .. 12 of 16 carry the losses, the rotations still accumulate over all frames): both forms of the fused
+    step against the separate kernels, B = 44 with 10 % missing joints."""
+    grads = {}
+    monkeypatch.setenv('P2C_FUSED_UPDATE', '0')
+    for fused in ('0', '1'):
+        monkeypatch.setenv('P2C_FUSED_TRAIN', fused)
+        flow, dm = make(B=44, missing=0.1)
+        monkeypatch.setattr(type(flow.movements_model), 'eval_slice', property(lambda self: slice(2, 13)))
+        trainer = _trainer(flow, dm)
+        trainer.optimizers[0].zero_grad_in_step = False
+        batch = dm.generate_batch(dev())
+        loss = trainer._forward_backward(flow, batch, 0)
+        assert _took_fused_path(flow) == (fused == '1')
+        grads[fused] = (loss.clone(), trainer.flat.flat_grad.clone())
+    close(grads['1'][0], grads['0'][0], 'loss', rtol=1e-6)
+    close(grads['1'][1], grads['0'][1], 'flat gradient', rtol=1e-4)
+
+
 def test_fused_step_with_world_motion_and_body25_targets_matches_separate_kernels(monkeypatch):
     """Non-identity trajectory (dloc / drot) and an eval slice: fused step vs the separate kernels (tolerance: the two paths
     run different weight-gradient orders at this batch size)."""
