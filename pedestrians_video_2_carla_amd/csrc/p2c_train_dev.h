@@ -1,6 +1,6 @@
 // p2c_train_dev.h -- geometry shared by the two forms of the fused train step's first launch: train_clip_kernel (p2c_train.hip:
 // one workgroup of eight wavefronts per clip, the latency form for about one clip per CU) and train_stream_kernel
-// (p2c_train_stream.hip: one wavefront per clip, the throughput form for several clips per CU). Both leave the same factor
+// (p2c_train_stream.hip: a pair of wavefronts per clip, four pairs per workgroup: the throughput form for several clips per CU). Both leave the same factor
 // blocks and per-clip loss sums for train_wgrad_kernel.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -1,4 +1,5 @@
-// p2c_train_stream.hip -- the THROUGHPUT form of the fused train step's first launch (gfx950): one wavefront per clip.
+// p2c_train_stream.hip -- the THROUGHPUT form of the fused train step's first launch (gfx950): two wavefronts per clip,
+// four clips in flight per CU.
 //
 // What it replaces: the same reference path as p2c_train.hip (modules/flow/pose_lifting.py:121-144 -> LinearAE.forward,
 // linear_ae.py:50-59 -> ProjectionModule, modules/layers/projection.py:73-123 -> transform_callable -> loss/loc_2d_3d.py:6-17
@@ -6,18 +7,21 @@
 // wavefronts and 156 KB of LDS on one clip at a time -- the latency form, right at one clip per CU (B = 256) and a queue of
 // dependent 16-sample chains beyond it (B = 1024: four clips per CU back to back, 57 us). Here
 //
-//   * a workgroup is FOUR wavefronts, one per SIMD, each with the whole register file of its SIMD (512 VGPRs) and each walking
-//     its OWN clips start to finish: no workgroup barrier after the prologue;
-//   * the packed weight image (84 KB) sits in LDS once per workgroup (LDS-DMA, one burst) and serves all four;
-//   * a wavefront's activations live in a private 18 KB LDS region, transposed ([feature row][16 frames], pitch 16 = the
-//     layout of the factor blocks train_wgrad_kernel reads: factor rows leave as straight 1 KB copies): H_0 .. H_5
-//     ping-pong through two small buffers, y^T / grad_y^T share the third; the ReLU masks of H_1 .. H_5 are 48 bits per
-//     lane in registers (lane (frame c, group g) of the dgrad meets exactly the elements it produced in the forward);
-//   * the pose head is the chain-lane arithmetic of p2c_pose_head_chain_dev.h with a different unit: eight lanes own
-//     a (clip, time SEGMENT of two frames) and the wavefront's eight segments cover the clip's sixteen frames. The only
-//     couplings between frames become cross-lane scans: the cumulative rotation (projection.py:190-193) an exclusive scan
-//     of 3x3 products over the segments (three ds_bpermute rounds), the backward's suffix sum of torques an add scan.
-//     y never leaves LDS, grad_y is written over it and is the dgrad chain's first operand: no y / grad_y traffic at any B.
+//   * a workgroup is EIGHT wavefronts in FOUR pairs (waves 2p, 2p + 1: two different SIMDs); a pair walks its OWN clips start to
+//     finish and meets only its partner (PairSync: two LDS counters) -- no workgroup barrier after the prologue, the four pairs
+//     drift apart and one pair's MFMA phases fill the matrix pipes while another's pose head holds the VALUs;
+//   * the packed weight image (84 KB) sits in LDS once per workgroup (LDS-DMA, one burst) and serves all four pairs;
+//   * a pair's activations live in a private 18 KB LDS region, transposed ([feature row][16 frames], pitch 16 = the layout of
+//     the factor blocks the weight-gradient launch reads: factor rows leave as straight 1 KB copies): H_0 .. H_5 ping-pong
+//     through two small buffers, y^T / grad_y^T share the third; a layer's 16-row output tiles are split between the pair's
+//     two waves (one pass over k per wave, up to GROUP accumulators), the ReLU masks of H_1 .. H_5 are 48 bits per lane in
+//     registers (the same wave owns a tile of H_l as a forward output and as a dgrad m-tile);
+//   * the pose head is the chain-lane arithmetic of p2c_pose_head_chain_dev.h with a different unit: eight lanes own a
+//     (clip, FRAME), wave `half` of the pair owns frames 8 half .. 8 half + 7. The only couplings between frames become scans:
+//     the cumulative rotation (projection.py:190-193) an exclusive scan of 3x3 products over the wave's eight frames (three
+//     ds_bpermute rounds) + one hand-over of the first wave's total to the second through LDS; the backward's suffix sum of
+//     torques an add scan + the second wave's total to the first. y never leaves LDS, grad_y is written over it and is the
+//     dgrad chain's first operand: no y / grad_y traffic at any B.
 //
 // Leaves what train_clip_kernel leaves: the clip's factor block (H_0 .. H_5 | G_1 .. G_6, 34 KB) and its three loss sums.
 // MLP arithmetic: the same fmaf chains in the same k order as p2c_mlp_dev.h (fp32 MFMA 16x16x4); pose head: the sums over
@@ -43,7 +47,7 @@ using ph::M3;
 using ph::V3;
 
 constexpr int SW = 8;                       // wavefronts per workgroup: two per SIMD
-constexpr int PAIRS = 4;                    // ... in four pairs (2p, 2p + 1): a pair shares an LDS region and a clip
+constexpr int PAIRS = 4;                    // ... in four pairs (2p, 2p + 1: two SIMDs): a pair shares an LDS region and a clip
 constexpr int PT = 16;                      // LDS pitch of an activation row (floats) = frames of a clip
 constexpr int ROWS_Y = 160;                 // y^T / grad_y^T (156 rows + k padding); H_0 before the first layer
 constexpr int ROWS_A = 80, ROWS_B = 48;     // ping-pong buffers: A holds H_1, H_3, H_5 / G_5, G_3, G_1; B holds H_2, H_4 / G_4, G_2
@@ -184,10 +188,9 @@ __device__ __forceinline__ void fwd_tiles(const WLane &L, const float *wl, const
     }
   }
 }
-// The two wavefronts of a pair split a layer's output tiles: the first takes tiles [0, ceil(n / 2)), the second the rest. Both
-// sit on one SIMD and share its matrix pipe -- the split buys no MFMA rate, it fills one wave's start-up (first operands exposed),
-// epilogue and factor stores with the other's MFMAs. The same split of H_l's tiles in the forward (as layer l-1's output) and in
-// the dgrad (as layer l's m-tiles) keeps a lane's ReLU mask bits with the wave that needs them.
+// The two wavefronts of a pair split a layer's output tiles: the first takes tiles [0, ceil(n / 2)), the second the rest (two
+// SIMDs, two matrix pipes: see the kernel). The same split of H_l's tiles in the forward (as layer l-1's output) and in the
+// dgrad (as layer l's m-tiles) keeps a lane's ReLU mask bits with the wave that needs them.
 __host__ __device__ constexpr int split0(int n) { return (n + 1) / 2; }
 template <int LL, int T0, int CNT>
 __device__ __forceinline__ void fwd_range(const WLane &L, const float *img, const float *in, float *out, uint64_t &mask) {
@@ -448,7 +451,7 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
   auto bperm = [](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
 
   const ch::FrameIn4 &in = pin.in;
-  M3 c[NS], P[NS];                                  // the frame's changes (rows b1, b2, b3); rel_rot BEFORE the frame
+  M3 c[NS], X[NS];                                  // the frame's changes (rows b1, b2, b3); their inclusive products over time
   float gs_n1[NS], gs_n2[NS], gs_d[NS];             // what the pull-back needs besides c: |a1|, |u2|, b1 . a2
   bool gs_ok[NS];
   ST(20);
@@ -464,26 +467,26 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
       ph::SixD s;
       c[k] = ph::rot6d_fwd(y6, s);
       gs_n1[k] = s.n1, gs_n2[k] = s.n2, gs_d[k] = s.d, gs_ok[k] = s.c1 && s.c2;
-    }
-    // ---- reference skeleton of the clip (data/carla/reference.py tables, staged in LDS) --------------------------------------
-    const int st = __builtin_amdgcn_readfirstlane(pin.st) & 3;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      const int j = L.start + k < ph::J ? L.start + k : ph::J - 1;
-      const int row = st * ph::J + j;
-      P[k] = ph::identity();
-      if (K::SCAN) {
-#pragma unroll
-        for (int i = 0; i < 9; ++i) P[k].m[i] = tab[TAB_ROT + row * 9 + i];
-      }
+      X[k] = c[k];
     }
     ST(21);
     if (K::SCAN) {
-      // rel_rot[t] = change[t] rel_rot[t-1] (projection.py:190-193): inclusive scan of the changes over the wave's eight frames
-      // (the four bones of a round travel together), then one more move makes it exclusive
-      M3 X[NS];
+      // rel_rot[t] = change[t] rel_rot[t-1], rel_rot[-1] = the clip's reference pose (projection.py:190-193; data/carla/reference.py
+      // tables, staged in LDS): frame 0's element of the scan is change[0] x reference, so the inclusive products ARE rel_rot -- no
+      // exclusive shift, no product with the reference per frame. Only the first wavefront holds frame 0.
+      if (half == 0) {
+        const int st = __builtin_amdgcn_readfirstlane(pin.st) & 3;
 #pragma unroll
-      for (int k = 0; k < NS; ++k) X[k] = c[k];
+        for (int k = 0; k < NS; ++k) {
+          const int j = L.start + k < ph::J ? L.start + k : ph::J - 1;
+          const int row = st * ph::J + j;
+          M3 Rref;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Rref.m[i] = tab[TAB_ROT + row * 9 + i];
+          X[k] = ch::sel(lane < 8, ph::mul(c[k], Rref), c[k]);
+        }
+      }
+      // inclusive scan over the wave's eight frames (the four bones of a round travel together)
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         M3 Q[NS];
@@ -495,27 +498,16 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
 #pragma unroll
         for (int k = 0; k < NS; ++k) X[k] = ch::sel(has, ph::mul(X[k], Q[k]), X[k]);
       }
-      if (half == 0 && lane >= 56) {               // the product of frames 0 .. 7: the second wavefront starts from it
+      if (half == 0 && lane >= 56) {               // rel_rot[7]: the second wavefront's frames continue from it
 #pragma unroll
         for (int k = 0; k < NS; ++k)
 #pragma unroll
           for (int i = 0; i < 9; ++i) xch[XCH_ROT + (L.chain * NS + k) * 9 + i] = X[k].m[i];
       }
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        M3 E;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) E.m[i] = bperm(up_addr[0], X[k].m[i]);
-        X[k] = ch::sel(lane >= 8, E, ph::identity());
-      }
-      // first wavefront: rel_rot before the frame = (exclusive product) x (reference pose), now; the second keeps its exclusive
-      // product in P's place and completes it behind the hand-over: (exclusive product) x (frames 0 .. 7) x (reference pose)
-#pragma unroll
-      for (int k = 0; k < NS; ++k) P[k] = (half == 0) ? ch::sel(lane >= 8, ph::mul(X[k], P[k]), P[k]) : X[k];
     }
   }
   ST(22);
-  ps.sync();                                       // ---- hand-over 1: the first half's product is in LDS ----
+  ps.sync();                                       // ---- hand-over 1: the first half's rel_rot[7] is in LDS ----
   ch::Acc acc{0.f, 0.f, 0.f};
   V3 taup[NS], later[NS], gb1[NS], gb2[NS], gb3[NS];   // rows of the change: what the pull-back needs of it
   M3 R[NS];                                        // rel_rot of the frame
@@ -525,22 +517,18 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
       gb1[k] = ph::v3(c[k].m[0], c[k].m[1], c[k].m[2]), gb2[k] = ph::v3(c[k].m[3], c[k].m[4], c[k].m[5]);
       gb3[k] = ph::v3(c[k].m[6], c[k].m[7], c[k].m[8]);
     }
-    if (K::SCAN && half != 0) {
-      const int st = __builtin_amdgcn_readfirstlane(pin.st) & 3;
 #pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        const int j = L.start + k < ph::J ? L.start + k : ph::J - 1;
-        const int row = st * ph::J + j;
-        M3 TA, Rref;
+    for (int k = 0; k < NS; ++k) {
+      R[k] = X[k];                                 // (kinds without a scan: the change itself)
+      if (K::SCAN && half != 0) {
+        M3 TA;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) TA.m[i] = xch[XCH_ROT + (L.chain * NS + k) * 9 + i], Rref.m[i] = tab[TAB_ROT + row * 9 + i];
-        P[k] = ph::mul(ph::mul(P[k], TA), Rref);
+        for (int i = 0; i < 9; ++i) TA.m[i] = xch[XCH_ROT + (L.chain * NS + k) * 9 + i];
+        R[k] = ph::mul(X[k], TA);
       }
     }
     ST(23);
     // ---- forward + backward of the frame down to the parent-frame torques -----------------------------------------------------
-#pragma unroll
-    for (int k = 0; k < NS; ++k) R[k] = K::SCAN ? ph::mul(c[k], P[k]) : c[k];       // rel_rot of the frame; c, P are dead from here
     V3 l[NS];
     {
       const int st = __builtin_amdgcn_readfirstlane(pin.st) & 3;
@@ -614,7 +602,7 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
     }
     // ---- pull-back through Gram-Schmidt (closed form, see pose_head_chain_bwd), grad_y^T over y^T ------------------------------
     // g = S rel_rot[t-1]^T enters only through its components in the frame (b1, b2, b3) = the rows of the change c, and
-    // rel_rot[t-1] = c^T rel_rot[t]: (g . b_i) = (S rel_rot[t]^T c . b_i) = (S rel_rot[t]^T)_i -- neither c nor rel_rot[t-1] is kept
+    // rel_rot[t-1] = c^T rel_rot[t]: (g . b_i) = (S rel_rot[t]^T c . b_i) = (S rel_rot[t]^T)_i -- rel_rot[t-1] is never formed
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       const V3 b1 = K::SCAN ? ph::cross(gb2[k], gb3[k]) : gb1[k], b2 = gb2[k], b3 = gb3[k];
