@@ -384,6 +384,7 @@ __device__ __forceinline__ void x_commit(const XRegs &r, const XOffs &xo, float 
 
 typedef __attribute__((address_space(3))) void *lds_void_ptr;
 constexpr int IMG_CHUNKS = ((S::w_total() >> 2) + 63) / 64;          // 1 KB pieces (64 lanes x 16 B)
+constexpr int IMG_CHUNKS_EARLY = (S::w_off(NLAY - 1) * 4 + 1023) / 1024;   // ... that hold layers 0 .. L-2 (and the head of the last layer)
 
 // targets of one frame for the lane's four bones + the clip's skeleton type: issued at the TOP of an iteration (in front of the
 // forward's factor stores: vmcnt retires in issue order, a load behind 26 stores waits for all of them), consumed by the pose head
@@ -412,6 +413,10 @@ __device__ __forceinline__ void pose_inputs(const p2c_pose_head_desc &d, const i
   }
 }
 
+__device__ __forceinline__ void x_landed(XRegs &r) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(r.v[u]));
+}
 // the loaded values are pinned HERE: the wait the compiler emits for them covers loads only when no store has been issued yet
 __device__ __forceinline__ void pose_inputs_landed(PoseIn &pi) {
 #pragma unroll
@@ -597,8 +602,11 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
   ps.sync();                                       // ---- hand-over 2: the second half's torque sums (and loss sums) are in LDS ----
   if (active) {
     if (half == 0 && lane == 0) {
+      // (an asm store like the factor rows': a store hipcc knows about makes the next write to its data registers -- the ds_read
+      // at the top of the next clip -- wait for vmcnt(0), i.e. for every factor store of this clip)
       float *pp = d.partials + (size_t)clip * 4;
-      pp[0] = acc.sum2 + xch[XCH_LOSS], pp[1] = acc.cnt2 + xch[XCH_LOSS + 1], pp[2] = acc.sum3 + xch[XCH_LOSS + 2], pp[3] = 0.f;
+      const f32x4 pv = {acc.sum2 + xch[XCH_LOSS], acc.cnt2 + xch[XCH_LOSS + 1], acc.sum3 + xch[XCH_LOSS + 2], 0.f};
+      asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(pp), "v"(pv) : "memory");
     }
     // ---- pull-back through Gram-Schmidt (closed form, see pose_head_chain_bwd), grad_y^T over y^T ------------------------------
     // g = S rel_rot[t-1]^T enters only through its components in the frame (b1, b2, b3) = the rows of the change c, and
@@ -673,12 +681,10 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
 #define P2C_STREAM_PAIRING 0
 #endif
   const int pair = P2C_STREAM_PAIRING ? (wave & 3) : (wave >> 1), half = P2C_STREAM_PAIRING ? (wave >> 2) : (wave & 1);
-  // which share of an odd tile split a wave takes: pairs p and p + 2 share their SIMDs, so the larger share alternates between
-  // the two SIMDs (layer 5's dgrad: 3 + 2 m-tiles -> 200 + 200 MFMAs per SIMD instead of 240 + 160 when both pairs are in it)
-#ifndef P2C_STREAM_SWAP
-#define P2C_STREAM_SWAP 0        // (A/B: alternating the larger share of an odd tile split between pairs p and p + 2: 220 vs 212 us)
-#endif
-  const int role = P2C_STREAM_SWAP ? (half ^ ((pair >> 1) & 1)) : half;
+  // (A/B, no gain either way: alternating the larger share of an odd tile split between pairs p and p + 2, which share their two
+  // SIMDs -- 200 + 200 instead of 240 + 160 MFMAs per SIMD in layer 5's dgrad: 220 vs 212 us at B = 8192 when always on; on
+  // only while every pair has a single clip and the pairs stay in step, B = 1024: 34.5 vs 34.7 us, inside the noise)
+  const int role = half;
   float *img = lds;
   float *tab = lds + S::w_total();
   float *scratch = tab + TAB_FLOATS;
@@ -695,20 +701,38 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
   // drain factor stores (vmcnt retires in issue order, and the compiler's waits in front of loaded values are vmcnt(0)).
   XRegs xr;
   if (half != 0) x_issue(m.x, clip, d.B, T, L.lane, xr);
+  // the loss weights (= ph::loss_coefs_n, its loads taken out: behind the barrier they were one more memory round trip)
+  const bool any_gl = gl.p[0] || gl.p[1] || gl.p[2];
+  const float gl_u0 = gl.p[0] ? *gl.p[0] : 0.f, gl_u1 = gl.p[1] ? *gl.p[1] : 0.f, gl_u2 = gl.p[2] ? *gl.p[2] : 0.f;
+  // The weight image arrives in two parts: layers 0 .. 4 (32 KB) before the loop, layer 5 (52 KB, two thirds of the burst) while the
+  // first clip's layers 0 .. 4 run. The late pieces are issued LAST in the prologue, from an asm statement: hipcc tracks an LDS-DMA
+  // builtin as a pending write to ALL of LDS and puts s_waitcnt vmcnt(0) in front of the next ds_read, whatever it reads. Nothing
+  // between their issue and the first layer-5 forward waits on the vector-memory counter (the first clip's targets are loaded
+  // and pinned in front of them, the loss coefficients are worked out in front of them, factor stores are never waited for);
+  // the wait + workgroup barrier in front of that layer is explicit.
   {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(m.w_image), 0, S::w_total() * 4, 0x00020000);
     const unsigned base = (unsigned)(uintptr_t)(lds_void_ptr)img;
-    constexpr int total4 = S::w_total() >> 2;
 #pragma unroll
-    for (int i = 0; i < (IMG_CHUNKS + SW - 1) / SW; ++i) {
+    for (int i = 0; i < (IMG_CHUNKS_EARLY + SW - 1) / SW; ++i) {
       const int ck = wave + i * SW;                                  // (wave-uniform)
-      if (ck < IMG_CHUNKS && ck * 64 + L.lane < total4)              // the last piece is partial: its tail lanes stay out
+      if (ck < IMG_CHUNKS_EARLY)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)(uintptr_t)(base + ck * 1024), 16, (ck * 64 + L.lane) * 16, 0, 0, 0);
     }
   }
-  for (int i = threadIdx.x; i < TAB_FLOATS; i += 64 * SW) tab[i] = i < TAB_ROT ? d.ref_rel_loc[i] : d.ref_rel_rot[i - TAB_ROT];
-  if (blockIdx.x == 0 && (int)threadIdx.x < m.n_counters) m.counters[threadIdx.x] = 0;   // arrival tickets of train_wgrad_kernel
-  if (threadIdx.x < SW) reinterpret_cast<int *>(scratch + 8)[threadIdx.x] = 0;            // the waves' rendezvous counters
+  // every load of the prologue is issued before the first one is waited for: ONE memory round trip (a table entry stored to LDS,
+  // a count added, a target address formed from a loaded value -- each is a round trip of its own when it sits between the issues)
+  PoseIn pin;                                      // targets of the pair's CURRENT clip (the next clip's are requested during the dgrad)
+  pin.st = 0;
+  pose_inputs(d, n_iter > 0 ? (int)clip : 0, lane0, half, pin);
+  constexpr int TAB_ROUNDS = (TAB_FLOATS + 64 * SW - 1) / (64 * SW);
+  float tabv[TAB_ROUNDS];
+#pragma unroll
+  for (int u = 0; u < TAB_ROUNDS; ++u) {
+    const int i = (int)threadIdx.x + u * 64 * SW, ic = i < TAB_FLOATS ? i : 0;
+    const float *src = ic < TAB_ROT ? d.ref_rel_loc + ic : d.ref_rel_rot + (ic - TAB_ROT);
+    tabv[u] = *src;
+  }
   {
     float cnt = 0.f;                               // small integers held in floats: exact in any order
     for (int i0 = 0; i0 < d.B; i0 += 8 * 64 * SW) {   // eight loads in flight per thread (a dependent add per load is a round trip each)
@@ -724,14 +748,50 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
     cnt = ph::wave_sum(cnt);
     if (L.lane == 0) scratch[wave] = cnt;
   }
+#pragma unroll
+  for (int u = 0; u < TAB_ROUNDS; ++u) {
+    const int i = (int)threadIdx.x + u * 64 * SW;
+    if (i < TAB_FLOATS) tab[i] = tabv[u];
+  }
+  if (blockIdx.x == 0 && (int)threadIdx.x < m.n_counters) m.counters[threadIdx.x] = 0;   // arrival tickets of train_wgrad_kernel
+  if (threadIdx.x < SW) reinterpret_cast<int *>(scratch + 8)[threadIdx.x] = 0;            // the waves' rendezvous counters
   if (half != 0) x_commit(xr, x_offsets(L.lane), Y, L.lane);       // H_0 of the pair's first clip
+  ST(40);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  pose_inputs_landed(pin);
   __syncthreads();
+  ST(41);
   float coef2 = 0.f, coef3 = 0.f;
   {
     float n2 = 0.f;
     for (int w = 0; w < SW; ++w) n2 += scratch[w];
-    ph::loss_coefs_n(d, gl, n2, ph::n3_elems(d), coef2, coef3);
+    const float n3 = ph::n3_elems(d), g2 = gl_u0 + gl_u2, g3 = gl_u1 + gl_u2;
+    if (any_gl) {
+      coef2 = (d.gt2d && n2 > 0.f) ? g2 / n2 : 0.f;
+      coef3 = (d.gt3d && n3 > 0.f) ? 2.f * g3 / n3 : 0.f;
+    }
+  }
+  ST(42);
+  // whatever the prologue loaded has landed, and hipcc knows (the builtin is a real s_waitcnt to its wait-count pass, an asm string
+  // is not): a load left pending on some path would come back as a vmcnt(0) in front of the loop's first ds_read
+  __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+  {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const uintptr_t wi = reinterpret_cast<uintptr_t>(m.w_image);
+    i32x4 rs;                                      // = the resource above: base, no stride, bytes, raw 32-bit data format
+    rs.x = __builtin_amdgcn_readfirstlane((int)(uint32_t)wi), rs.y = __builtin_amdgcn_readfirstlane((int)((wi >> 32) & 0xffffu));
+    rs.z = S::w_total() * 4, rs.w = 0x00020000;
+    const unsigned base = (unsigned)(uintptr_t)(lds_void_ptr)img;
+    constexpr int total4 = S::w_total() >> 2;
+#pragma unroll
+    for (int i = 0; i < (IMG_CHUNKS - IMG_CHUNKS_EARLY + SW - 1) / SW; ++i) {
+      const int ck = IMG_CHUNKS_EARLY + wave + i * SW;               // (wave-uniform)
+      if (ck < IMG_CHUNKS && ck * 64 + L.lane < total4) {            // the last piece is partial: its tail lanes stay out
+        const unsigned dst = __builtin_amdgcn_readfirstlane(base + ck * 1024);
+        const int voff = (ck * 64 + L.lane) * 16;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(dst), "v"(voff), "s"(rs) : "memory");
+      }
+    }
   }
 
   ST(1);
@@ -747,9 +807,6 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
     const bool active = true;
     float *fdst = m.factors + (size_t)((active && !(P2C_STREAM_EXPERIMENT & 8)) ? clip : blockIdx.x * PAIRS + pair) * F_ROWS * 16;
     uint64_t mask = 0;
-    PoseIn pin;
-    pin.st = 0;
-    if (active) pose_inputs(d, (int)clip, lane0, half, pin);
     const bool mlp = active && !(P2C_STREAM_EXPERIMENT & 2);
     {
       // ---- LinearAE forward, the pair's two wavefronts side by side (one barrier per layer); every H_l leaves for the factor
@@ -764,7 +821,6 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       if (mlp) {
         half_read(Y, L.lane, half, h0);
         fwd_layer<0>(L, role, img, Y, A, mask);
-        pose_inputs_landed(pin);                   // (in front of the first factor store: the wait covers loads only)
         half_store(h0, fdst + f_h_off(0) * 16, L.lane, half);
       }
       ps.sync();     
@@ -801,6 +857,10 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
       }
       ps.sync();     
       ST(8);
+      if (it == 0) {                               // layer 5's part of the image: every wave's pieces have landed (once per kernel)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       HalfRows<S::dims(5)> h5;
       if (mlp) {
         half_read(A, L.lane, half, h5);
@@ -822,12 +882,18 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
 #if P2C_STREAM_PRIO
       __builtin_amdgcn_s_setprio(P2C_STREAM_PRIO);
 #endif
-      if (half != 0) x_issue(m.x, clip + stride, d.B, T, L.lane, xr);   // the pair's next clip: lands behind the first dgrad layer
+      // the pair's next clip: its x tile and targets are requested here and pinned behind the first dgrad layer -- the one point of
+      // the loop where this wave's vector-memory queue holds nothing recent (vmcnt retires in issue order: a load waited for behind
+      // factor stores waits for all of them)
+      if (half != 0) x_issue(m.x, clip + stride, d.B, T, L.lane, xr);
+      pose_inputs(d, (int)(clip + stride < d.B ? clip + stride : clip), lane0, half, pin);
       // ---- dgrad chain, side by side; every G_l leaves as soon as it exists ----------------------------------------------------------
       HalfRows<S::dims(6)> g6;
       if (mlp) {
         half_read(Y, L.lane, half, g6);
         dgrad_layer<5>(L, role, img, Y, A, mask);
+        pose_inputs_landed(pin);
+        if (half != 0) x_landed(xr);
         half_store(g6, fdst + f_g_off(6) * 16, L.lane, half);
       }
       ps.sync();                                    // ---- grad_y^T has been read: the y rows are free for the next clip's H_0 ----
@@ -873,6 +939,10 @@ __global__ __launch_bounds__(64 * SW) void train_stream_kernel(const p2c_pose_he
     }
     ps.sync();                                      // ---- the next clip's H_0 is in place, buffer A has been read ----
     ST(63);
+  }
+  if (n_iter == 0) {                               // (a pair without a clip: the workgroup's second barrier counts every wave)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
 }
 

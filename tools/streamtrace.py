@@ -28,9 +28,9 @@ names = {1: 'prologue', 2: 'loop top', 3: 'target loads issued', 4: 'fwd L0 + st
          33: 'G6 store + dgrad L5 + sync', 34: 'dgrad L4 + x commit', 35: 'dgrad L3', 36: 'dgrad L2', 37: 'dgrad L1 + G1 store', 63: 'sync (end)'}
 cyc, wall = t[63] - t[0], (t[61] - t[62]) * 10.0
 print(f'B={B}: kernel (wave 0) {cyc} cycles, {wall:.0f} ns, {cyc / max(wall, 1):.2f} GHz; last clip {t[63] - t[2]} cycles')
-order = sorted((v, i) for i, v in enumerate(t[:61]) if v >= t[2] and i > 2) + [(t[63], 63)]
+order = sorted((v, i) for i, v in enumerate(t[:61]) if v >= t[2] and i > 2 and i < 40) + [(t[63], 63)]
 prev = t[2]
 for v, i in order:
     print(f'   [{i:2d}] +{v - prev:6d}  {names.get(i, "")}')
     prev = v
-print(f'   prologue {t[1] - t[0]} cycles')
+print(f'   prologue {t[1] - t[0]} cycles: loads issued +{t[40] - t[0]}, landed + barrier +{t[41] - t[40]}, coefficients +{t[42] - t[41]}, late pieces issued +{t[1] - t[42]}')
