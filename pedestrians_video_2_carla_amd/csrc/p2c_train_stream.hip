@@ -492,8 +492,11 @@ __device__ __forceinline__ void pose_phase(const p2c_pose_head_desc &d, const bo
         }
       }
       // inclusive scan over the wave's eight frames (the four bones of a round travel together)
+      ST(43);
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
+        if (r == 1) ST(44);
+        if (r == 2) ST(45);
         M3 Q[NS];
 #pragma unroll
         for (int k = 0; k < NS; ++k)

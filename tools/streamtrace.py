@@ -25,10 +25,10 @@ t = list(buf)
 names = {1: 'prologue', 2: 'loop top', 3: 'target loads issued', 4: 'fwd L0 + store + sync', 5: 'fwd L1', 6: 'fwd L2', 7: 'fwd L3', 8: 'fwd L4',
          9: 'fwd L5', 20: 'sync (y complete)', 21: 'read y, 6D -> R, tables', 22: 'prefix scan', 23: 'hand-over 1', 24: 'R, FK',
          25: 'head4', 26: 'subtree, torque', 27: 'suffix scan, loss sums', 28: 'hand-over 2 + pull-back + write', 32: 'sync (grad_y complete)',
-         33: 'G6 store + dgrad L5 + sync', 34: 'dgrad L4 + x commit', 35: 'dgrad L3', 36: 'dgrad L2', 37: 'dgrad L1 + G1 store', 63: 'sync (end)'}
+         33: 'G6 store + dgrad L5 + sync', 34: 'dgrad L4 + x commit', 35: 'dgrad L3', 36: 'dgrad L2', 37: 'dgrad L1 + G1 store', 43: 'change[0] x reference', 44: 'scan round 0', 45: 'scan round 1', 63: 'sync (end)'}
 cyc, wall = t[63] - t[0], (t[61] - t[62]) * 10.0
 print(f'B={B}: kernel (wave 0) {cyc} cycles, {wall:.0f} ns, {cyc / max(wall, 1):.2f} GHz; last clip {t[63] - t[2]} cycles')
-order = sorted((v, i) for i, v in enumerate(t[:61]) if v >= t[2] and i > 2 and i < 40) + [(t[63], 63)]
+order = sorted((v, i) for i, v in enumerate(t[:61]) if v >= t[2] and i > 2 and (i < 40 or 43 <= i <= 50)) + [(t[63], 63)]
 prev = t[2]
 for v, i in order:
     print(f'   [{i:2d}] +{v - prev:6d}  {names.get(i, "")}')
