@@ -21,6 +21,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/step_b1024_stats" 
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD --output-format csv -d "$OUT/pmc_stream_b8192_SQ_INSTS" -- python3 tools/prof_step.py 8192 10 > "$OUT/pmc_stream_INSTS.log" 2>&1 || exit 1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_stream_b8192_SQ_CYCLES" -- python3 tools/prof_step.py 8192 10 > "$OUT/pmc_stream_CYCLES.log" 2>&1 || exit 1
 echo "step pmc done"
+# ONLY_STEP=1: the fused train step's kernels changed, the pose-head / GEMM / cfg3 / cfg5 kernels did not (their summaries and
+# traffic stamps stay valid)
+if [ -n "$ONLY_STEP" ]; then echo "all done (step only)"; exit 0; fi
 for B in 256 1024 8192 16384 65536; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/pmc_head_b${B}_$C" -- python3 tools/prof_kernels.py $B 5 > "$OUT/pmc_head_${B}_$C.log" 2>&1 || exit 1
