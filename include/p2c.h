@@ -266,10 +266,10 @@ P2C_API int p2c_train_step(const p2c_train_step_desc *desc, const float *const g
  * step), 3: both (= p2c_train_step). bench.py times the launches one by one with it. */
 P2C_API int p2c_train_step_launch(const p2c_train_step_desc *desc, const float *const grad_losses[3], int32_t which,
                                   void *stream);
-/* The first launch has two forms: one workgroup of eight wavefronts per clip (latency form, about one clip per CU) and one
- * wavefront per clip with the weight image shared by four (throughput form, csrc/p2c_train_stream.hip), taken from min_b clips
- * on when the descriptor allows it (identity joint maps, CARLA targets, no world motion). Returns the previous threshold;
- * min_b < 0 only queries. Default 768 (env P2C_STREAM_MIN_B). Both leave the same factor blocks for the second launch. */
+/* The first launch has two forms: one workgroup of eight wavefronts per clip (latency form, up to one clip per CU) and a
+ * pair of wavefronts per clip, four pairs sharing a workgroup's weight image (throughput form, csrc/p2c_train_stream.hip), taken
+ * from min_b clips on when the descriptor allows it (identity joint maps, CARLA targets, no world motion). Returns the previous threshold;
+ * min_b < 0 only queries. Default 257 = more than one clip per CU (env P2C_STREAM_MIN_B). Both leave the same factor blocks for the second launch. */
 P2C_API int p2c_train_step_set_stream_min_batch(int32_t min_b);
 /* The second launch has two forms as well: a workgroup per dW tile and clip slice with the combine, the optimizer and the loss
  * reduction in the same launch (few hundred clips), and -- from min_b clips on (default 3072, env P2C_WGRAD_STREAM_MIN_B) -- a

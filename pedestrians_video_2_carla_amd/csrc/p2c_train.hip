@@ -890,7 +890,8 @@ static int g_stream_min_b = -1;
 static int stream_min_b() {
   if (g_stream_min_b < 0) {
     const char *e = getenv("P2C_STREAM_MIN_B");
-    g_stream_min_b = e ? atoi(e) : 768;       // measured (tools/step_sweep.py): 512 clips 47 vs 44 us, 1024 clips 55 vs 76 us
+    g_stream_min_b = e ? atoi(e) : 257;       // measured (tools/step_sweep.py, whole step): 320 clips 35.5 vs 42.1 us, 512: 37.7 vs 45.8,
+                                              // 768: 47.6 vs 60.1, 1024: 52.7 vs 76.0 -- past one clip per CU the pair form wins at once
   }
   return g_stream_min_b;
 }

@@ -979,9 +979,11 @@ int p2c_internal_train_stream_launch(const p2c_pose_head_desc &d, const p2c::Gra
     (void)hipFuncSetAttribute((const void *)train_stream_kernel<P2C_KIND_RELATIVE_ROT_6D>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_done = true;
   }
+  // every CU gets a workgroup as soon as there are 256 clips: pair p of workgroup b walks clips b + grid (p + 4 i), so with fewer
+  // than four clips per CU the later pairs of every workgroup stay idle (B = 512: two pairs per CU, one per SIMD pair, instead of
+  // four pairs on half the CUs)
   constexpr int kCUs = 256;
-  const int want = (d.B + PAIRS - 1) / PAIRS;
-  const dim3 grid((unsigned)(want < kCUs ? want : kCUs));
+  const dim3 grid((unsigned)(d.B < kCUs ? d.B : kCUs));
   const size_t lds_bytes = (size_t)LDS_FLOATS * sizeof(float);
   if (d.kind == P2C_KIND_POSE_CHANGES_6D)
     hipLaunchKernelGGL(train_stream_kernel<P2C_KIND_POSE_CHANGES_6D>, grid, dim3(64 * SW), lds_bytes, stream, d, gl, m);
