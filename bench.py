@@ -351,7 +351,7 @@ STEP_FLOPS_PER_CLIP = 2.0 * (17212 + 33072) * T_FRAMES      # LinearAE forward +
 STEP_BYTES_PER_CLIP = 4 * T_FRAMES * JOINTS * (2 + 2 + 3) + 4   # frames + both targets in, nothing out but three scalars
 
 
-def step_sweep(device, sizes=(256, 1024, 8192, 65536)):
+def step_sweep(device, sizes=(256, 512, 1024, 8192, 65536)):
     """The whole train step (trainer.train_step on a resident batch: LinearAE pose_changes, loc_2d_3d, fp32, AdamW in the step) at
     several batch sizes: ms per step from three blocks of wall-clocked steps (min), clips/s, the fraction of the fp32-MFMA peak
     (1.61 MFLOP per clip) and of the HBM peak (11 652 B per clip) that rate corresponds to, and the step's launches, each timed
