@@ -336,6 +336,13 @@ typedef struct p2c_lstm_desc {
   const float *bias_a, *bias_b; /* (4H) or NULL: fwd adds them to gx as it reads it (b_ih, b_hh), so the projection GEMM runs bias-free */
   float *g_gx_bt;               /* (B,T,4H) or NULL: bwd writes a second, batch-first copy of g_gx (pairs with a batch-first layer input) */
   int32_t gx_bt;                /* fwd: gx is laid out (B,T,4H) -- the projection of a batch-first input, no permute copy */
+  /* nn.LSTM's inter-layer dropout on this layer's output, drawn inside the kernels (drop_state != NULL; the protocol of the four
+   * words: p2c_decoder_desc): fwd writes out_drop (T,B,H) = out * mask beside the raw `out` (fwd without out_drop draws nothing),
+   * bwd takes g_out as the gradient of out_drop. */
+  float *out_drop;
+  int32_t *drop_state;
+  float drop_p;
+  int32_t drop_site;
 } p2c_lstm_desc;
 P2C_API int p2c_lstm_rec_fwd(const p2c_lstm_desc *desc, void *stream);
 P2C_API int p2c_lstm_rec_bwd(const p2c_lstm_desc *desc, void *stream);
@@ -377,6 +384,13 @@ typedef struct p2c_decoder_desc {
    * frame t of clip b -- the stored output AND the next step's input -- is target[t][b]; its rows of d out_total are zero (the
    * reference writes the targets into the output tensor itself: those rows carry neither loss nor gradient). */
   const float *force, *target;
+  /* the dropout mask drawn inside the kernels instead of read from `drop` (drop == NULL, drop_state != NULL): keep(e) =
+   * hash(seed, step, site, element e of the (T,B,H) mask) >= drop_p 2^32, mask = keep / (1 - drop_p). drop_state: 4 int32 words
+   * on the device {seed_lo, seed_hi, step, next}; fwd reads step and leaves next = step + 1, bwd reads next - 1 and leaves
+   * step = next, so the two launches of a step draw the same mask and a replayed graph advances by itself. */
+  int32_t *drop_state;
+  float drop_p;
+  int32_t drop_site;
 } p2c_decoder_desc;
 P2C_API int p2c_decoder_fwd(const p2c_decoder_desc *desc, void *stream);
 P2C_API int p2c_decoder_bwd(const p2c_decoder_desc *desc, void *stream);

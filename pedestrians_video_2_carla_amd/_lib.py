@@ -80,7 +80,8 @@ class LstmDesc(ctypes.Structure):
     _fields_ = [('T', ctypes.c_int32), ('B', ctypes.c_int32), ('H', ctypes.c_int32), ('gx', _f32p), ('h0', _f32p),
                 ('c0', _f32p), ('w_hh', _f32p), ('out', _f32p), ('hT', _f32p), ('cT', _f32p), ('acts', _f32p),
                 ('cs', _f32p), ('g_out', _f32p), ('g_hT', _f32p), ('g_cT', _f32p), ('g_gx', _f32p), ('g_h0', _f32p),
-                ('g_c0', _f32p), ('bias_a', _f32p), ('bias_b', _f32p), ('g_gx_bt', _f32p), ('gx_bt', ctypes.c_int32)]
+                ('g_c0', _f32p), ('bias_a', _f32p), ('bias_b', _f32p), ('g_gx_bt', _f32p), ('gx_bt', ctypes.c_int32),
+                ('out_drop', _f32p), ('drop_state', ctypes.c_void_p), ('drop_p', ctypes.c_float), ('drop_site', ctypes.c_int32)]
 
 
 class DecoderDesc(ctypes.Structure):
@@ -89,7 +90,8 @@ class DecoderDesc(ctypes.Structure):
         (n, _f32p) for n in ('k0', 'c0', 'k1', 'c1', 'w_ih0', 'w_ih1', 'w_fc', 'b_fc', 'x0', 'drop', 'out', 'acts0', 'acts1',
                              'h0d', 'h1', 'g_out', 'g_gates0', 'g_gates1', 'g_outtot', 'g_c0', 'g_c1',
                              'hid0', 'hid1', 'w_hh0', 'w_hh1', 'b0a', 'b0b', 'b1a', 'b1b', 'kw0', 'kw1', 'out_bt',
-                             'g_k0', 'g_k1', 'g_hid0', 'g_hid1')] + [('g_out_bt', ctypes.c_int32), ('force', _f32p), ('target', _f32p)]
+                             'g_k0', 'g_k1', 'g_hid0', 'g_hid1')] + [('g_out_bt', ctypes.c_int32), ('force', _f32p), ('target', _f32p),
+                                                     ('drop_state', ctypes.c_void_p), ('drop_p', ctypes.c_float), ('drop_site', ctypes.c_int32)]
 
 
 class AtbProblem(ctypes.Structure):

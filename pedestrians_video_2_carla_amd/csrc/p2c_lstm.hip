@@ -41,6 +41,10 @@ struct Args {
   const float *bias_a, *bias_b;   // (4H) or NULL: added to gx as it is read (b_ih, b_hh: the projection GEMM then runs bias-free)
   float *g_gx_bt;       // (B, T, 4H) or NULL: second copy of g_gx, batch-first (pairs with a batch-first layer input)
   int32_t T, B, H, gx_bt;         // gx_bt: gx is laid out (B, T, 4H)
+  // inter-layer dropout on this layer's output, drawn in the kernels (p2c_rec_dev.h): fwd also writes out_drop = out * mask (the
+  // next layer's input; `out` stays the raw h the weight gradients need), bwd takes g_out as the gradient of out_drop
+  float *out_drop;      // (T, B, H) or NULL
+  DropRng rng;
 };
 
 __device__ __forceinline__ f32x4 load4(const float *p, bool ok) {
@@ -91,6 +95,9 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
   const bool ok = b < a.B;
   const int u0 = w * 16 + 4 * g;                  // first of this lane's four hidden units
   const int B = a.B, T = a.T;
+  DropRng rng = a.rng;
+  const bool hashed = rng.state != nullptr && a.out_drop != nullptr;
+  if (hashed) drop_begin(rng, false), drop_end(rng, false);
   const int off4 = (b * 4 * H + u0) * 4, off1 = (b * H + u0) * 4;   // byte offsets inside one step's rows
 
   float frag[4][KS];                              // A fragments: gate q, rows 16w + (lane & 15), k = 4 ks + g
@@ -125,6 +132,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
     for (int q = 0; q < 4; ++q) nxt[q] = bload4(rg, offx + q * H * 4);
   }
   __syncthreads();
+  if (hashed) drop_keys(rng);
 #pragma unroll
   for (int q = 0; q < 4; ++q) pin(nxt[q]);        // resident on entry: the loop header then carries no pending loads
   int cur = 0;
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
       bstore4(ra, off4, ai), bstore4(ra, off4 + H * 4, af), bstore4(ra, off4 + 2 * H * 4, ag), bstore4(ra, off4 + 3 * H * 4, ao);
       bstore4(rc, off1, cst);
       bstore4(ro, off1, h);
+      if (hashed) bstore4(step_rows(a.out_drop, t, B, H), off1, h * drop_value4(rng, (uint32_t)((t * B + b) * H + u0)));
     }
     lds_barrier();
     cur ^= 1;
@@ -196,6 +205,9 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
   const bool ok = b < a.B;
   const int u0 = w * 16 + 4 * g;
   const int B = a.B, T = a.T;
+  DropRng rng = a.rng;
+  const bool hashed = rng.state != nullptr;
+  if (hashed) drop_begin(rng, true), drop_end(rng, true);
   const int off4 = (b * 4 * H + u0) * 4, off1 = (b * H + u0) * 4;
 
   float frag[KS];                                 // A fragments of W_hh^T: rows = units 16w + (lane & 15), k = gate row 4 ks + g
@@ -207,18 +219,20 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
       if (4 * ks / Chunks<H>::ROWS == ch) frag[ks] = dyn_lds[(4 * ks + g - ch * Chunks<H>::ROWS) * (H + 1) + w * 16 + c];
   }
   __syncthreads();                                // the staging image is dead: its space becomes the d-gates buffers
+  if (hashed) drop_keys(rng);
 
   f32x4 dh = a.g_hT ? load4(a.g_hT + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 dc = a.g_cT ? load4(a.g_cT + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
   // The saved rows of step t - 1 are requested at the top of step t and pinned at its end: their latency hides behind the
   // whole step (cell math + 64 MFMAs).
-  struct Saved { f32x4 ai, af, ag, ao, cp, go; };
+  struct Saved { f32x4 ai, af, ag, ao, cp, go, m; };
   auto fetch = [&](int t, Saved &s) {             // t >= 0
     const __amdgpu_buffer_rsrc_t ra = step_rows(a.acts, t, B, 4 * H), rg = step_rows(a.g_out, t, B, H);
     const __amdgpu_buffer_rsrc_t rc = (t > 0) ? step_rows(a.cs, t - 1, B, H) : step_rows(a.c0, 0, B, H);
     s.ai = bload4(ra, off4), s.af = bload4(ra, off4 + H * 4), s.ag = bload4(ra, off4 + 2 * H * 4), s.ao = bload4(ra, off4 + 3 * H * 4);
     s.cp = bload4(rc, off1);
     s.go = bload4(rg, off1);
+    s.m = hashed ? drop_value4(rng, (uint32_t)((t * B + b) * H + u0)) : (f32x4){1.f, 1.f, 1.f, 1.f};   // (applied where go is used: a product here would wait for the load)
   };
   Saved nx = {};
   f32x4 ct = {0.f, 0.f, 0.f, 0.f};
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
   pin(nx.ai), pin(nx.af), pin(nx.ag), pin(nx.ao), pin(nx.cp), pin(nx.go), pin(ct);
   int cur = 0;
   for (int t = T - 1; t >= 0; --t) {
-    const f32x4 ai = nx.ai, af = nx.af, ag = nx.ag, ao = nx.ao, cp = nx.cp, go = nx.go;
+    const f32x4 ai = nx.ai, af = nx.af, ag = nx.ag, ao = nx.ao, cp = nx.cp, go = nx.go * nx.m;
     fetch(t > 0 ? t - 1 : 0, nx);                  // (the last step re-reads its own rows: no branch in the body)
     f32x4 pi, pf, pg, po;                          // gradients of the pre-activation gates
 #pragma unroll
@@ -300,6 +314,9 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_narrow_kernel(cons
   const int b = blockIdx.x * NS + s;              // this lane's sequence (its MFMA column)
   const bool ok = b < a.B;
   const int B = a.B, T = a.T;
+  DropRng rng = a.rng;
+  const bool hashed = rng.state != nullptr && a.out_drop != nullptr;
+  if (hashed) drop_begin(rng, false), drop_end(rng, false);
   const int offg = (b * 4 * H + u) * 4, offh = (b * H + u) * 4;   // byte offsets inside one step's rows
 
   float frag[H];                                  // A operand: row (lane & 3) = gate, of this lane's block = unit; k = 0..H-1
@@ -325,6 +342,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_narrow_kernel(cons
     for (int q = 0; q < 4; ++q) nxt[q] = bload1(rg, offx + q * H * 4);
   }
   __syncthreads();
+  if (hashed) drop_keys(rng);
   pin(nxt);
   int cur = 0;
   float hlast = 0.f;
@@ -355,6 +373,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_narrow_kernel(cons
       bstore1(ra, offg, ai), bstore1(ra, offg + H * 4, af), bstore1(ra, offg + 2 * H * 4, ag), bstore1(ra, offg + 3 * H * 4, ao);
       bstore1(rc, offh, cst);
       bstore1(ro, offh, h);
+      if (hashed) bstore1(step_rows(a.out_drop, t, B, H), offh, h * drop_value(rng, (uint32_t)((t * B + b) * H + u)));
     }
     lds_barrier();
     cur ^= 1;
@@ -387,6 +406,9 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(cons
   const int b = blockIdx.x * NS + s;
   const bool ok = b < a.B;
   const int B = a.B, T = a.T;
+  DropRng rng = a.rng;
+  const bool hashed = rng.state != nullptr;
+  if (hashed) drop_begin(rng, true), drop_end(rng, true);
   const int offg = (b * 4 * H + u) * 4, offh = (b * H + u) * 4;
 
   float frag[H];                                  // A operand: row (lane & 3) -> unit 16w + 4ug + (lane & 3); k -> gate row q H + k
@@ -402,7 +424,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(cons
 
   float dh = (a.g_hT && ok) ? a.g_hT[(size_t)b * H + u] : 0.f;
   float dc = (a.g_cT && ok) ? a.g_cT[(size_t)b * H + u] : 0.f;
-  struct Saved { f32x4 act; float cp, go; };
+  struct Saved { f32x4 act; float cp, go, m; };
   auto fetch = [&](int t, Saved &sv) {
     const __amdgpu_buffer_rsrc_t ra = step_rows(a.acts, t, B, 4 * H), rg = step_rows(a.g_out, t, B, H);
     const __amdgpu_buffer_rsrc_t rc = (t > 0) ? step_rows(a.cs, t - 1, B, H) : step_rows(a.c0, 0, B, H);
@@ -410,7 +432,9 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(cons
     for (int j = 0; j < 4; ++j) sv.act[j] = bload1(ra, offg + j * H * 4);
     sv.cp = bload1(rc, offh);
     sv.go = bload1(rg, offh);
+    sv.m = hashed ? drop_value(rng, (uint32_t)((t * B + b) * H + u)) : 1.f;
   };
+  if (hashed) drop_keys(rng);                     // (behind the W_hh staging above)
   Saved nx = {};
   float ct = 0.f;
   if (T > 0) {
@@ -422,7 +446,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(cons
   asm volatile("" : "+v"(nx.cp), "+v"(nx.go), "+v"(ct));
   int cur = 0;
   for (int t = T - 1; t >= 0; --t) {
-    const float ai = nx.act[0], af = nx.act[1], ag = nx.act[2], ao = nx.act[3], cp = nx.cp, go = nx.go;
+    const float ai = nx.act[0], af = nx.act[1], ag = nx.act[2], ao = nx.act[3], cp = nx.cp, go = nx.go * nx.m;
     fetch(t > 0 ? t - 1 : 0, nx);
     const float dht = go + dh;
     const float tc = tanhf_(ct);
@@ -479,6 +503,12 @@ static int check(const p2c_lstm_desc *d, Args &a) {
   a.g_h0 = d->g_h0, a.g_c0 = d->g_c0, a.T = d->T, a.B = d->B, a.H = d->H;
   a.bias_a = d->bias_a, a.bias_b = d->bias_b, a.g_gx_bt = d->g_gx_bt, a.gx_bt = d->gx_bt;
   if ((a.gx_bt || a.g_gx_bt) && (int64_t)a.B * a.T * 4 * a.H * 4 >= (int64_t)1 << 31) return P2C_E_SHAPE;
+  if (d->drop_state) {
+    if (!(d->drop_p >= 0.f && d->drop_p < 1.f)) return P2C_E_SHAPE;
+    a.out_drop = d->out_drop;
+    a.rng.state = d->drop_state, a.rng.site = d->drop_site, a.rng.scale = 1.f / (1.f - d->drop_p);
+    a.rng.thresh = (uint32_t)((double)d->drop_p * 4294967296.0);
+  }
   return 0;
 }
 

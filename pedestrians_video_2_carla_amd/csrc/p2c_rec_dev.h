@@ -51,6 +51,52 @@ __device__ __forceinline__ void bstore1(__amdgpu_buffer_rsrc_t r, int byte_off, 
 }
 constexpr int OOB = 0x7fffff00;          // a byte offset no descriptor of these kernels reaches (host: records < 2^30)
 
+// ---- dropout masks drawn INSIDE the time-loop kernels (nn.LSTM's inter-layer dropout, seq2seq.py:36-58 / 110-115) -------------------
+// mask(e) = keep(e) / (1 - p), keep(e) = hash(seed, step, site, e) >= p 2^32 for element e of the (T, B, H) tensor: a stateless
+// function of the element index, so the forward and the backward of a step draw the SAME mask without a mask tensor, a
+// generator launch or the framework's RNG-state fills. `state` (device, 4 x int32, owned by the module that owns the dropout
+// site): {seed_lo, seed_hi, step, next}. The forward reads `step` and leaves next = step + 1; the backward reads next - 1 and
+// leaves step = next -- no kernel reads a word another workgroup of the same launch may have rewritten, and a replayed HIP
+// graph advances the stream by itself. (A training-mode forward WITHOUT a backward draws the same masks again next time.)
+struct DropRng {
+  int32_t *state;        // NULL: no hashed mask
+  uint32_t thresh;       // p 2^32
+  float scale;           // 1 / (1 - p)
+  int32_t site;          // distinguishes the dropout sites that share a state
+  uint32_t k0, k1;       // per-launch keys (drop_begin: the raw seed words; drop_keys: the keys)
+  uint32_t thresh_step;  // the step the launch draws for (drop_begin)
+};
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {      // "lowbias32" integer finaliser: full avalanche
+  x ^= x >> 16, x *= 0x7feb352du;
+  x ^= x >> 15, x *= 0x846ca68bu;
+  x ^= x >> 16;
+  return x;
+}
+// Two halves: the three state words are REQUESTED at the top of a kernel (drop_begin) and turned into the launch's keys behind its
+// weight staging (drop_keys) -- a memory round trip in front of the first time step otherwise.
+__device__ __forceinline__ void drop_begin(DropRng &r, const bool backward) {
+  if (!r.state) return;
+  r.k0 = (uint32_t)r.state[0], r.k1 = (uint32_t)r.state[1];
+  r.thresh_step = backward ? (uint32_t)r.state[3] - 1u : (uint32_t)r.state[2];
+}
+__device__ __forceinline__ void drop_keys(DropRng &r) {
+  if (!r.state) return;
+  const uint32_t s0 = r.k0, s1 = r.k1, step = r.thresh_step;
+  r.k0 = mix32(s0 ^ (step * 0x9E3779B9u));
+  r.k1 = mix32(s1 + step + 0x85EBCA6Bu * (uint32_t)(r.site + 1));
+}
+__device__ __forceinline__ void drop_end(const DropRng &r, const bool backward) {      // one thread of the launch
+  if (!r.state || blockIdx.x != 0 || threadIdx.x != 0) return;
+  if (backward) r.state[2] = r.state[3];
+  else r.state[3] = r.state[2] + 1;
+}
+__device__ __forceinline__ float drop_value(const DropRng &r, const uint32_t e) {
+  return mix32(mix32(e + r.k0) ^ r.k1) >= r.thresh ? r.scale : 0.f;
+}
+__device__ __forceinline__ f32x4 drop_value4(const DropRng &r, const uint32_t e) {
+  return (f32x4){drop_value(r, e), drop_value(r, e + 1), drop_value(r, e + 2), drop_value(r, e + 3)};
+}
+
 // Values loaded one step ahead are pinned (made resident) BEFORE the step's stores are issued: the wait the compiler
 // inserts for them then covers the loads only -- placed after the stores, vmcnt would also count the stores' round trip.
 __device__ __forceinline__ void pin(f32x4 &v) { asm volatile("" : "+v"(v)); }

@@ -34,6 +34,7 @@ struct Args {
   const float *w_ih0, *w_ih1, *w_fc, *b_fc;   // (4H,O), (4H,H), (O,H), (O)
   const float *x0;                       // (B,O) or NULL = zeros (<sos>)
   const float *drop;                     // (T,B,H) multiplicative dropout mask on the layer-0 output, or NULL
+  DropRng rng;                           // ... or drawn here (rng.state != NULL; `drop` wins when both are given)
   float *out;                            // (T,B,O)
   float *acts0, *acts1, *h0d, *h1;       // saved for the backward: (T,B,4H) x2, (T,B,H) x2
   const float *g_out;                    // (T,B,O)
@@ -117,6 +118,9 @@ __device__ __forceinline__ void store_gates(__amdgpu_buffer_rsrc_t rs, int off4,
 // a compile-time bound keeps the k-loop free of the uniform guards that cut the MFMA stream into 4-instruction blocks.
 template <int KS0>
 __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
+  DropRng rng = a.rng;                              // (its state words are requested here, behind nothing; the keys are formed behind the staging)
+  const bool hashed = !a.drop && rng.state != nullptr;
+  if (hashed) drop_begin(rng, false), drop_end(rng, false);
   extern __shared__ float img[];                    // staging image of one weight matrix at a time
   __shared__ float xT[OMAX * TP], h0T[H * TP], h1T[H * TP];
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -164,15 +168,20 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) xT[(u0 + r) * TP + c] = (a.x0 && ok && u0 + r < O) ? a.x0[(size_t)b * O + u0 + r] : 0.f;
   }
-  f32x4 mask = bload4(step_rows(a.drop, 0, B, H), off1);
+  if (hashed) drop_keys(rng);
+  // this step's dropout mask: a row of the caller's mask tensor, or drawn from the element index (t, b, unit)
+  auto mask_of = [&](const int t) -> f32x4 {
+    return hashed ? drop_value4(rng, (uint32_t)((t * B + b) * H + u0)) : bload4(step_rows(a.drop, t, B, H), off1);
+  };
+  f32x4 mask = mask_of(0);
   __syncthreads();
   pin(mask);
-  const bool has_drop = a.drop != nullptr;
+  const bool has_drop = a.drop != nullptr || hashed;
 
   for (int t = 0; t < T; ++t) {
     f32x4 acc[4], ai, af, ag, ao, h;
     const f32x4 m = mask;                            // this step's dropout mask was requested one step ahead
-    mask = bload4(step_rows(a.drop, (t + 1 < T) ? t + 1 : t, B, H), off1);
+    mask = mask_of((t + 1 < T) ? t + 1 : t);
     // teacher forcing: flag and target features of this step, requested now, used behind the fc product (NULL: zeros)
     const float forced = bload1(step_rows(a.force, t, B, 1), b * 4);
     f32x4 tgt;
@@ -236,6 +245,9 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
 // ---- backward ----------------------------------------------------------------------------------------------------------
 template <int KS0>
 __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
+  DropRng rng = a.rng;                              // (its state words are requested here, behind nothing; the keys are formed behind the staging)
+  const bool hashed = !a.drop && rng.state != nullptr;
+  if (hashed) drop_begin(rng, true), drop_end(rng, true);
   extern __shared__ float img[];
   __shared__ float doT[OMAX * TP], dg1T[G4 * TP], dg0T[G4 * TP];
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -269,7 +281,8 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
     offo[r] = (u0 + r < O) ? (b * O + u0 + r) * 4 : OOB;
     offi[r] = (u0 + r < O) ? ((a.g_out_bt ? b * T * O : b * O) + u0 + r) * 4 : OOB;
   }
-  const bool has_drop = a.drop != nullptr;
+  if (hashed) drop_keys(rng);
+  const bool has_drop = a.drop != nullptr || hashed;
 
   // The rows a step reads (loss gradient, saved gates of both layers, dropout mask) are requested at the top of the previous
   // step and pinned at its end (a round trip to rows of a fresh 8 MB tensor measured longer than one 64-MFMA chain):
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
     for (int r = 0; r < 4; ++r) s.go[r] = bload1(rg, offi[r]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) s.a1[q] = bload4(r1, off4 + q * H * 4), s.a0[q] = bload4(r0, off4 + q * H * 4);
-    s.m = bload4(step_rows(a.drop, t, B, H), off1);
+    s.m = hashed ? drop_value4(rng, (uint32_t)((t * B + b) * H + u0)) : bload4(step_rows(a.drop, t, B, H), off1);
   };
   auto pin_all = [&](Saved &s) {
     pin(s.go), pin(s.m);
@@ -419,6 +432,9 @@ __device__ __forceinline__ f32x4 load_gates1(__amdgpu_buffer_rsrc_t rs, int offg
 
 template <int KS0>
 __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
+  DropRng rng = a.rng;                              // (its state words are requested here, behind nothing; the keys are formed behind the staging)
+  const bool hashed = !a.drop && rng.state != nullptr;
+  if (hashed) drop_begin(rng, false), drop_end(rng, false);
   constexpr int K0 = 4 * KS0;
   extern __shared__ float img[];                    // staging image of one weight matrix at a time
   __shared__ __attribute__((aligned(16))) float xs[NS][OP], h0s[NS][HP], h1s[NS][HP];
@@ -472,14 +488,18 @@ __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
   const float c0r = ok ? a.c0[(size_t)b * H + u] : 0.f, c1r = ok ? a.c1[(size_t)b * H + u] : 0.f;
   const float bfc = (u < O) ? a.b_fc[u] : 0.f;
   xs[s][u] = (a.x0 && ok && u < O) ? a.x0[(size_t)b * O + u] : 0.f;    // features >= O stay zero
-  float mask = bload1(step_rows(a.drop, 0, B, H), offh);
+  if (hashed) drop_keys(rng);
+  auto mask_of = [&](const int t) -> float {
+    return hashed ? drop_value(rng, (uint32_t)((t * B + b) * H + u)) : bload1(step_rows(a.drop, t, B, H), offh);
+  };
+  float mask = mask_of(0);
   __syncthreads();
   asm volatile("" : "+v"(mask));
-  const bool has_drop = a.drop != nullptr;
+  const bool has_drop = a.drop != nullptr || hashed;
 
   for (int t = 0; t < T; ++t) {
     const float m = mask;
-    mask = bload1(step_rows(a.drop, (t + 1 < T) ? t + 1 : t, B, H), offh);
+    mask = mask_of((t + 1 < T) ? t + 1 : t);
     const float forced = bload1(step_rows(a.force, t, B, 1), b * 4);     // teacher forcing (NULL tensors read as zero)
     const float tgt = bload1(step_rows(a.target, t, B, O), offo);
     f32x4 act;
@@ -510,6 +530,9 @@ __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
 
 template <int KS0>
 __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
+  DropRng rng = a.rng;                              // (its state words are requested here, behind nothing; the keys are formed behind the staging)
+  const bool hashed = !a.drop && rng.state != nullptr;
+  if (hashed) drop_begin(rng, true), drop_end(rng, true);
   extern __shared__ float img[];
   __shared__ __attribute__((aligned(16))) float dos[NS][OP], dg1s[NS][GP], dg0s[NS][GP];
   const int lane = threadIdx.x & 63, s = lane & 3, blk = lane >> 2, q = blk & 3;
@@ -536,7 +559,8 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
   const float c0r = ok ? a.c0[(size_t)b * H + u] : 0.f, c1r = ok ? a.c1[(size_t)b * H + u] : 0.f;
   float dc0 = 0.f, dc1 = 0.f, dx = 0.f;
   f32x4 dk0 = zero4(), dk1 = zero4();                // sum_t d gates_l = the gradient of k_l
-  const bool has_drop = a.drop != nullptr;
+  if (hashed) drop_keys(rng);
+  const bool has_drop = a.drop != nullptr || hashed;
 
   struct Saved { f32x4 a1, a0; float go, m, forced; };
   auto fetch = [&](int t, Saved &sv) {
@@ -544,7 +568,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
     sv.go = bload1(a.g_out_bt ? bt_rows(a.g_out, t, B, T, O) : step_rows(a.g_out, t, B, O), offi);
     sv.a1 = load_gates1(step_rows(a.acts1, t, B, G4), offg);
     sv.a0 = load_gates1(step_rows(a.acts0, t, B, G4), offg);
-    sv.m = bload1(step_rows(a.drop, t, B, H), offh);
+    sv.m = hashed ? drop_value(rng, (uint32_t)((t * B + b) * H + u)) : bload1(step_rows(a.drop, t, B, H), offh);
   };
   auto pin_all = [&](Saved &sv) {
     pin(sv.a1), pin(sv.a0);
@@ -655,6 +679,11 @@ static int fill(Args &a, const p2c_decoder_desc *d) {
   a.g_hid0 = d->g_hid0, a.g_hid1 = d->g_hid1, a.g_out_bt = d->g_out_bt;
   if ((d->force != nullptr) != (d->target != nullptr)) return P2C_E_NULL;
   a.force = d->force, a.target = d->target;
+  if (d->drop_state) {
+    if (!(d->drop_p >= 0.f && d->drop_p < 1.f)) return P2C_E_SHAPE;
+    a.rng.state = d->drop_state, a.rng.site = d->drop_site, a.rng.scale = 1.f / (1.f - d->drop_p);
+    a.rng.thresh = (uint32_t)((double)d->drop_p * 4294967296.0);
+  }
   return 0;
 }
 

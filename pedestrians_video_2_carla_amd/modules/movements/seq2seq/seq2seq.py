@@ -219,7 +219,8 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         if (type(self)._format_input is Seq2Seq._format_input and isinstance(rnn, nn.LSTM) and _fused_ok(rnn, x)
                 and ops.encoder_stack_supported(rnn, x, self.invert_sequence)):
             # the 2-layer encoder over the batch-first rows as one explicit launch sequence (ops.EncoderStackFunction)
-            return ops.encoder_stack(x.reshape(*x.shape[:2], self.encoder.input_size), rnn)
+            return ops.encoder_stack(x.reshape(*x.shape[:2], self.encoder.input_size), rnn,
+                                     drop_state=self._kernel_drop_state(x.device) if (rnn.dropout > 0 and rnn.training) else None)
         return self.encoder(self._format_input(x))
 
     def _decoder_loop_fusable(self, x: Tensor) -> bool:
@@ -228,6 +229,17 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         return (_fused_ok(rnn, x) and rnn.bias and not rnn.bidirectional and isinstance(self.decoder.fc_out, nn.Linear)
                 and ops.decoder_loop_supported(rnn.hidden_size, rnn.num_layers, self.decoder.output_size))
 
+    def _kernel_drop_state(self, device) -> Tensor:
+        """The state of this model's in-kernel dropout streams (ops.dropout_state; site 0 = encoder, 1 = decoder), or None when
+        the framework's dropout is asked for (P2C_TORCH_DROPOUT=1)."""
+        from pedestrians_video_2_carla_amd import ops
+        if not ops.kernel_dropout_enabled():
+            return None
+        st = getattr(self, '_drop_state', None)
+        if st is None or st.device != device:
+            st = self._drop_state = ops.dropout_state(device)
+        return st
+
     def _fused_decoder(self, hidden: Tensor, cell: Tensor, clip_length: int, force_idx: Tensor = None,
                        forced: Tensor = None) -> Tensor:
         from pedestrians_video_2_carla_amd import ops
@@ -235,7 +247,10 @@ class Seq2Seq(MovementsModelOutputTypeMixin, MovementsModel):
         # (the decoder state is the encoder's for every frame: its recurrent terms k_l = b_ih_l + b_hh_l + W_hh_l hidden_l are
         # per-clip constants, formed inside the launch)
         drop = None
-        if rnn.dropout > 0 and rnn.training:      # nn.LSTM's inter-layer dropout, one mask tensor for all frames:
+        state = self._kernel_drop_state(hidden.device) if (rnn.dropout > 0 and rnn.training) else None
+        if state is not None:                      # nn.LSTM's inter-layer dropout, its mask drawn inside the decoder kernels
+            drop = (state, float(rnn.dropout), 1)
+        elif rnn.dropout > 0 and rnn.training:     # ... or one mask tensor for all frames from the framework's generator:
             shape = (clip_length, hidden.shape[1], rnn.hidden_size)       # dropout(ones) = mask / keep in ONE launch
             ones = getattr(self, '_drop_ones', None)
             if ones is None or ones.shape != shape or ones.device != hidden.device or ones.dtype != hidden.dtype:

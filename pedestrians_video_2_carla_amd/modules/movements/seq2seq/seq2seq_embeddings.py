@@ -120,7 +120,8 @@ class Seq2SeqEmbeddings(Seq2Seq):
             b_eff = (w_ih * bias.unsqueeze(0)).sum((1, 2)) + rnn.bias_ih_l0 + rnn.bias_hh_l0
         from pedestrians_video_2_carla_amd import ops
         if ops.encoder_stack_supported(rnn, x, self.invert_sequence):             # batch-first rows, one explicit launch sequence
-            return ops.encoder_stack(x.reshape(B, T, -1), rnn, input_map=(w_eff, b_eff))
+            return ops.encoder_stack(x.reshape(B, T, -1), rnn, input_map=(w_eff, b_eff),
+                                     drop_state=self._kernel_drop_state(x.device) if (rnn.dropout > 0 and rnn.training) else None)
         seq = x.permute(1, 0, 2, 3).reshape(T, B, -1)                             # sequence first, raw keypoints
         if self.invert_sequence:
             seq = seq.flip(0)

@@ -4,6 +4,8 @@ PyTorch is plumbing here (device memory, streams, autograd graph); the arithmeti
 No CPU path: host tensors raise.
 """
 import ctypes
+import os
+import weakref
 from dataclasses import dataclass, field
 from typing import Dict, Optional, Sequence, Tuple
 
@@ -947,6 +949,48 @@ def joint_embeddings(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tens
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# dropout masks drawn inside the time-loop kernels (csrc/p2c_rec_dev.h)
+# ----------------------------------------------------------------------------------------------------------------------
+_DROP_INSTANCES = 0
+
+
+def dropout_state(device) -> Tensor:
+    """Four int32 words {seed_lo, seed_hi, step, next} for the kernels that draw their dropout masks themselves. The seed comes
+    from ``torch.initial_seed()`` (what ``torch.manual_seed`` / ``seed_everything`` set), the rank of the process and a
+    per-state counter -- reproducible under a fixed seed, different per rank and per module, and nothing is drawn from the
+    framework's generators (no generator launch, no RNG-state fill in front of a replayed graph)."""
+    global _DROP_INSTANCES
+    _DROP_INSTANCES += 1
+    rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+    seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + _DROP_INSTANCES * 0x94D049BB133111EB) % (1 << 64)
+    lo, hi = seed & 0x7FFFFFFF, (seed >> 32) & 0x7FFFFFFF
+    st = torch.tensor([lo, hi, 0, 0], dtype=torch.int32, device=device)
+    _DROP_STATES.append(weakref.ref(st))
+    return st
+
+
+_DROP_STATES = []
+
+
+def dropout_states_snapshot() -> list:
+    """(state, copy) of every live in-kernel dropout state: what has to be put back for a step to draw the same masks again
+    (the trainer's capture-time replay check compares an eager step with replays of the captured one)."""
+    live = [r() for r in _DROP_STATES]
+    _DROP_STATES[:] = [weakref.ref(t) for t in live if t is not None]
+    return [(t, t.clone()) for t in live if t is not None]
+
+
+def dropout_states_restore(snapshot: list) -> None:
+    for t, saved in snapshot:
+        t.copy_(saved)
+
+
+def kernel_dropout_enabled() -> bool:
+    """P2C_TORCH_DROPOUT=1: the framework's dropout (one generator launch per site + RNG-state fills per replay) instead."""
+    return os.environ.get('P2C_TORCH_DROPOUT', '0') != '1'
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # LSTM layer: library GEMM for the input projection + one HIP launch for the recurrence (K7b)
 # ----------------------------------------------------------------------------------------------------------------------
 def lstm_supported(hidden_size: int) -> bool:
@@ -1403,7 +1447,8 @@ class DecoderStackFunction(torch.autograd.Function):
                  'bias_ih_l1', 'bias_hh_l1', 'fc_out.weight', 'fc_out.bias')
         hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc = (
             _require_device(t, n) for t, n in zip((hidden, cell, w_ih0, w_hh0, b_ih0, b_hh0, w_ih1, w_hh1, b_ih1, b_hh1, w_fc, b_fc), names))
-        drop = None if drop is None else _require_device(drop, 'dropout mask')
+        hashed = drop if isinstance(drop, tuple) else None         # (state, p, site): the mask is drawn inside the kernels
+        drop = None if (drop is None or hashed is not None) else _require_device(drop, 'dropout mask')
         L, B, H = hidden.shape
         O = w_fc.shape[0]
         G = 4 * H
@@ -1423,6 +1468,9 @@ class DecoderStackFunction(torch.autograd.Function):
         if kw is not None:
             d.kw0, d.kw1 = kw[0].data_ptr(), kw[1].data_ptr()
         d.drop = _ptr(drop)
+        if hashed is not None:
+            d.drop_state, d.drop_p, d.drop_site = hashed[0].data_ptr(), float(hashed[1]), int(hashed[2])
+        ctx.hashed = hashed
         if force is not None:            # teacher forcing: (T,B) 0 / 1 flags and the (T,B,O) target frames
             force = _require_device(force, 'force flags').contiguous()
             target = _require_device(target, 'forced targets').contiguous()
@@ -1454,6 +1502,8 @@ class DecoderStackFunction(torch.autograd.Function):
         d.w_ih0, d.w_ih1, d.w_fc, d.b_fc = w_ih0.data_ptr(), w_ih1.data_ptr(), w_fc.data_ptr(), b_fc.data_ptr()
         d.w_hh0, d.w_hh1 = w_hh0.data_ptr(), w_hh1.data_ptr()
         d.drop = _ptr(drop)
+        if ctx.hashed is not None:
+            d.drop_state, d.drop_p, d.drop_site = ctx.hashed[0].data_ptr(), float(ctx.hashed[1]), int(ctx.hashed[2])
         d.acts0, d.acts1, d.h0d, d.h1 = acts0.data_ptr(), acts1.data_ptr(), h0d.data_ptr(), h1.data_ptr()
         d.g_out, d.g_out_bt = g_out_bt.data_ptr(), 1
         if force is not None:
@@ -1521,7 +1571,7 @@ class EncoderStackFunction(torch.autograd.Function):
     weight-gradient launch pairs less."""
 
     @staticmethod
-    def forward(ctx, x, w_in, b_in_a, b_in_b, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1, p_drop: float, train: bool):
+    def forward(ctx, x, w_in, b_in_a, b_in_b, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1, p_drop: float, train: bool, drop_state=None):
         lib = _lib.lib()
         ctx.set_materialize_grads(False)
         x = _require_device(x, 'x')
@@ -1541,24 +1591,31 @@ class EncoderStackFunction(torch.autograd.Function):
         acts0, acts1 = torch.empty(T, B, G, **f32), torch.empty(T, B, G, **f32)
         cs0, cs1 = torch.empty(T, B, H, **f32), torch.empty(T, B, H, **f32)
 
-        def rec(gx, gx_bt, ba, bb, w_hh, out, acts, cs, k):
+        hashed = bool(train and p_drop > 0 and drop_state is not None)      # the inter-layer mask is drawn inside the recurrence
+
+        def rec(gx, gx_bt, ba, bb, w_hh, out, acts, cs, k, out_drop=None):
             d = _lib.LstmDesc()
             d.T, d.B, d.H, d.gx_bt = T, B, H, int(gx_bt)
             d.gx, d.w_hh, d.bias_a, d.bias_b = gx.data_ptr(), w_hh.data_ptr(), _ptr(ba), _ptr(bb)
             d.out, d.hT, d.cT, d.acts, d.cs = out.data_ptr(), hidden[k].data_ptr(), cell[k].data_ptr(), acts.data_ptr(), cs.data_ptr()
+            if out_drop is not None:
+                d.out_drop, d.drop_state, d.drop_p, d.drop_site = out_drop.data_ptr(), drop_state.data_ptr(), float(p_drop), 0
             _lib.check(lib.p2c_lstm_rec_fwd(ctypes.byref(d), _stream()), 'p2c_lstm_rec_fwd')
 
         with torch.cuda.device(x.device):
             gx0 = gemm(x.view(B * T, I), w_in, True)                       # (B,T,4H) rows, bias-free (K16)
-            rec(gx0, True, b_in_a, b_in_b, w_hh0, out0, acts0, cs0, 0)
             mask = None
             x1 = out0
-            if train and p_drop > 0:
+            if hashed:
+                x1 = torch.empty(T, B, H, **f32)
+            rec(gx0, True, b_in_a, b_in_b, w_hh0, out0, acts0, cs0, 0, x1 if hashed else None)
+            if train and p_drop > 0 and not hashed:
                 x1, mask = torch.native_dropout(out0, p_drop, True)
             gx1 = gemm(x1.view(T * B, H), w_ih1, True)
             rec(gx1, False, b_ih1, b_hh1, w_hh1, out1, acts1, cs1, 1)
         ctx.save_for_backward(x, w_in, b_in_a, b_in_b, w_hh0, w_ih1, w_hh1, b_ih1, b_hh1, out0, x1, mask, out1, acts0, cs0, acts1, cs1)
         ctx.p_drop = p_drop
+        ctx.drop_state = drop_state if hashed else None
         return hidden, cell
 
     @staticmethod
@@ -1578,6 +1635,8 @@ class EncoderStackFunction(torch.autograd.Function):
             d.T, d.B, d.H = T, B, H
             d.w_hh, d.acts, d.cs = w_hh.data_ptr(), acts.data_ptr(), cs.data_ptr()
             d.g_out = _ptr(g_out)
+            if k == 0 and ctx.drop_state is not None:                     # g_out is the gradient of the DROPPED output
+                d.drop_state, d.drop_p, d.drop_site = ctx.drop_state.data_ptr(), float(ctx.p_drop), 0
             d.g_hT = None if g_hidden is None else g_hidden[k].data_ptr()
             d.g_cT = None if g_cell is None else g_cell[k].data_ptr()
             d.g_gx, d.g_gx_bt = g_gx.data_ptr(), _ptr(g_gx_bt)
@@ -1617,19 +1676,20 @@ class EncoderStackFunction(torch.autograd.Function):
             g['w_in'] = res[3][0]
             g['b_in_a'] = res[3][1] if b_in_a is not None else None
             g['b_in_b'] = res[3][1] if (b_in_a is not None and b_in_b is not None) else None
-        return (None, g['w_in'], g['b_in_a'], g['b_in_b'], g['w_hh0'], g['w_ih1'], g['w_hh1'], g['b_ih1'], g['b_hh1'], None, None)
+        return (None, g['w_in'], g['b_in_a'], g['b_in_b'], g['w_hh0'], g['w_ih1'], g['w_hh1'], g['b_ih1'], g['b_hh1'], None, None, None)
 
 
-def encoder_stack(x: Tensor, rnn, input_map=None) -> Tuple[Tensor, Tensor]:
+def encoder_stack(x: Tensor, rnn, input_map=None, drop_state: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """(hidden, cell) (2,B,H) of the 2-layer ``nn.LSTM`` ``rnn`` run from the zero state over the batch-first x (B,T,I).
-    ``input_map`` = (weight (4H,I), bias (4H)) replaces layer 0's (weight_ih_l0, bias_ih_l0 + bias_hh_l0)."""
+    ``input_map`` = (weight (4H,I), bias (4H)) replaces layer 0's (weight_ih_l0, bias_ih_l0 + bias_hh_l0). ``drop_state``
+    (``dropout_state``): the inter-layer dropout mask is drawn inside the recurrence kernels (site 0 of that state)."""
     _prefer_rocblas_once()
     if input_map is not None:
         w_in, b_a, b_b = input_map[0], input_map[1], None
     else:
         w_in, b_a, b_b = rnn.weight_ih_l0, rnn.bias_ih_l0, rnn.bias_hh_l0
     return EncoderStackFunction.apply(x, w_in, b_a, b_b, rnn.weight_hh_l0, rnn.weight_ih_l1, rnn.weight_hh_l1,
-                                      rnn.bias_ih_l1, rnn.bias_hh_l1, float(rnn.dropout), bool(rnn.training))
+                                      rnn.bias_ih_l1, rnn.bias_hh_l1, float(rnn.dropout), bool(rnn.training), drop_state)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

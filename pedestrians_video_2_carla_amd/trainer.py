@@ -467,7 +467,7 @@ class Trainer:
         NOT compared with an eager step here; ``ranks_agree`` only establishes that every rank holds the same bits.)
         Capture-time check: the new graph is replayed twice -- other tensors allocated, written and freed before each replay --
         and its parameter update compared with the same step issued eagerly from the same parameters and random-number state
-        (a captured step draws the same philox offsets as the eager one; the build's kernels give the same bits either way:
+        (a captured step draws the same philox offsets as the eager one, and the in-kernel dropout streams are put back; the build's kernels give the same bits either way:
         measured difference exactly 0 for cfg2 / cfg3 / cfg5 with dropout and stochastic depth on). A step that reads memory the
         graph does not own, or captured a stale address, shows up here; the trainer then goes back to eager steps and says so.
         NOT caught here: on this stack (PyTorch 2.10 / ROCm 7.0) a captured backward with one of the framework's multi-block
@@ -480,6 +480,8 @@ class Trainer:
             return
         dev = state.device
         rng = torch.cuda.get_rng_state(dev)
+        from pedestrians_video_2_carla_amd import ops
+        drop = ops.dropout_states_snapshot()                 # the masks drawn inside kernels: the same stream position each time
         before = state.clone()
         # ground truth: the same step issued eagerly on the static batch, from the same parameters and random-number state (a
         # captured step draws the same philox offsets as the eager one when it starts from the same generator state)
@@ -489,6 +491,7 @@ class Trainer:
         torch.cuda.synchronize(dev)
         want = state - before
         self._restore(flow, snapshot)
+        ops.dropout_states_restore(drop)
         updates = []
         for attempt in range(2):
             # what a training loop does between two steps: other tensors come and go (and leave their values behind)
@@ -499,6 +502,7 @@ class Trainer:
             torch.cuda.synchronize(dev)
             updates.append(state - before)
             self._restore(flow, snapshot)
+            ops.dropout_states_restore(drop)
         torch.cuda.set_rng_state(rng, dev)
         scale = float(want.abs().max())
         diff = max(float((u - want).abs().max()) for u in updates)

@@ -390,6 +390,139 @@ def test_encoder_stack_inter_layer_dropout():
     assert abs(fd.item() - (g * direction).sum().item()) <= 2e-2 * max(1.0, abs(fd.item()))
 
 
+def _hash_mask(state, site, p, shape):
+    """numpy restatement of csrc/p2c_rec_dev.h (drop_begin / drop_value) for the FORWARD of the step `state` is at."""
+    import numpy as np
+    M = 0xFFFFFFFF
+
+    def mix(x):
+        x = x.astype(np.uint64)
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x7feb352d)) & np.uint64(M)
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846ca68b)) & np.uint64(M)
+        x ^= x >> np.uint64(16)
+        return x
+    s0, s1, step = (int(v) & M for v in state[:3])
+    k0 = int(mix(np.array([s0 ^ ((step * 0x9E3779B9) & M)], dtype=np.uint64))[0])
+    k1 = int(mix(np.array([(s1 + step + 0x85EBCA6B * (site + 1)) & M], dtype=np.uint64))[0])
+    n = 1
+    for v in shape:
+        n *= v
+    e = np.arange(n, dtype=np.uint64)
+    h = mix(mix((e + np.uint64(k0)) & np.uint64(M)) ^ np.uint64(k1))
+    keep = h >= np.uint64(int(p * 4294967296.0))
+    return torch.from_numpy((keep.astype(np.float32) * np.float32(1.0 / (1.0 - p))).reshape(shape))
+
+
+@pytest.mark.parametrize('T,B,H', [(16, 37, 64), (5, 130, 32), (9, 21, 128)])
+def test_dropout_drawn_inside_the_recurrence(T, B, H):
+    """p2c_lstm_desc.out_drop / drop_state: the forward writes out * mask beside the raw output, mask = the documented hash of
+    (seed, step, site, element) -- restated in numpy -- on both tilings; it leaves state = {.., step, step + 1}; the backward
+    takes g_out as the gradient of the dropped output (= the plain backward fed g_out * mask) and leaves
+    {.., step + 1, step + 1}; the keep rate is 1 - p."""
+    import ctypes
+    from pedestrians_video_2_carla_amd import _lib, ops
+    d = dev()
+    lib = _lib.lib()
+    p, site = 0.2, 3
+    g = torch.Generator(device=d).manual_seed(T + B + H)
+    gx, w_hh = torch.randn(T, B, 4 * H, device=d, generator=g) * 0.5, torch.randn(4 * H, H, device=d, generator=g) * 0.2
+    g_out = torch.randn(T, B, H, device=d, generator=g)
+    state = ops.dropout_state(d)
+    state[2:] = torch.tensor([7, 0], dtype=torch.int32)
+    before = state.cpu().tolist()
+    f = dict(dtype=torch.float32, device=d)
+    out, out_drop, acts, cs = torch.empty(T, B, H, **f), torch.empty(T, B, H, **f), torch.empty(T, B, 4 * H, **f), torch.empty(T, B, H, **f)
+
+    def desc(hashed):
+        q = _lib.LstmDesc()
+        q.T, q.B, q.H = T, B, H
+        q.gx, q.w_hh, q.out, q.acts, q.cs = gx.data_ptr(), w_hh.data_ptr(), out.data_ptr(), acts.data_ptr(), cs.data_ptr()
+        if hashed:
+            q.out_drop, q.drop_state, q.drop_p, q.drop_site = out_drop.data_ptr(), state.data_ptr(), p, site
+        return q
+    _lib.check(lib.p2c_lstm_rec_fwd(ctypes.byref(desc(True)), ops._stream()), 'fwd')
+    torch.cuda.synchronize()
+    assert state.cpu().tolist() == before[:3] + [8]
+    mask = _hash_mask(before, site, p, (T, B, H)).to(d)
+    assert torch.equal(out_drop, out * mask)
+    assert abs(float((mask > 0).float().mean()) - (1 - p)) < 4 * (p * (1 - p) / mask.numel()) ** 0.5
+    g_plain, g_hash = torch.empty(T, B, 4 * H, **f), torch.empty(T, B, 4 * H, **f)
+    q = desc(False)
+    fed = g_out * mask
+    q.g_out, q.g_gx = fed.data_ptr(), g_plain.data_ptr()
+    _lib.check(lib.p2c_lstm_rec_bwd(ctypes.byref(q), ops._stream()), 'bwd')
+    q = desc(True)
+    q.g_out, q.g_gx = g_out.data_ptr(), g_hash.data_ptr()
+    _lib.check(lib.p2c_lstm_rec_bwd(ctypes.byref(q), ops._stream()), 'bwd')
+    torch.cuda.synchronize()
+    close(g_hash, g_plain, 'd gates', rtol=1e-6)           # (the kernel's g_out * mask may contract into the next fma)
+    assert state.cpu().tolist() == before[:2] + [8, 8]
+
+
+@pytest.mark.parametrize('T,B,O', [(16, 37, 52), (5, 130, 12)])
+def test_decoder_dropout_drawn_inside_the_kernels(T, B, O):
+    """ops.decoder_stack with drop = (state, p, site): output and every gradient equal, bit for bit, the run that READS the same
+    mask as a tensor (the numpy restatement of the hash), on both tilings; two steps in a row draw different masks."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    H, p, site = 64, 0.2, 1
+    torch.manual_seed(T * 3 + B)
+    dec, fc = torch.nn.LSTM(O, H, num_layers=2).to(d), torch.nn.Linear(H, O).to(d)
+    hidden0, cell0 = torch.randn(2, B, H, device=d) * 0.3, torch.randn(2, B, H, device=d) * 0.3
+    up = torch.randn(B, T, O, device=d)
+    state = ops.dropout_state(d)
+    start = state.cpu().tolist()
+
+    def run(drop):
+        for q in list(dec.parameters()) + list(fc.parameters()):
+            q.grad = None
+        hidden, cell = hidden0.clone().requires_grad_(True), cell0.clone().requires_grad_(True)
+        out = ops.decoder_stack(hidden, cell, dec, fc, T, drop)
+        (out * up).sum().backward()
+        return [out.detach().clone(), hidden.grad.clone(), cell.grad.clone()] + [q.grad.clone() for q in list(dec.parameters()) + list(fc.parameters())]
+    got = run((state, p, site))
+    torch.cuda.synchronize()
+    assert state.cpu().tolist() == start[:2] + [1, 1]
+    want = run(_hash_mask(start, site, p, (T, B, H)).to(d))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), i
+    again = run((state, p, site))                          # the next step of the stream: another mask
+    assert not torch.equal(again[0], got[0])
+    want2 = run(_hash_mask(start[:2] + [1, 1], site, p, (T, B, H)).to(d))
+    assert torch.equal(again[0], want2[0])
+
+
+@pytest.mark.parametrize('T,B,I,H', [(16, 37, 52, 64), (7, 19, 20, 32)])
+def test_encoder_stack_with_dropout_drawn_inside_the_recurrence(T, B, I, H):
+    """ops.encoder_stack(drop_state=...): final states and all parameter gradients against torch.nn.LSTM layers in fp64 with the
+    SAME inter-layer mask (the numpy restatement of the hash, site 0), 1e-4."""
+    from pedestrians_video_2_carla_amd import ops
+    d = dev()
+    p = 0.2
+    torch.manual_seed(T + B + I)
+    rnn = torch.nn.LSTM(I, H, num_layers=2, dropout=p, batch_first=True).to(d).train()
+    x = torch.randn(B, T, I, device=d)
+    up_h, up_c = torch.randn(2, B, H, device=d), torch.randn(2, B, H, device=d)
+    state = ops.dropout_state(d)
+    start = state.cpu().tolist()
+    hidden, cell = ops.encoder_stack(x, rnn, drop_state=state)
+    ((hidden * up_h).sum() + (cell * up_c).sum()).backward()
+    mask = _hash_mask(start, 0, p, (T, B, H)).double()
+    l0, l1 = torch.nn.LSTM(I, H).double(), torch.nn.LSTM(H, H).double()
+    sd = {k: v.detach().double().cpu() for k, v in rnn.state_dict().items()}
+    l0.load_state_dict({k[:-1] + '0': sd[k] for k in sd if k.endswith('_l0')})
+    l1.load_state_dict({k[:-1] + '0': sd[k] for k in sd if k.endswith('_l1')})
+    o0, (h0, c0) = l0(x.double().cpu().transpose(0, 1))
+    o1, (h1, c1) = l1(o0 * mask)
+    ((torch.stack([h0[0], h1[0]]) * up_h.double().cpu()).sum() + (torch.stack([c0[0], c1[0]]) * up_c.double().cpu()).sum()).backward()
+    close(hidden, torch.stack([h0[0], h1[0]]), 'hidden'), close(cell, torch.stack([c0[0], c1[0]]), 'cell')
+    for name, q in rnn.named_parameters():
+        ref = (l0 if name.endswith('_l0') else l1)
+        close(q.grad, getattr(ref, name[:-1] + '0').grad, 'grad ' + name, rtol=5e-4)
+
+
 def test_atb_group_equals_the_single_launches():
     """p2c_atb_group: five problems of different shapes (strided rows, bias, second bias destination, accumulate) behind one
     launch pair give bit for bit what p2c_atb gives one by one."""
