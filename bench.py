@@ -654,9 +654,10 @@ def extra_config(device, name, steps=100, warmup=10):
         out['roofline'] = [mfma_entry(k, B, rt[k], fl) for k, fl in rflops.items()]
         out['note'] = ('the time-loop launches are latency chains (one to three workgroup barriers per time step); at B <= 4096 they '
                        'run 4 sequences per workgroup on v_mfma_f32_4x4x1_16B (128 workgroups at B = 512), above that 16 on '
-                       'v_mfma_f32_16x16x4. The step is 24 launches: fold, 2 projection GEMMs + 1 input-gradient GEMM (K16: no '
-                       'library GEMM in the step), 2 + 2 encoder recurrences, dropout, decoder fwd / bwd with the frame-invariant '
-                       'terms inside, 2 grouped weight-gradient pairs, loss, AdamW')
+                       'v_mfma_f32_16x16x4. The step is 19 launches: fold, 2 projection GEMMs + 1 input-gradient GEMM (K16: no '
+                       'library GEMM in the step), 2 + 2 encoder recurrences, decoder fwd / bwd with the frame-invariant terms '
+                       'inside, 2 grouped weight-gradient pairs, loss, AdamW; the inter-layer dropout masks are drawn inside the '
+                       'time-loop kernels (no generator launch, no RNG-state fill in front of a replay)')
     return out
 
 

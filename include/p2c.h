@@ -385,7 +385,7 @@ typedef struct p2c_decoder_desc {
    * reference writes the targets into the output tensor itself: those rows carry neither loss nor gradient). */
   const float *force, *target;
   /* the dropout mask drawn inside the kernels instead of read from `drop` (drop == NULL, drop_state != NULL): keep(e) =
-   * hash(seed, step, site, element e of the (T,B,H) mask) >= drop_p 2^32, mask = keep / (1 - drop_p). drop_state: 4 int32 words
+   * hash(seed, step, site, element e of the (T,B,H) mask) >= drop_p 2^32 (csrc/p2c_rec_dev.h: drop_value), mask = keep / (1 - drop_p). drop_state: 4 int32 words
    * on the device {seed_lo, seed_hi, step, next}; fwd reads step and leaves next = step + 1, bwd reads next - 1 and leaves
    * step = next, so the two launches of a step draw the same mask and a replayed graph advances by itself. */
   int32_t *drop_state;

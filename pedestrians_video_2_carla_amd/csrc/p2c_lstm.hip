@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
   const int B = a.B, T = a.T;
   DropRng rng = a.rng;
   const bool hashed = rng.state != nullptr && a.out_drop != nullptr;
-  if (hashed) drop_begin(rng, false), drop_end(rng, false);
+  if (hashed) drop_begin(rng, false);
   const int off4 = (b * 4 * H + u0) * 4, off1 = (b * H + u0) * 4;   // byte offsets inside one step's rows
 
   float frag[4][KS];                              // A fragments: gate q, rows 16w + (lane & 15), k = 4 ks + g
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
     for (int q = 0; q < 4; ++q) nxt[q] = bload4(rg, offx + q * H * 4);
   }
   __syncthreads();
-  if (hashed) drop_keys(rng);
+  if (hashed) drop_keys(rng, false);
 #pragma unroll
   for (int q = 0; q < 4; ++q) pin(nxt[q]);        // resident on entry: the loop header then carries no pending loads
   int cur = 0;
@@ -182,7 +182,12 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_kernel(const Args 
       bstore4(ra, off4, ai), bstore4(ra, off4 + H * 4, af), bstore4(ra, off4 + 2 * H * 4, ag), bstore4(ra, off4 + 3 * H * 4, ao);
       bstore4(rc, off1, cst);
       bstore4(ro, off1, h);
-      if (hashed) bstore4(step_rows(a.out_drop, t, B, H), off1, h * drop_value4(rng, (uint32_t)((t * B + b) * H + u0)));
+      {   // (the store in either case -- a NULL tensor has no records -- and ALU only under the branch: a store under a branch makes
+          // every counted wait behind the merge a full drain)
+        f32x4 m = {1.f, 1.f, 1.f, 1.f};
+        if (hashed) m = drop_value4(rng, (uint32_t)((t * B + b) * H + u0));
+        bstore4(step_rows(a.out_drop, t, B, H), off1, h * m);
+      }
     }
     lds_barrier();
     cur ^= 1;
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
   const int B = a.B, T = a.T;
   DropRng rng = a.rng;
   const bool hashed = rng.state != nullptr;
-  if (hashed) drop_begin(rng, true), drop_end(rng, true);
+  if (hashed) drop_begin(rng, true);
   const int off4 = (b * 4 * H + u0) * 4, off1 = (b * H + u0) * 4;
 
   float frag[KS];                                 // A fragments of W_hh^T: rows = units 16w + (lane & 15), k = gate row 4 ks + g
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
       if (4 * ks / Chunks<H>::ROWS == ch) frag[ks] = dyn_lds[(4 * ks + g - ch * Chunks<H>::ROWS) * (H + 1) + w * 16 + c];
   }
   __syncthreads();                                // the staging image is dead: its space becomes the d-gates buffers
-  if (hashed) drop_keys(rng);
+  if (hashed) drop_keys(rng, true);
 
   f32x4 dh = a.g_hT ? load4(a.g_hT + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 dc = a.g_cT ? load4(a.g_cT + (size_t)b * H + u0, ok) : (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -232,7 +237,8 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_kernel(const Args 
     s.ai = bload4(ra, off4), s.af = bload4(ra, off4 + H * 4), s.ag = bload4(ra, off4 + 2 * H * 4), s.ao = bload4(ra, off4 + 3 * H * 4);
     s.cp = bload4(rc, off1);
     s.go = bload4(rg, off1);
-    s.m = hashed ? drop_value4(rng, (uint32_t)((t * B + b) * H + u0)) : (f32x4){1.f, 1.f, 1.f, 1.f};   // (applied where go is used: a product here would wait for the load)
+    s.m = (f32x4){1.f, 1.f, 1.f, 1.f};             // (applied where go is used: a product here would wait for the load)
+    if (hashed) s.m = drop_value4(rng, (uint32_t)((t * B + b) * H + u0));
   };
   Saved nx = {};
   f32x4 ct = {0.f, 0.f, 0.f, 0.f};
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_narrow_kernel(cons
   const int B = a.B, T = a.T;
   DropRng rng = a.rng;
   const bool hashed = rng.state != nullptr && a.out_drop != nullptr;
-  if (hashed) drop_begin(rng, false), drop_end(rng, false);
+  if (hashed) drop_begin(rng, false);
   const int offg = (b * 4 * H + u) * 4, offh = (b * H + u) * 4;   // byte offsets inside one step's rows
 
   float frag[H];                                  // A operand: row (lane & 3) = gate, of this lane's block = unit; k = 0..H-1
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_narrow_kernel(cons
     for (int q = 0; q < 4; ++q) nxt[q] = bload1(rg, offx + q * H * 4);
   }
   __syncthreads();
-  if (hashed) drop_keys(rng);
+  if (hashed) drop_keys(rng, false);
   pin(nxt);
   int cur = 0;
   float hlast = 0.f;
@@ -373,7 +379,11 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_fwd_narrow_kernel(cons
       bstore1(ra, offg, ai), bstore1(ra, offg + H * 4, af), bstore1(ra, offg + 2 * H * 4, ag), bstore1(ra, offg + 3 * H * 4, ao);
       bstore1(rc, offh, cst);
       bstore1(ro, offh, h);
-      if (hashed) bstore1(step_rows(a.out_drop, t, B, H), offh, h * drop_value(rng, (uint32_t)((t * B + b) * H + u)));
+      {
+        float m = 1.f;
+        if (hashed) m = drop_value(rng, (uint32_t)((t * B + b) * H + u));
+        bstore1(step_rows(a.out_drop, t, B, H), offh, h * m);
+      }
     }
     lds_barrier();
     cur ^= 1;
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(cons
   const int B = a.B, T = a.T;
   DropRng rng = a.rng;
   const bool hashed = rng.state != nullptr;
-  if (hashed) drop_begin(rng, true), drop_end(rng, true);
+  if (hashed) drop_begin(rng, true);
   const int offg = (b * 4 * H + u) * 4, offh = (b * H + u) * 4;
 
   float frag[H];                                  // A operand: row (lane & 3) -> unit 16w + 4ug + (lane & 3); k -> gate row q H + k
@@ -432,9 +442,10 @@ __global__ __launch_bounds__(64 * (H / 16)) void lstm_rec_bwd_narrow_kernel(cons
     for (int j = 0; j < 4; ++j) sv.act[j] = bload1(ra, offg + j * H * 4);
     sv.cp = bload1(rc, offh);
     sv.go = bload1(rg, offh);
-    sv.m = hashed ? drop_value(rng, (uint32_t)((t * B + b) * H + u)) : 1.f;
+    sv.m = 1.f;
+    if (hashed) sv.m = drop_value(rng, (uint32_t)((t * B + b) * H + u));
   };
-  if (hashed) drop_keys(rng);                     // (behind the W_hh staging above)
+  if (hashed) drop_keys(rng, true);                     // (behind the W_hh staging above)
   Saved nx = {};
   float ct = 0.f;
   if (T > 0) {

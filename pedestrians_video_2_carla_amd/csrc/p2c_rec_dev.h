@@ -73,25 +73,27 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {      // "lowbias32" inte
   return x;
 }
 // Two halves: the three state words are REQUESTED at the top of a kernel (drop_begin) and turned into the launch's keys behind its
-// weight staging (drop_keys) -- a memory round trip in front of the first time step otherwise.
+// weight staging (drop_keys), where one thread of the launch also leaves the word the NEXT launch of the stream reads -- from the
+// registers it already has: a load + dependent store of its own at the top of the kernel held workgroup 0 back by a memory round
+// trip, i.e. the whole launch (decoder: + 2 ... 3 us).
 __device__ __forceinline__ void drop_begin(DropRng &r, const bool backward) {
   if (!r.state) return;
   r.k0 = (uint32_t)r.state[0], r.k1 = (uint32_t)r.state[1];
   r.thresh_step = backward ? (uint32_t)r.state[3] - 1u : (uint32_t)r.state[2];
 }
-__device__ __forceinline__ void drop_keys(DropRng &r) {
+__device__ __forceinline__ void drop_keys(DropRng &r, const bool backward) {
   if (!r.state) return;
   const uint32_t s0 = r.k0, s1 = r.k1, step = r.thresh_step;
   r.k0 = mix32(s0 ^ (step * 0x9E3779B9u));
   r.k1 = mix32(s1 + step + 0x85EBCA6Bu * (uint32_t)(r.site + 1));
-}
-__device__ __forceinline__ void drop_end(const DropRng &r, const bool backward) {      // one thread of the launch
-  if (!r.state || blockIdx.x != 0 || threadIdx.x != 0) return;
-  if (backward) r.state[2] = r.state[3];
-  else r.state[3] = r.state[2] + 1;
+  // forward: next = step + 1 (the backward reads it); backward: step = next (the next forward reads it). No launch reads the word
+  // it writes, so the moment of the store does not matter.
+  if (blockIdx.x == 0 && threadIdx.x == 0) r.state[backward ? 2 : 3] = (int32_t)(step + 1u);
 }
 __device__ __forceinline__ float drop_value(const DropRng &r, const uint32_t e) {
-  return mix32(mix32(e + r.k0) ^ r.k1) >= r.thresh ? r.scale : 0.f;
+  // one Fibonacci multiply spreads the element index, the launch key shifts it, one avalanche finaliser: three 32-bit multiplies
+  // on the dependent chain of a time step (two finalisers in a row were four, and ~200 cycles of latency per step)
+  return (mix32(e * 0x9E3779B1u + r.k0) ^ r.k1) >= r.thresh ? r.scale : 0.f;
 }
 __device__ __forceinline__ f32x4 drop_value4(const DropRng &r, const uint32_t e) {
   return (f32x4){drop_value(r, e), drop_value(r, e + 1), drop_value(r, e + 2), drop_value(r, e + 3)};

@@ -120,7 +120,7 @@ template <int KS0>
 __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
   DropRng rng = a.rng;                              // (its state words are requested here, behind nothing; the keys are formed behind the staging)
   const bool hashed = !a.drop && rng.state != nullptr;
-  if (hashed) drop_begin(rng, false), drop_end(rng, false);
+  if (hashed) drop_begin(rng, false);
   extern __shared__ float img[];                    // staging image of one weight matrix at a time
   __shared__ float xT[OMAX * TP], h0T[H * TP], h1T[H * TP];
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -168,11 +168,20 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) xT[(u0 + r) * TP + c] = (a.x0 && ok && u0 + r < O) ? a.x0[(size_t)b * O + u0 + r] : 0.f;
   }
-  if (hashed) drop_keys(rng);
+  if (hashed) drop_keys(rng, false);
   // this step's dropout mask: a row of the caller's mask tensor, or drawn from the element index (t, b, unit)
-  auto mask_of = [&](const int t) -> f32x4 {
-    return hashed ? drop_value4(rng, (uint32_t)((t * B + b) * H + u0)) : bload4(step_rows(a.drop, t, B, H), off1);
+  // This step's dropout mask: a row of the caller's mask tensor (requested in either case -- a NULL tensor has no records and costs
+  // nothing -- so that both forms have the same loads outstanding) AND, drawn from the element index, the hashed one; the choice is
+  // a select where the mask is used. (Written into the LOADED value under a branch, the hash's first instruction re-used the load's
+  // destination register and the compiler put s_waitcnt vmcnt(0) in front of it: every load of the step's prefetch drained at the
+  // top of the step, + 0.4 us per step.)
+  auto mask_of = [&](const int t) -> f32x4 { return bload4(step_rows(a.drop, t, B, H), off1); };
+  auto hash_of = [&](const int t) -> f32x4 {
+    f32x4 m = {1.f, 1.f, 1.f, 1.f};
+    if (hashed) m = drop_value4(rng, (uint32_t)((t * B + b) * H + u0));
+    return m;
   };
+  f32x4 maskh = hash_of(0);
   f32x4 mask = mask_of(0);
   __syncthreads();
   pin(mask);
@@ -180,8 +189,8 @@ __global__ __launch_bounds__(256) void decoder_fwd_kernel(const Args a) {
 
   for (int t = 0; t < T; ++t) {
     f32x4 acc[4], ai, af, ag, ao, h;
-    const f32x4 m = mask;                            // this step's dropout mask was requested one step ahead
-    mask = mask_of((t + 1 < T) ? t + 1 : t);
+    const f32x4 m = hashed ? maskh : mask;           // this step's dropout mask was requested / drawn one step ahead
+    mask = mask_of((t + 1 < T) ? t + 1 : t), maskh = hash_of((t + 1 < T) ? t + 1 : t);
     // teacher forcing: flag and target features of this step, requested now, used behind the fc product (NULL: zeros)
     const float forced = bload1(step_rows(a.force, t, B, 1), b * 4);
     f32x4 tgt;
@@ -247,7 +256,7 @@ template <int KS0>
 __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
   DropRng rng = a.rng;                              // (its state words are requested here, behind nothing; the keys are formed behind the staging)
   const bool hashed = !a.drop && rng.state != nullptr;
-  if (hashed) drop_begin(rng, true), drop_end(rng, true);
+  if (hashed) drop_begin(rng, true);
   extern __shared__ float img[];
   __shared__ float doT[OMAX * TP], dg1T[G4 * TP], dg0T[G4 * TP];
   const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
@@ -281,13 +290,13 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
     offo[r] = (u0 + r < O) ? (b * O + u0 + r) * 4 : OOB;
     offi[r] = (u0 + r < O) ? ((a.g_out_bt ? b * T * O : b * O) + u0 + r) * 4 : OOB;
   }
-  if (hashed) drop_keys(rng);
+  if (hashed) drop_keys(rng, true);
   const bool has_drop = a.drop != nullptr || hashed;
 
   // The rows a step reads (loss gradient, saved gates of both layers, dropout mask) are requested at the top of the previous
   // step and pinned at its end (a round trip to rows of a fresh 8 MB tensor measured longer than one 64-MFMA chain):
   // requested at their use, each of the three groups would put that round trip on the critical path of the step.
-  struct Saved { f32x4 go, a1[4], a0[4], m; float forced; };
+  struct Saved { f32x4 go, a1[4], a0[4], m, mh; float forced; };
   auto fetch = [&](int t, Saved &s) {
     s.forced = bload1(step_rows(a.force, t, B, 1), b * 4);
     const __amdgpu_buffer_rsrc_t rg = a.g_out_bt ? bt_rows(a.g_out, t, B, T, O) : step_rows(a.g_out, t, B, O);
@@ -296,7 +305,9 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
     for (int r = 0; r < 4; ++r) s.go[r] = bload1(rg, offi[r]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) s.a1[q] = bload4(r1, off4 + q * H * 4), s.a0[q] = bload4(r0, off4 + q * H * 4);
-    s.m = hashed ? drop_value4(rng, (uint32_t)((t * B + b) * H + u0)) : bload4(step_rows(a.drop, t, B, H), off1);
+    s.m = bload4(step_rows(a.drop, t, B, H), off1);
+    s.mh = (f32x4){1.f, 1.f, 1.f, 1.f};              // (a value of its own, chosen at the use: see the forward)
+    if (hashed) s.mh = drop_value4(rng, (uint32_t)((t * B + b) * H + u0));
   };
   auto pin_all = [&](Saved &s) {
     pin(s.go), pin(s.m);
@@ -342,7 +353,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_kernel(const Args a) {
       e1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1T[ks + 1], dg1T[(4 * ks + 4 + g) * TP + c], e1, 0, 0, 0);
     }
     dh = e0 + e1;
-    if (has_drop) dh *= sv.m;
+    if (has_drop) dh *= hashed ? sv.mh : sv.m;
     cell_bwd(dh, sv.a0[0], sv.a0[1], sv.a0[2], sv.a0[3], c0r, pi, pf, pg, po, dc0);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -434,7 +445,7 @@ template <int KS0>
 __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
   DropRng rng = a.rng;                              // (its state words are requested here, behind nothing; the keys are formed behind the staging)
   const bool hashed = !a.drop && rng.state != nullptr;
-  if (hashed) drop_begin(rng, false), drop_end(rng, false);
+  if (hashed) drop_begin(rng, false);
   constexpr int K0 = 4 * KS0;
   extern __shared__ float img[];                    // staging image of one weight matrix at a time
   __shared__ __attribute__((aligned(16))) float xs[NS][OP], h0s[NS][HP], h1s[NS][HP];
@@ -488,18 +499,22 @@ __global__ __launch_bounds__(256) void decoder_fwd_narrow_kernel(const Args a) {
   const float c0r = ok ? a.c0[(size_t)b * H + u] : 0.f, c1r = ok ? a.c1[(size_t)b * H + u] : 0.f;
   const float bfc = (u < O) ? a.b_fc[u] : 0.f;
   xs[s][u] = (a.x0 && ok && u < O) ? a.x0[(size_t)b * O + u] : 0.f;    // features >= O stay zero
-  if (hashed) drop_keys(rng);
-  auto mask_of = [&](const int t) -> float {
-    return hashed ? drop_value(rng, (uint32_t)((t * B + b) * H + u)) : bload1(step_rows(a.drop, t, B, H), offh);
+  if (hashed) drop_keys(rng, false);
+  auto mask_of = [&](const int t) -> float { return bload1(step_rows(a.drop, t, B, H), offh); };    // (see decoder_fwd_kernel)
+  auto hash_of = [&](const int t) -> float {
+    float m = 1.f;
+    if (hashed) m = drop_value(rng, (uint32_t)((t * B + b) * H + u));
+    return m;
   };
+  float maskh = hash_of(0);
   float mask = mask_of(0);
   __syncthreads();
   asm volatile("" : "+v"(mask));
   const bool has_drop = a.drop != nullptr || hashed;
 
   for (int t = 0; t < T; ++t) {
-    const float m = mask;
-    mask = mask_of((t + 1 < T) ? t + 1 : t);
+    const float m = hashed ? maskh : mask;
+    mask = mask_of((t + 1 < T) ? t + 1 : t), maskh = hash_of((t + 1 < T) ? t + 1 : t);
     const float forced = bload1(step_rows(a.force, t, B, 1), b * 4);     // teacher forcing (NULL tensors read as zero)
     const float tgt = bload1(step_rows(a.target, t, B, O), offo);
     f32x4 act;
@@ -532,7 +547,7 @@ template <int KS0>
 __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
   DropRng rng = a.rng;                              // (its state words are requested here, behind nothing; the keys are formed behind the staging)
   const bool hashed = !a.drop && rng.state != nullptr;
-  if (hashed) drop_begin(rng, true), drop_end(rng, true);
+  if (hashed) drop_begin(rng, true);
   extern __shared__ float img[];
   __shared__ __attribute__((aligned(16))) float dos[NS][OP], dg1s[NS][GP], dg0s[NS][GP];
   const int lane = threadIdx.x & 63, s = lane & 3, blk = lane >> 2, q = blk & 3;
@@ -559,16 +574,18 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
   const float c0r = ok ? a.c0[(size_t)b * H + u] : 0.f, c1r = ok ? a.c1[(size_t)b * H + u] : 0.f;
   float dc0 = 0.f, dc1 = 0.f, dx = 0.f;
   f32x4 dk0 = zero4(), dk1 = zero4();                // sum_t d gates_l = the gradient of k_l
-  if (hashed) drop_keys(rng);
+  if (hashed) drop_keys(rng, true);
   const bool has_drop = a.drop != nullptr || hashed;
 
-  struct Saved { f32x4 a1, a0; float go, m, forced; };
+  struct Saved { f32x4 a1, a0; float go, m, mh, forced; };
   auto fetch = [&](int t, Saved &sv) {
     sv.forced = bload1(step_rows(a.force, t, B, 1), b * 4);
     sv.go = bload1(a.g_out_bt ? bt_rows(a.g_out, t, B, T, O) : step_rows(a.g_out, t, B, O), offi);
     sv.a1 = load_gates1(step_rows(a.acts1, t, B, G4), offg);
     sv.a0 = load_gates1(step_rows(a.acts0, t, B, G4), offg);
-    sv.m = hashed ? drop_value(rng, (uint32_t)((t * B + b) * H + u)) : bload1(step_rows(a.drop, t, B, H), offh);
+    sv.m = bload1(step_rows(a.drop, t, B, H), offh);
+    sv.mh = 1.f;
+    if (hashed) sv.mh = drop_value(rng, (uint32_t)((t * B + b) * H + u));
   };
   auto pin_all = [&](Saved &sv) {
     pin(sv.a1), pin(sv.a0);
@@ -597,7 +614,7 @@ __global__ __launch_bounds__(256) void decoder_bwd_narrow_kernel(const Args a) {
     lds_barrier();
     // ---- layer-1 input gradient, layer-0 cell
     dh = quarter_product<H>(f1T, dg1s[s] + q * HP, q);
-    if (has_drop) dh *= sv.m;
+    if (has_drop) dh *= hashed ? sv.mh : sv.m;
     p = cell_bwd1(dh, sv.a0, c0r, dc0);
     dk0 += p;
     dg0s[s][u] = p[0], dg0s[s][HP + u] = p[1], dg0s[s][2 * HP + u] = p[2], dg0s[s][3 * HP + u] = p[3];

@@ -410,7 +410,7 @@ def _hash_mask(state, site, p, shape):
     for v in shape:
         n *= v
     e = np.arange(n, dtype=np.uint64)
-    h = mix(mix((e + np.uint64(k0)) & np.uint64(M)) ^ np.uint64(k1))
+    h = mix((e * np.uint64(0x9E3779B1) + np.uint64(k0)) & np.uint64(M)) ^ np.uint64(k1)
     keep = h >= np.uint64(int(p * 4294967296.0))
     return torch.from_numpy((keep.astype(np.float32) * np.float32(1.0 / (1.0 - p))).reshape(shape))
 
