@@ -951,18 +951,14 @@ def joint_embeddings(x: Tensor, weights: Sequence[Tensor], biases: Sequence[Tens
 # ----------------------------------------------------------------------------------------------------------------------
 # dropout masks drawn inside the time-loop kernels (csrc/p2c_rec_dev.h)
 # ----------------------------------------------------------------------------------------------------------------------
-_DROP_INSTANCES = 0
-
-
 def dropout_state(device) -> Tensor:
-    """Four int32 words {seed_lo, seed_hi, step, next} for the kernels that draw their dropout masks themselves. The seed comes
-    from ``torch.initial_seed()`` (what ``torch.manual_seed`` / ``seed_everything`` set), the rank of the process and a
-    per-state counter -- reproducible under a fixed seed, different per rank and per module, and nothing is drawn from the
-    framework's generators (no generator launch, no RNG-state fill in front of a replayed graph)."""
-    global _DROP_INSTANCES
-    _DROP_INSTANCES += 1
+    """Four int32 words {seed_lo, seed_hi, step, next} for the kernels that draw their dropout masks themselves. The seed is ONE
+    draw from the framework's default CPU generator (what ``torch.manual_seed`` / ``seed_everything`` seed) mixed with the rank of
+    the process: a run repeats under a fixed seed, two modules and two ranks draw different masks, and after this one draw
+    nothing comes from the framework's generators (no generator launch, no RNG-state fill in front of a replayed graph)."""
     rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
-    seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03 + _DROP_INSTANCES * 0x94D049BB133111EB) % (1 << 64)
+    draw = int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
+    seed = (draw * 0x9E3779B97F4A7C15 + rank * 0xD1B54A32D192ED03) % (1 << 64)
     lo, hi = seed & 0x7FFFFFFF, (seed >> 32) & 0x7FFFFFFF
     st = torch.tensor([lo, hi, 0, 0], dtype=torch.int32, device=device)
     _DROP_STATES.append(weakref.ref(st))
@@ -980,9 +976,18 @@ def dropout_states_snapshot() -> list:
     return [(t, t.clone()) for t in live if t is not None]
 
 
-def dropout_states_restore(snapshot: list) -> None:
+def dropout_states_restore(snapshot: list, rewind_new: bool = False) -> None:
+    """Put the snapshot's states back; ``rewind_new``: a state created since the snapshot (by a warm-up step of the trainer)
+    goes back to step 0 -- the position it had when its first step drew from it."""
+    known = set()
     for t, saved in snapshot:
         t.copy_(saved)
+        known.add(id(t))
+    if rewind_new:
+        for r in _DROP_STATES:
+            t = r()
+            if t is not None and id(t) not in known:
+                t[2:].zero_()
 
 
 def kernel_dropout_enabled() -> bool:

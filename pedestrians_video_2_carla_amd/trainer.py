@@ -610,6 +610,8 @@ class Trainer:
         # optimizer state is created lazily by the first step: run one throw-away step so every state tensor exists
         # and the snapshot / restore pair can work in place
         params = [t.clone() for t in self._state_tensors(flow)]
+        from pedestrians_video_2_carla_amd import ops
+        self._drop_pre = ops.dropout_states_snapshot()       # the streams of the in-kernel dropout masks belong to the state too
         return params
 
     def _restore(self, flow, snapshot):
@@ -621,6 +623,8 @@ class Trainer:
                 t.zero_()
             if self.flat is not None:
                 self.flat.zero_grad()                    # whatever the warm-up steps left in the gradient buffer
+            from pedestrians_video_2_carla_amd import ops
+            ops.dropout_states_restore(getattr(self, '_drop_pre', []), rewind_new=True)   # replay #1 draws what eager step #1 would
         for m in getattr(self, '_packed', []):           # the parameters were rewritten behind the optimizer's back
             m.repack()
         torch.cuda.synchronize()
