@@ -84,7 +84,8 @@ __device__ __forceinline__ void drop_begin(DropRng &r, const bool backward) {
 __device__ __forceinline__ void drop_keys(DropRng &r, const bool backward) {
   if (!r.state) return;
   const uint32_t s0 = r.k0, s1 = r.k1, step = r.thresh_step;
-  r.k0 = mix32(s0 ^ (step * 0x9E3779B9u));
+  r.k0 = mix32(s0 ^ (step * 0x9E3779B9u) ^ ((uint32_t)(r.site + 1) * 0x632BE59Bu));   // (the site in BOTH keys: with k1 alone two sites' hashes
+                                                                                       // differ by a constant xor -- their masks are dependent)
   r.k1 = mix32(s1 + step + 0x85EBCA6Bu * (uint32_t)(r.site + 1));
   // forward: next = step + 1 (the backward reads it); backward: step = next (the next forward reads it). No launch reads the word
   // it writes, so the moment of the store does not matter.

@@ -383,3 +383,51 @@ def test_stochastic_depth_factors_of_a_stack_come_from_one_draw():
     m.train()
     y = m(torch.randn(3, 9, 26, 2))
     assert y.shape == (3, 1, 26, 3) and torch.isfinite(y).all()
+
+
+def _drop_keep(state, site, p, n):
+    """The mask hash of csrc/p2c_rec_dev.h (drop_keys / drop_value) restated with numpy integers: keep flags of n elements."""
+    M = np.uint64(0xFFFFFFFF)
+
+    def mix(x):
+        x = x.astype(np.uint64)
+        x ^= x >> np.uint64(16)
+        x = (x * np.uint64(0x7feb352d)) & M
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846ca68b)) & M
+        x ^= x >> np.uint64(16)
+        return x
+    s0, s1, step = (int(v) & 0xFFFFFFFF for v in state[:3])
+    k0 = mix(np.array([s0 ^ ((step * 0x9E3779B9) & 0xFFFFFFFF) ^ (((site + 1) * 0x632BE59B) & 0xFFFFFFFF)], dtype=np.uint64))[0]
+    k1 = mix(np.array([(s1 + step + 0x85EBCA6B * (site + 1)) & 0xFFFFFFFF], dtype=np.uint64))[0]
+    e = np.arange(n, dtype=np.uint64)
+    h = mix((e * np.uint64(0x9E3779B1) + k0) & M) ^ k1
+    return h >= np.uint64(int(p * 4294967296.0))
+
+
+def test_in_kernel_dropout_streams_are_seeded_reproducibly_and_draw_independent_masks():
+    """ops.dropout_state (the state of the dropout masks the time-loop kernels draw themselves): one draw from the default CPU
+    generator -- the same state again under the same seed, another one for the next module; and the documented hash behind it
+    (restated here with numpy; the GPU tests hold the kernels to the same restatement bit for bit): keep rate 1 - p, masks of
+    consecutive steps, of two sites and of two seeds uncorrelated, no structure along the element index."""
+    from pedestrians_video_2_carla_amd import ops
+    cpu = torch.device('cpu')
+    torch.manual_seed(123)
+    a, b = ops.dropout_state(cpu).tolist(), ops.dropout_state(cpu).tolist()
+    torch.manual_seed(123)
+    a2 = ops.dropout_state(cpu).tolist()
+    assert a == a2 and a[:2] != b[:2] and a[2:] == [0, 0]
+    n, p = 1 << 18, 0.2
+    sigma = (p * (1 - p) / n) ** 0.5
+    base = _drop_keep(a, 0, p, n)
+    assert abs(base.mean() - (1 - p)) < 4 * sigma
+    others = [_drop_keep(a[:2] + [1, 1], 0, p, n), _drop_keep(a, 1, p, n), _drop_keep(b, 0, p, n)]
+    for other in others:                       # next step / other site / other module: independent of the first mask
+        assert abs(other.mean() - (1 - p)) < 4 * sigma
+        both = (base & other).mean()
+        assert abs(both - (1 - p) ** 2) < 5 * sigma
+    for lag in (1, 2, 64, 64 * 512):            # neighbours along the unit, batch and time axes of a (T, 512, 64) mask
+        both = (base[:-lag] & base[lag:]).mean()
+        assert abs(both - (1 - p) ** 2) < 5 * sigma, lag
+    for p_edge, want in ((0.0, 1.0),):
+        assert _drop_keep(a, 0, p_edge, 1024).mean() == want

@@ -404,7 +404,7 @@ def _hash_mask(state, site, p, shape):
         x ^= x >> np.uint64(16)
         return x
     s0, s1, step = (int(v) & M for v in state[:3])
-    k0 = int(mix(np.array([s0 ^ ((step * 0x9E3779B9) & M)], dtype=np.uint64))[0])
+    k0 = int(mix(np.array([s0 ^ ((step * 0x9E3779B9) & M) ^ (((site + 1) * 0x632BE59B) & M)], dtype=np.uint64))[0])
     k1 = int(mix(np.array([(s1 + step + 0x85EBCA6B * (site + 1)) & M], dtype=np.uint64))[0])
     n = 1
     for v in shape:
